@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric on MI355X.
+
+One "step" = one pass of the hot path over one per-GPU batch of synthetic input:
+  fused FPN RoIAlign forward + backward, P2-P5, 256 ch, 800x1333, N=2 images, 512 RoIs/img, 7x7 bins
+  x 4 samples (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0.  `value` = images/s over all ranks (weak scaling: every rank
+processes its own images; the path has no data-path collective -- RoIs/images are independent,
+SURVEY 8(e)).  `--grad-allreduce MB` additionally overlaps an RCCL all-reduce of an MB-sized fp32
+gradient buffer with every step (the reference's only inter-GPU exchange, detection_train.py:42-43).
+
+roofline: ALGORITHMIC bytes of one forward launch (N*S_F + 16*N*R + 3*N*S_O
+= 335.9 MB at N=2) / the forward kernel's average duration measured with HIP events on the launch
+stream inside the timed region; peak = 8 TB/s HBM3E.  The backward (4 launches, one per level,
+same algorithmic bytes) is reported next to it.
+cpu_baseline: the CPU oracle (oracle/, a port of operator_cxx's arithmetic) timed on the host
+cores on the same workload, rank 0, N=1 only.  It is a reported baseline, not the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--images", type=int, default=2, help="images per GPU (reference: 2)")
+    ap.add_argument("--rois", type=int, default=512)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--grad-allreduce", type=float, default=0.0,
+                    help="MB of fp32 gradients all-reduced (RCCL) per step, overlapped; 0 = off")
+    ap.add_argument("--tuning", action="append", default=[], help="key=value kernel knob (A/B)")
+    ap.add_argument("--extra", action="store_true", help="also time the un-fused 4-op graph path")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(n_img, n_roi, channels, shapes, pooled=49):
+    s_f = 4 * channels * sum(h * w for h, w in shapes)      # every level read (fwd) / written (bwd)
+    s_o = 4 * n_roi * channels * pooled                      # one (R,C,7,7) fp32 tensor per image
+    return n_img * s_f + n_img * n_roi * 16 + 3 * n_img * s_o
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from simpledet_amd import ops, synth
+    from simpledet_amd._lib import lib
+
+    for kv in args.tuning:
+        k, v = kv.split("=")
+        lib().set_tuning(k, int(v))
+
+    strides = list(synth.FPN_STRIDES)
+    shapes = synth.FPN_SHAPES
+    # disjoint synthetic images per rank
+    feats_np = synth.feature_maps(args.seed + 17 * rank, args.images, args.channels, shapes)
+    rois_np = synth.random_rois(args.seed + 17 * rank, args.images, args.rois)
+    feats = [torch.from_numpy(f).cuda() for f in feats_np]
+    rois = torch.from_numpy(rois_np).cuda()
+    out_shape = (args.images, args.rois, args.channels, 7, 7)
+    dy = torch.randn(out_shape, device="cuda")
+    d_feats = [torch.empty_like(f) for f in feats]
+    grad_buf = None
+    comm_stream = None
+    if args.grad_allreduce > 0 and world > 1:
+        grad_buf = torch.randn(int(args.grad_allreduce * 1e6 / 4), device="cuda")
+        comm_stream = torch.cuda.Stream()
+
+    state = {}
+
+    def step(ev=None):
+        if grad_buf is not None:
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                dist.all_reduce(grad_buf)
+        if ev:
+            ev[0].record()
+        out, ax, ay = ops.fpn_roi_align_forward(feats, rois, strides, (7, 7))
+        if ev:
+            ev[1].record()
+        ops.fpn_roi_align_backward(dy, rois, ax, ay, None, strides, d_feats=d_feats)
+        if ev:
+            ev[2].record()
+        if grad_buf is not None:
+            torch.cuda.current_stream().wait_stream(comm_stream)
+        state["out"] = out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    ms_per_step = elapsed * 1e3 / args.steps
+    total_images = args.images * world * args.steps
+    value = total_images / elapsed
+
+    extra = {}
+    if args.extra and rank == 0:
+        # the reference's graph structure through the drop-in per-level ops:
+        # assign -> 4 x ROIAlign_v2 (3 full-size outputs each) -> add_n
+        def graph_step():
+            per, _ = ops.fpn_roi_assign(rois, strides)
+            total = None
+            for f, p, s in zip(feats, per, strides):
+                o, _, _ = ops.roi_align_v2_forward(f, p, (7, 7), 1.0 / s)
+                total = o if total is None else total + o
+            return total
+        for _ in range(3):
+            graph_step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            graph_step()
+        e1.record()
+        torch.cuda.synchronize()
+        extra["unfused_4op_fwd_ms"] = e0.elapsed_time(e1) / 10
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    alg = algorithmic_bytes(args.images, args.rois, args.channels, shapes)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "roi_align_fwd_pmc.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "kernel": "roi_align_fwd_tiled<7,7,8,448> (fused FPN forward, 1 launch/step)",
+        "bound": "hbm",
+        "achieved": alg / (fwd_ms * 1e-3) / 1e9,
+        "peak": PEAK_HBM_GBS,
+        "unit": "GB/s",
+        "frac": alg / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "traffic": traffic,
+        "algorithmic_bytes": alg,
+        "avg_launch_ms": fwd_ms,
+        "backward": {
+            "kernel": "roi_align_bwd_plane (4 launches/step, one per FPN level)",
+            "achieved": alg / (bwd_ms * 1e-3) / 1e9,
+            "frac": alg / (bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "avg_ms": bwd_ms,
+        },
+        "fwd_bwd_frac": 2 * alg / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS,
+    }
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as orc
+        cores = os.cpu_count() or 1
+        dy_np = dy.cpu().numpy()
+        # warm (page in) once, then time a bounded sample: cpu_passes x the same full workload
+        o = orc.fpn_roi_align_fwd(feats_np, rois_np, strides, (7, 7), nthreads=cores)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_passes):
+            o = orc.fpn_roi_align_fwd(feats_np, rois_np, strides, (7, 7), nthreads=cores)
+            orc.fpn_roi_align_bwd(dy_np, rois_np, o[1], o[2], [f.shape for f in feats_np], strides,
+                                  nthreads=cores)
+        cpu_t = time.perf_counter() - t0
+        cpu_baseline = {
+            "value": args.images * args.cpu_passes / cpu_t,
+            "unit": "images/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "%d passes of the same fwd+bwd workload (N=%d, %d RoIs/img) through "
+                      "oracle/liboracle.so, OpenMP over outputs (fwd) / planes (bwd)"
+                      % (args.cpu_passes, args.images, args.rois),
+            "ms_per_step": cpu_t * 1e3 / args.cpu_passes,
+        }
+        # the GPU result of the last step must still match the oracle (cheap sanity, not timed)
+        extra["matches_oracle"] = bool(np.array_equal(state["out"].cpu().numpy(), o[0]))
+
+    line = {
+        "metric": "images/sec at 800x1333 FPN 512-RoI RoIAlign fwd+bwd",
+        "value": value,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "fused FPN RoIAlign_v2 fwd+bwd, P2-P5 %dch 800x1333, N=%d img/GPU, %d RoIs/img, "
+                        "7x7x4 samples (BASELINE configs[1])" % (args.channels, args.images, args.rois),
+            "images_per_gpu": args.images,
+            "rois_per_image": args.rois,
+            "sharding": "images across ranks, no data-path collective"
+                        + (", +%.0f MB grad all-reduce/step" % args.grad_allreduce
+                           if grad_buf is not None else ""),
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+    }
+    line.update(extra)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+// Shared host/device helpers for the simpledet_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+// error codes returned through the C ABI (include/simpledet_ops.h)
+#define SD_OK 0
+#define SD_ERR_INVALID_ARG (-1)
+#define SD_ERR_UNSUPPORTED (-2)
+#define SD_ERR_HIP (-3)
+#define SD_ERR_WORKSPACE (-4)
+
+namespace sd {
+
+// thread-local last-error message, read through sd_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define SD_REQUIRE(cond, ...)                                    \
+  do {                                                           \
+    if (!(cond)) return ::sd::fail(SD_ERR_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define SD_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return ::sd::fail(SD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                            \
+  } while (0)
+
+#define SD_LAUNCH_CHECK() SD_HIP_CHECK(hipGetLastError())
+
+// runtime tuning knobs (A/B of kernel variants from bench.py; defaults are the shipped path)
+int tuning(const char* key, int dflt);
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// mshadow_op::maximum / minimum semantics (a > b ? a : b), kept explicit for NaN parity
+__host__ __device__ static inline float fmaxr(float a, float b) { return a > b ? a : b; }
+__host__ __device__ static inline float fminr(float a, float b) { return a < b ? a : b; }
+__host__ __device__ static inline int imaxr(int a, int b) { return a > b ? a : b; }
+__host__ __device__ static inline int iminr(int a, int b) { return a < b ? a : b; }
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kNumXCD = 8;     // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+constexpr int kNumCU = 256;
+
+}  // namespace sd

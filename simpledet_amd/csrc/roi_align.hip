@@ -1,0 +1,745 @@
+// ROIAlign_v2 forward/backward for gfx950 (MI355X), single level and fused FPN.
+//
+// Semantics follow the reference bit for bit (build with -ffp-contract=off, IEEE divide/sqrt):
+//   forward   operator_cxx/contrib/roi_align_v2-inl.h:61-153 (max over the interior sample grid of
+//             each bin, float argmax (x,y) stored); mixed float/double loop bounds kept (:120-125)
+//   backward  operator_cxx/contrib/roi_align_v2.cu:35-84 (GPU scatter semantics)
+//   assign    models/FPN/assign_layer_fpn.py:17-41
+//
+// MI355X design:
+//  * forward: one workgroup = one RoI x G channels.  The bilinear sample grid is separable: the
+//    rows/columns a RoI touches are two short index lists (<= 4*PH rows, 4*PW cols).  Lanes fill an
+//    LDS tile  tile[c][row][col] = data[c][rowidx[row]][colidx[col]]  with dense, line-friendly
+//    global loads (14 independent loads in flight per lane), then every lane owns one (channel,bin)
+//    output, reads its 16 taps from LDS and writes out/argmax with fully contiguous stores.
+//    Blocks are ordered so that each XCD works on its own channel slice (private-L2 reuse).
+//  * backward: one workgroup = (image, row band, CPB channels) of ONE level.  The gradient plane
+//    lives in LDS (up to 160 KB/CU on CDNA4), RoI bins are scattered into it with LDS float atomics
+//    and the plane is written to HBM exactly once with coalesced 16-B stores: no zero-fill pass, no
+//    global atomics.  (The reference zero-fills dX and issues 4 global atomics per output.)
+//  * naive kernels (one thread per output, the reference's structure) are kept for unusual pooled
+//    sizes, as the in-kernel fallback for degenerate sample loops, and as the A/B baseline.
+#include "common.h"
+#include "../../include/simpledet_ops.h"
+#include <float.h>
+#include <math.h>
+
+namespace sd {
+
+struct RoiLevels {
+  const float* data[SD_MAX_FPN_LEVELS];
+  int H[SD_MAX_FPN_LEVELS], W[SD_MAX_FPN_LEVELS], stride[SD_MAX_FPN_LEVELS];
+  float scale[SD_MAX_FPN_LEVELS];
+  int nlvl;
+  float canon_scale, canon_level, k_min, k_max;
+};
+
+// models/FPN/assign_layer_fpn.py:27-33 in float32; returns level index or -1 (matches no stride)
+__device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2,
+                                         const RoiLevels& L) {
+  float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+  float s = sqrtf(area);
+  float t = floorf(L.canon_level + log2f(s / L.canon_scale + 1e-6f));
+  t = t < L.k_min ? L.k_min : (t > L.k_max ? L.k_max : t);
+  if (!(t == t)) return -1;
+  int ts = ((int)ldexpf(1.f, (int)t)) & 255;  // (2 ** lvl).astype('uint8')
+  int lvl = -1;
+  for (int l = L.nlvl - 1; l >= 0; --l)
+    if (ts == L.stride[l]) lvl = l;
+  return lvl;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact per-element forward (reference structure)
+// ------------------------------------------------------------------------------------------------
+struct FwdOut {
+  float val, ax, ay;
+};
+
+__device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ plane, int height,
+                                                     int width, float x1, float y1, float x2,
+                                                     float y2, float spatial_scale, int ph, int pw,
+                                                     int pooled_height, int pooled_width) {
+  float roi_start_w = x1 * spatial_scale;
+  float roi_start_h = y1 * spatial_scale;
+  float roi_end_w = x2 * spatial_scale;
+  float roi_end_h = y2 * spatial_scale;
+  float roi_width = roi_end_w - roi_start_w;
+  float roi_height = roi_end_h - roi_start_h;
+  float bin_size_h = roi_height / (float)pooled_height;
+  float bin_size_w = roi_width / (float)pooled_width;
+  float hstart = (float)ph * bin_size_h;
+  float wstart = (float)pw * bin_size_w;
+  float hend = (float)(ph + 1) * bin_size_h;
+  float wend = (float)(pw + 1) * bin_size_w;
+  hstart = fminr(fmaxr(hstart + roi_start_h, 0.f), (float)(height - 1));
+  hend = fminr(fmaxr(hend + roi_start_h, 0.f), (float)(height - 1));
+  wstart = fminr(fmaxr(wstart + roi_start_w, 0.f), (float)(width - 1));
+  wend = fminr(fmaxr(wend + roi_start_w, 0.f), (float)(width - 1));
+  bool is_empty = (hend <= hstart) || (wend <= wstart);
+  FwdOut o{0.f, -1.f, -1.f};
+  if (!is_empty) {
+    o.val = -FLT_MAX;
+    float h_stride = (float)((double)(hend - hstart) / 3.0);
+    float w_stride = (float)((double)(wend - wstart) / 3.0);
+    double hlim = (double)(hend - h_stride) + 0.01;
+    double wlim = (double)(wend - w_stride) + 0.01;
+    float hstep = fmaxr(h_stride, 0.01f), wstep = fmaxr(w_stride, 0.01f);
+    for (float h = hstart + h_stride; (double)h <= hlim; h += hstep) {
+      int hlow = iminr(imaxr((int)floorf(h), 0), height - 1);
+      int hhigh = iminr(imaxr((int)ceilf(h), 0), height - 1);
+      float alpha = (hlow == hhigh) ? 0.5f : (h - (float)hlow) / (float)(hhigh - hlow);
+      for (float w = wstart + w_stride; (double)w <= wlim; w += wstep) {
+        int wleft = iminr(imaxr((int)floorf(w), 0), width - 1);
+        int wright = iminr(imaxr((int)ceilf(w), 0), width - 1);
+        float beta = (wleft == wright) ? 0.5f : (w - (float)wleft) / (float)(wright - wleft);
+        float value = (1 - alpha) * (1 - beta) * plane[hlow * width + wleft] +
+                      alpha * (1 - beta) * plane[hhigh * width + wleft] +
+                      (1 - alpha) * beta * plane[hlow * width + wright] +
+                      alpha * beta * plane[hhigh * width + wright];
+        if (value > o.val) {
+          o.val = value;
+          o.ax = w;
+          o.ay = h;
+        }
+      }
+    }
+  }
+  return o;
+}
+
+struct FwdArgs {
+  RoiLevels L;
+  const float* rois;
+  float* out;
+  float* ax;
+  float* ay;
+  int B, C, R, PH, PW;
+  int map;  // block -> (roi, channel group) ordering
+};
+
+__global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
+  const int PP = a.PH * a.PW;
+  const long count = (long)a.B * a.R * a.C * PP;
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < count;
+       index += (long)gridDim.x * blockDim.x) {
+    int pw = (int)(index % a.PW);
+    int ph = (int)((index / a.PW) % a.PH);
+    int c = (int)((index / PP) % a.C);
+    int n = (int)(index / PP / a.C);
+    const float* r = a.rois + (long)n * 4;
+    float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+    int lvl = 0;
+    if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
+    FwdOut o{0.f, -1.f, -1.f};
+    if (lvl >= 0) {
+      int H = a.L.H[lvl], W = a.L.W[lvl];
+      const float* plane = a.L.data[lvl] + ((long)(n / a.R) * a.C + c) * H * W;
+      o = roi_align_fwd_elem(plane, H, W, x1, y1, x2, y2, a.L.scale[lvl], ph, pw, a.PH, a.PW);
+    }
+    if (a.L.nlvl > 1) o.val = o.val + 0.0f;  // add_n with the other levels' zeros
+    a.out[index] = o.val;
+    a.ax[index] = o.ax;
+    a.ay[index] = o.ay;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiled forward
+// ------------------------------------------------------------------------------------------------
+template <int PH, int PW, int G>
+struct FwdSmem {
+  static constexpr int NR = 4 * PH, NC = 4 * PW, CELLS = NR * NC;
+  float tile[G * CELLS];
+  int rowoff[NR];  // row * W, or -1 for an unused slot
+  int coloff[NC];
+  float hval[2 * PH], alpha[2 * PH];
+  float wval[2 * PW], beta[2 * PW];
+  int hcnt[PH], wcnt[PW];
+};
+
+// sample table of one axis bin; returns the number of loop iterations (reference loop, capped at 3)
+__device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, float end_c,
+                                            float scale, int size, int mul, float* val, float* frac,
+                                            int* off) {
+  float roi_start = start_c * scale;
+  float roi_end = end_c * scale;
+  float roi_len = roi_end - roi_start;
+  float bin = roi_len / (float)pooled;
+  float lo = (float)p * bin;
+  float hi = (float)(p + 1) * bin;
+  lo = fminr(fmaxr(lo + roi_start, 0.f), (float)(size - 1));
+  hi = fminr(fmaxr(hi + roi_start, 0.f), (float)(size - 1));
+  int cnt = 0;
+  off[0] = off[1] = off[2] = off[3] = -1;
+  if (!(hi <= lo)) {
+    float stride = (float)((double)(hi - lo) / 3.0);
+    double lim = (double)(hi - stride) + 0.01;
+    float step = fmaxr(stride, 0.01f);
+    for (float v = lo + stride; (double)v <= lim; v += step) {
+      if (cnt < 2) {
+        int low = iminr(imaxr((int)floorf(v), 0), size - 1);
+        int high = iminr(imaxr((int)ceilf(v), 0), size - 1);
+        val[cnt] = v;
+        frac[cnt] = (low == high) ? 0.5f : (v - (float)low) / (float)(high - low);
+        off[2 * cnt] = low * mul;
+        off[2 * cnt + 1] = high * mul;
+      }
+      ++cnt;
+      if (cnt >= 3) break;
+    }
+  }
+  return cnt;
+}
+
+template <int PH, int PW, int G, int THREADS>
+__global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
+  using S = FwdSmem<PH, PW, G>;
+  constexpr int NR = S::NR, NC = S::NC, CELLS = S::CELLS, PP = PH * PW;
+  static_assert(THREADS % NC == 0, "each lane keeps one tile column");
+  __shared__ S s;
+
+  const int tid = threadIdx.x;
+  const int ncg = a.C / G;
+  const int nroi = a.B * a.R;
+  int n, cg;
+  if (a.map == 1) {  // XCD x owns channel groups {x, x+8, ...}: its L2 only ever sees those planes
+    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+    cg = xcd + kNumXCD * (j / nroi);
+    n = j % nroi;
+  } else {
+    n = blockIdx.x / ncg;
+    cg = blockIdx.x % ncg;
+  }
+  const int c0 = cg * G;
+  const float* r = a.rois + (long)n * 4;
+  const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+  int lvl = 0;
+  if (a.L.nlvl > 1) lvl = __builtin_amdgcn_readfirstlane(fpn_level(x1, y1, x2, y2, a.L));
+
+  const long obase = ((long)n * a.C + c0) * PP;
+  if (lvl < 0) {  // assigned to no level: every per-level op sees a zero box
+    for (int e = tid; e < G * PP; e += THREADS) {
+      a.out[obase + e] = 0.f;
+      a.ax[obase + e] = -1.f;
+      a.ay[obase + e] = -1.f;
+    }
+    return;
+  }
+  const int H = a.L.H[lvl], W = a.L.W[lvl];
+  const float scale = a.L.scale[lvl];
+  const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + c0) * H * W;
+
+  // ---- per-RoI sample tables (one lane per axis bin) ----
+  int my_cnt = 0;
+  if (tid < PH) {
+    my_cnt = axis_samples(tid, PH, y1, y2, scale, H, W, &s.hval[2 * tid], &s.alpha[2 * tid],
+                          &s.rowoff[4 * tid]);
+    s.hcnt[tid] = my_cnt;
+  } else if (tid >= kWave && tid < kWave + PW) {
+    const int q = tid - kWave;
+    my_cnt = axis_samples(q, PW, x1, x2, scale, W, 1, &s.wval[2 * q], &s.beta[2 * q],
+                          &s.coloff[4 * q]);
+    s.wcnt[q] = my_cnt;
+  }
+  // a 3-iteration sample loop (stride within an ulp of 0.01) does not fit the 2x2 tile layout
+  const int fallback = __syncthreads_or(my_cnt >= 3);
+
+  if (fallback) {
+    for (int e = tid; e < G * PP; e += THREADS) {
+      const int c = e / PP, bin = e % PP;
+      FwdOut o = roi_align_fwd_elem(base + (long)c * H * W, H, W, x1, y1, x2, y2, scale, bin / PW,
+                                    bin % PW, PH, PW);
+      if (a.L.nlvl > 1) o.val = o.val + 0.0f;
+      a.out[obase + e] = o.val;
+      a.ax[obase + e] = o.ax;
+      a.ay[obase + e] = o.ay;
+    }
+    return;
+  }
+
+  // ---- tile fill: lane keeps its column, walks rows/channels; all loads independent ----
+  {
+    const int co = s.coloff[tid % NC];
+    const long plane = (long)H * W;
+#pragma unroll
+    for (int it = 0; it < (G * CELLS + THREADS - 1) / THREADS; ++it) {
+      const int cell = tid + it * THREADS;
+      if ((G * CELLS) % THREADS == 0 || cell < G * CELLS) {
+        const int c = cell / CELLS;
+        const int ro = s.rowoff[(cell % CELLS) / NC];
+        float v = 0.f;
+        if (ro >= 0 && co >= 0) v = base[c * plane + ro + co];
+        s.tile[cell] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- one lane per (channel, bin): 2x2 samples x 4 taps from LDS, contiguous stores ----
+  for (int e = tid; e < G * PP; e += THREADS) {
+    const int c = e / PP, bin = e % PP, p = bin / PW, q = bin % PW;
+    const int hc = s.hcnt[p], wc = s.wcnt[q];
+    float maxval = 0.f, mx = -1.f, my = -1.f;
+    if (hc > 0 && wc > 0) {
+      maxval = -FLT_MAX;
+      const float* t0 = &s.tile[c * CELLS + (4 * p) * NC + 4 * q];
+      for (int k = 0; k < hc; ++k) {
+        const float alpha = s.alpha[2 * p + k];
+        const float hv = s.hval[2 * p + k];
+        for (int l = 0; l < wc; ++l) {
+          const float beta = s.beta[2 * q + l];
+          const float* t = t0 + (2 * k) * NC + 2 * l;
+          const float2 top = *reinterpret_cast<const float2*>(t);
+          const float2 bot = *reinterpret_cast<const float2*>(t + NC);
+          float value = (1 - alpha) * (1 - beta) * top.x + alpha * (1 - beta) * bot.x +
+                        (1 - alpha) * beta * top.y + alpha * beta * bot.y;
+          if (value > maxval) {
+            maxval = value;
+            mx = s.wval[2 * q + l];
+            my = hv;
+          }
+        }
+      }
+    }
+    if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+    a.out[obase + e] = maxval;
+    a.ax[obase + e] = mx;
+    a.ay[obase + e] = my;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  RoiLevels L;        // data[] unused; used for the level filter
+  const float* dy;
+  const float* ax;
+  const float* ay;
+  const float* rois;
+  float* dx;          // this level's gradient (B,C,H,W)
+  int B, C, R, PP, H, W;
+  float scale;
+  int filter_lvl;     // >= 0: only RoIs assigned to this level contribute (fused FPN); -1: all
+  int band_rows, nbands;
+  int req;            // 1 write, 3 add
+};
+
+// reference structure: zero-fill (by the caller) + 4 global atomics per output element
+__global__ __launch_bounds__(256) void roi_align_bwd_atomic(BwdArgs a) {
+  const long count = (long)a.B * a.R * a.C * a.PP;
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < count;
+       index += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((index / a.PP) % a.C);
+    const int n = (int)(index / a.PP / a.C);
+    if (a.filter_lvl >= 0) {
+      const float* r = a.rois + (long)n * 4;
+      if (fpn_level(r[0], r[1], r[2], r[3], a.L) != a.filter_lvl) continue;
+    }
+    const float a_x = a.ax[index], a_y = a.ay[index];
+    if (a_x != -1.f && a_y != -1.f) {
+      const int H = a.H, W = a.W;
+      float* d = a.dx + ((long)(n / a.R) * a.C + c) * H * W;
+      int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+      int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+      int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+      int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+      float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
+      float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
+      const float g = a.dy[index];
+      atomicAdd(d + hlow * W + wleft, g * (1 - alpha) * (1 - beta));
+      atomicAdd(d + hlow * W + wright, g * (1 - alpha) * beta);
+      atomicAdd(d + hhigh * W + wleft, g * alpha * (1 - beta));
+      atomicAdd(d + hhigh * W + wright, g * alpha * beta);
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One workgroup owns CPB channel planes (rows [row0,row1) of them) of one image in LDS.
+template <int PP, int CPB, int THREADS>
+__global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int H = a.H, W = a.W;
+  const int ncb = a.C / CPB;
+  // block -> (unit = image x band, channel block); channel blocks of one unit are contiguous per XCD
+  int u, cb;
+  if (ncb % kNumXCD == 0) {
+    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD, per = ncb / kNumXCD;
+    cb = xcd * per + (j % per);
+    u = j / per;
+  } else {
+    cb = blockIdx.x % ncb;
+    u = blockIdx.x / ncb;
+  }
+  const int img = u / a.nbands, band = u % a.nbands;
+  const int row0 = band * a.band_rows;
+  const int row1 = iminr(row0 + a.band_rows, H);
+  const int band_elems = (row1 - row0) * W;  // per channel
+  const int c0 = cb * CPB;
+
+  float* plane = smem;                                   // CPB * band_elems (rounded up to 4)
+  const int plane_total = CPB * band_elems;
+  int* list = reinterpret_cast<int*>(smem + ((plane_total + 3) & ~3));  // R entries
+  int* nlist = list + a.R;
+
+  for (int i = tid; i < plane_total; i += THREADS) plane[i] = 0.f;
+  if (tid == 0) *nlist = 0;
+  __syncthreads();
+
+  // ---- RoIs of this image that can touch this band (and belong to this level) ----
+  for (int r = tid; r < a.R; r += THREADS) {
+    const float* rp = a.rois + ((long)img * a.R + r) * 4;
+    const float x1 = rp[0], y1 = rp[1], x2 = rp[2], y2 = rp[3];
+    bool take = true;
+    if (a.filter_lvl >= 0) take = fpn_level(x1, y1, x2, y2, a.L) == a.filter_lvl;
+    if (take && a.nbands > 1) {
+      // conservative row range of every tap of this RoI (taps lie within the clipped bins +-1)
+      float s = fminr(fmaxr(y1 * a.scale, 0.f), (float)(H - 1));
+      float e = fminr(fmaxr(y2 * a.scale, 0.f), (float)(H - 1));
+      float lo = fminr(s, e) - 2.f, hi = fmaxr(s, e) + 2.f;
+      if (hi < (float)row0 || lo > (float)(row1 - 1)) take = false;
+    }
+    if (take) list[atomicAdd(nlist, 1)] = r;
+  }
+  __syncthreads();
+  const int nl = *nlist;
+
+  // ---- scatter bins into the LDS planes ----
+  const long roi_stride = (long)a.C * PP;
+  const long img_base = (long)img * a.R * roi_stride + (long)c0 * PP;
+  for (int it = tid; it < nl * (CPB * PP); it += THREADS) {
+    const int li = it / (CPB * PP), rem = it % (CPB * PP);
+    const long idx = img_base + (long)list[li] * roi_stride + rem;
+    const float a_x = a.ax[idx], a_y = a.ay[idx];
+    const float g = a.dy[idx];  // issued with the argmax loads, not behind the test
+    if (a_x != -1.f && a_y != -1.f) {
+      int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+      int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+      int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+      int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+      float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
+      float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
+      float* pl = plane + (rem / PP) * band_elems;
+      if (hlow >= row0 && hlow < row1) {
+        lds_add(pl + (hlow - row0) * W + wleft, g * (1 - alpha) * (1 - beta));
+        lds_add(pl + (hlow - row0) * W + wright, g * (1 - alpha) * beta);
+      }
+      if (hhigh >= row0 && hhigh < row1) {
+        lds_add(pl + (hhigh - row0) * W + wleft, g * alpha * (1 - beta));
+        lds_add(pl + (hhigh - row0) * W + wright, g * alpha * beta);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- write the band out once; CPB planes are contiguous in HBM when nbands == 1 ----
+  if (a.nbands == 1) {
+    float* dst = a.dx + ((long)img * a.C + c0) * H * W;
+    const long off = ((long)img * a.C + c0) * H * W;
+    if (((off | plane_total) & 3) == 0) {
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      const float4* p4 = reinterpret_cast<const float4*>(plane);
+      for (int i = tid; i < plane_total / 4; i += THREADS) {
+        float4 v = p4[i];
+        if (a.req == SD_REQ_ADD) {
+          float4 o = d4[i];
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        d4[i] = v;
+      }
+    } else {
+      for (int i = tid; i < plane_total; i += THREADS)
+        dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
+    }
+  } else {  // CPB == 1 by construction
+    const long off = (((long)img * a.C + c0) * H + row0) * W;
+    float* dst = a.dx + off;
+    if (((off | band_elems) & 3) == 0) {
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      const float4* p4 = reinterpret_cast<const float4*>(plane);
+      for (int i = tid; i < band_elems / 4; i += THREADS) {
+        float4 v = p4[i];
+        if (a.req == SD_REQ_ADD) {
+          float4 o = d4[i];
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        d4[i] = v;
+      }
+    } else {
+      for (int i = tid; i < band_elems; i += THREADS)
+        dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fpn_assign_kernel(const float* rois, int n_rois,
+                                                         RoiLevels L, float* rois_per_level,
+                                                         int32_t* level) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rois) return;
+  const float* r = rois + (long)i * 4;
+  const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+  const int lvl = fpn_level(x1, y1, x2, y2, L);
+  if (level) level[i] = lvl;
+  if (rois_per_level)
+    for (int l = 0; l < L.nlvl; ++l) {
+      float4 v = (l == lvl) ? make_float4(x1, y1, x2, y2) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(rois_per_level + ((long)l * n_rois + i) * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int fill_levels(RoiLevels& L, const float* const* feats, const int* Hs, const int* Ws,
+                       const int* strides, int nlvl, float canon_scale, float canon_level) {
+  SD_REQUIRE(nlvl >= 1 && nlvl <= SD_MAX_FPN_LEVELS, "nlvl=%d out of range [1,%d]", nlvl,
+             SD_MAX_FPN_LEVELS);
+  int smin = strides[0], smax = strides[0];
+  for (int l = 0; l < nlvl; ++l) {
+    SD_REQUIRE(Hs[l] > 0 && Ws[l] > 0 && strides[l] > 0, "level %d: bad H/W/stride", l);
+    L.data[l] = feats ? feats[l] : nullptr;
+    L.H[l] = Hs[l];
+    L.W[l] = Ws[l];
+    L.stride[l] = strides[l];
+    L.scale[l] = 1.0f / (float)strides[l];
+    if (strides[l] < smin) smin = strides[l];
+    if (strides[l] > smax) smax = strides[l];
+  }
+  L.nlvl = nlvl;
+  L.canon_scale = canon_scale;
+  L.canon_level = canon_level;
+  L.k_min = (float)log2((double)smin);
+  L.k_max = (float)log2((double)smax);
+  return SD_OK;
+}
+
+static int launch_fwd(FwdArgs& a, hipStream_t st) {
+  const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
+  if (count == 0) return SD_OK;
+  const int variant = tuning("roi_align_fwd", 1);  // 0 naive, 1 tiled
+  a.map = tuning("roi_align_fwd_map", 1);
+  const int nroi = a.B * a.R;
+  if (variant == 1 && a.PH == 7 && a.PW == 7 && a.C % 8 == 0) {
+    constexpr int G = 8;
+    if ((a.C / G) % kNumXCD != 0) a.map = 0;
+    hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, G, 448>), dim3(nroi * (a.C / G)), dim3(448), 0,
+                       st, a);
+  } else if (variant == 1 && a.PH == 14 && a.PW == 14 && a.C % 4 == 0) {
+    constexpr int G = 4;
+    if ((a.C / G) % kNumXCD != 0) a.map = 0;
+    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, G, 448>), dim3(nroi * (a.C / G)), dim3(448), 0,
+                       st, a);
+  } else {
+    const int grid = (int)((count + 255) / 256 < 65536 * 16 ? (count + 255) / 256 : 65536 * 16);
+    hipLaunchKernelGGL(roi_align_fwd_naive, dim3(grid), dim3(256), 0, st, a);
+  }
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+template <int PP>
+static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
+  // LDS budget: small planes share a CU between several workgroups; a plane larger than the
+  // budget is cut into row bands of <= 140 KB (one workgroup per CU)
+  const long plane_bytes = (long)a.H * a.W * 4;
+  const long budget = (long)tuning("roi_align_bwd_lds_kb", 72) * 1024;
+  const long maxb = 140 * 1024;
+  int cpb = 1;
+  a.nbands = 1;
+  a.band_rows = a.H;
+  if (plane_bytes <= budget) {
+    for (int c : {8, 4, 2})
+      if (c * plane_bytes <= budget && a.C % c == 0) {
+        cpb = c;
+        break;
+      }
+  } else if (plane_bytes > maxb) {
+    a.nbands = (int)((plane_bytes + maxb - 1) / maxb);
+    a.band_rows = (a.H + a.nbands - 1) / a.nbands;
+    a.nbands = (a.H + a.band_rows - 1) / a.band_rows;
+  }
+  const long band_elems = (long)a.band_rows * a.W;
+  const size_t lds = (size_t)(((cpb * band_elems + 3) & ~3L) + a.R + 4) * 4;
+  SD_REQUIRE(lds <= 160 * 1024, "RoIAlign backward needs %zu B of LDS (R=%d too large)", lds, a.R);
+  const int grid = a.B * a.nbands * (a.C / cpb);
+  const bool big = lds > 80 * 1024;
+#define SD_BWD_LAUNCH(CPB, T)                                                                   \
+  do {                                                                                          \
+    auto k = roi_align_bwd_plane<PP, CPB, T>;                                                   \
+    if (lds > 64 * 1024)                                                                        \
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds));                                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(T), lds, st, a);                                     \
+  } while (0)
+  if (big) {
+    if (cpb == 1) SD_BWD_LAUNCH(1, 1024);
+    else if (cpb == 2) SD_BWD_LAUNCH(2, 1024);
+    else if (cpb == 4) SD_BWD_LAUNCH(4, 1024);
+    else SD_BWD_LAUNCH(8, 1024);
+  } else {
+    if (cpb == 1) SD_BWD_LAUNCH(1, 256);
+    else if (cpb == 2) SD_BWD_LAUNCH(2, 256);
+    else if (cpb == 4) SD_BWD_LAUNCH(4, 256);
+    else SD_BWD_LAUNCH(8, 256);
+  }
+#undef SD_BWD_LAUNCH
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+static int launch_bwd(BwdArgs& a, hipStream_t st) {
+  const long count = (long)a.B * a.R * a.C * a.PP;
+  const size_t dx_bytes = (size_t)a.B * a.C * a.H * a.W * 4;
+  if (dx_bytes == 0) return SD_OK;
+  const int variant = tuning("roi_align_bwd", 1);  // 0 global atomics, 1 LDS planes
+  const size_t list_bytes = (size_t)(a.R + 8) * 4;
+  if (variant == 1 && (a.PP == 49 || a.PP == 196) && list_bytes < 20 * 1024 && count > 0) {
+    return a.PP == 49 ? launch_bwd_plane<49>(a, st) : launch_bwd_plane<196>(a, st);
+  }
+  if (a.req == SD_REQ_WRITE) SD_HIP_CHECK(hipMemsetAsync(a.dx, 0, dx_bytes, st));
+  if (count == 0) return SD_OK;
+  const int grid = (int)((count + 255) / 256 < 65536 * 16 ? (count + 255) / 256 : 65536 * 16);
+  hipLaunchKernelGGL(roi_align_bwd_atomic, dim3(grid), dim3(256), 0, st, a);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+static int check_dims(int B, int C, int R, int ph, int pw) {
+  SD_REQUIRE(B >= 0 && C >= 0 && R >= 0, "negative dimension (B=%d C=%d R=%d)", B, C, R);
+  SD_REQUIRE(ph > 0 && pw > 0, "pooled_size must be nonzero (got %d x %d)", ph, pw);
+  SD_REQUIRE((long)B * R * C * ph * pw < (1L << 31), "output has >= 2^31 elements");
+  return SD_OK;
+}
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" int sd_roi_align_v2_fwd(const float* data, const float* rois, float* out,
+                                   float* maxidx_x, float* maxidx_y, int B, int C, int H, int W,
+                                   int R, int pooled_h, int pooled_w, float spatial_scale,
+                                   void* stream) {
+  if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
+  SD_REQUIRE(H > 0 && W > 0 && (long)H * W < (1L << 30), "bad feature size %d x %d", H, W);
+  SD_REQUIRE(spatial_scale >= 0.f && spatial_scale <= 1.f, "spatial_scale %g outside [0,1]",
+             (double)spatial_scale);
+  SD_REQUIRE((data && rois && out && maxidx_x && maxidx_y) || (long)B * R * C == 0,
+             "null tensor pointer");
+  FwdArgs a{};
+  a.L.nlvl = 1;
+  a.L.data[0] = data;
+  a.L.H[0] = H;
+  a.L.W[0] = W;
+  a.L.stride[0] = 0;
+  a.L.scale[0] = spatial_scale;
+  a.rois = rois; a.out = out; a.ax = maxidx_x; a.ay = maxidx_y;
+  a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
+  return launch_fwd(a, (hipStream_t)stream);
+}
+
+extern "C" int sd_roi_align_v2_bwd(const float* out_grad, const float* rois, const float* maxidx_x,
+                                   const float* maxidx_y, float* d_data, float* d_rois,
+                                   int req_data, int req_rois, int B, int C, int H, int W, int R,
+                                   int pooled_h, int pooled_w, float spatial_scale, void* stream) {
+  if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
+  SD_REQUIRE(H > 0 && W > 0 && (long)H * W < (1L << 30), "bad feature size %d x %d", H, W);
+  SD_REQUIRE(req_data == SD_REQ_NULL || req_data == SD_REQ_WRITE || req_data == SD_REQ_ADD,
+             "ROIAlign: Backward doesn't support req_data=%d (kWriteInplace)", req_data);
+  SD_REQUIRE(req_rois == SD_REQ_NULL || req_rois == SD_REQ_WRITE || req_rois == SD_REQ_ADD,
+             "ROIAlign: Backward doesn't support req_rois=%d (kWriteInplace)", req_rois);
+  hipStream_t st = (hipStream_t)stream;
+  if (req_data != SD_REQ_NULL) {
+    SD_REQUIRE(d_data && ((out_grad && maxidx_x && maxidx_y && rois) || (long)B * R * C == 0),
+               "null tensor pointer");
+    BwdArgs a{};
+    a.L.nlvl = 1;
+    a.dy = out_grad; a.ax = maxidx_x; a.ay = maxidx_y; a.rois = rois; a.dx = d_data;
+    a.B = B; a.C = C; a.R = R; a.PP = pooled_h * pooled_w; a.H = H; a.W = W;
+    a.scale = spatial_scale;
+    a.filter_lvl = -1;
+    a.req = req_data;
+    if (int e = launch_bwd(a, st)) return e;
+  }
+  if (req_rois == SD_REQ_WRITE && (long)B * R > 0) {  // roi_align_v2.cu:139-141
+    SD_REQUIRE(d_rois, "d_rois is null but req_rois == write");
+    SD_HIP_CHECK(hipMemsetAsync(d_rois, 0, (size_t)B * R * 4 * sizeof(float), st));
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_fpn_roi_align_fwd(const float* const* feats_host, const int* Hs_host,
+                                    const int* Ws_host, const int* strides_host, int nlvl,
+                                    const float* rois, float* out, float* maxidx_x,
+                                    float* maxidx_y, int B, int C, int R, int pooled_h,
+                                    int pooled_w, float roi_canonical_scale,
+                                    float roi_canonical_level, void* stream) {
+  if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
+  SD_REQUIRE(feats_host && Hs_host && Ws_host && strides_host, "null level description");
+  FwdArgs a{};
+  if (int e = fill_levels(a.L, feats_host, Hs_host, Ws_host, strides_host, nlvl,
+                          roi_canonical_scale, roi_canonical_level))
+    return e;
+  for (int l = 0; l < nlvl; ++l) SD_REQUIRE(feats_host[l] || (long)B * C == 0, "feats[%d] null", l);
+  if (nlvl == 1) a.L.nlvl = 2, a.L.stride[1] = -1;  // keep the assignment filter on (1-level FPN)
+  a.rois = rois; a.out = out; a.ax = maxidx_x; a.ay = maxidx_y;
+  a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
+  return launch_fwd(a, (hipStream_t)stream);
+}
+
+extern "C" int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois,
+                                    const float* maxidx_x, const float* maxidx_y,
+                                    float* const* d_feats_host, const int* Hs_host,
+                                    const int* Ws_host, const int* strides_host, int nlvl,
+                                    int req_data, int B, int C, int R, int pooled_h, int pooled_w,
+                                    float roi_canonical_scale, float roi_canonical_level,
+                                    void* stream) {
+  if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
+  SD_REQUIRE(d_feats_host && Hs_host && Ws_host && strides_host, "null level description");
+  SD_REQUIRE(req_data == SD_REQ_NULL || req_data == SD_REQ_WRITE || req_data == SD_REQ_ADD,
+             "ROIAlign: Backward doesn't support req_data=%d (kWriteInplace)", req_data);
+  if (req_data == SD_REQ_NULL) return SD_OK;
+  BwdArgs a{};
+  if (int e = fill_levels(a.L, nullptr, Hs_host, Ws_host, strides_host, nlvl, roi_canonical_scale,
+                          roi_canonical_level))
+    return e;
+  if (nlvl == 1) a.L.nlvl = 2, a.L.stride[1] = -1;
+  a.dy = out_grad; a.ax = maxidx_x; a.ay = maxidx_y; a.rois = rois;
+  a.B = B; a.C = C; a.R = R; a.PP = pooled_h * pooled_w;
+  a.req = req_data;
+  for (int l = 0; l < nlvl; ++l) {
+    SD_REQUIRE(d_feats_host[l] || (long)B * C == 0, "d_feats[%d] null", l);
+    a.dx = d_feats_host[l];
+    a.H = Hs_host[l];
+    a.W = Ws_host[l];
+    a.scale = a.L.scale[l];
+    a.filter_lvl = l;
+    if (int e = launch_bwd(a, (hipStream_t)stream)) return e;
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_fpn_roi_assign(const float* rois, int n_rois, const int* strides_host, int nlvl,
+                                 float roi_canonical_scale, float roi_canonical_level,
+                                 float* rois_per_level, int32_t* level, void* stream) {
+  SD_REQUIRE(n_rois >= 0, "n_rois < 0");
+  SD_REQUIRE(strides_host, "strides null");
+  RoiLevels L{};
+  int ones[SD_MAX_FPN_LEVELS];
+  for (int l = 0; l < SD_MAX_FPN_LEVELS; ++l) ones[l] = 1;
+  if (int e = fill_levels(L, nullptr, ones, ones, strides_host, nlvl, roi_canonical_scale,
+                          roi_canonical_level))
+    return e;
+  if (n_rois == 0) return SD_OK;
+  SD_REQUIRE(rois, "rois null");
+  hipLaunchKernelGGL(fpn_assign_kernel, dim3(cdiv(n_rois, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rois, n_rois, L, rois_per_level, level);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}

@@ -1,0 +1,76 @@
+// Error reporting, ABI version and tuning knobs of libsimpledet_ops_hip.so.
+#include "common.h"
+#include "../../include/simpledet_ops.h"
+#include <mutex>
+#include <string.h>
+
+namespace sd {
+
+char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+struct Knob {
+  const char* key;
+  int value;
+  bool set;
+};
+// every knob a kernel launcher reads must be listed here (sd_set_tuning rejects unknown keys)
+Knob g_knobs[] = {
+    {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default)
+    {"roi_align_fwd_map", 0, false},     // 0 roi-major, 1 XCD-owns-channel-slice (default)
+    {"roi_align_bwd", 0, false},         // 0 global atomics, 1 LDS planes (default)
+    {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup for small planes
+    {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes (default)
+    {"nms_scan", 0, false},              // 0 single-wave scan, 1 (default) block scan
+    {"soft_nms_threads", 0, false},
+    {"proposal_target_shuffle", 0, false},
+    {"deform_gemm", 0, false},
+};
+std::mutex g_mu;
+}  // namespace
+
+int tuning(const char* key, int dflt) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& k : g_knobs)
+    if (!strcmp(k.key, key)) return k.set ? k.value : dflt;
+  return dflt;
+}
+
+}  // namespace sd
+
+extern "C" const char* sd_last_error(void) { return sd::err_buf(); }
+extern "C" int sd_abi_version(void) { return 1; }
+
+extern "C" int sd_set_tuning(const char* key, int value) {
+  if (!key) return sd::fail(SD_ERR_INVALID_ARG, "null tuning key");
+  std::lock_guard<std::mutex> lk(sd::g_mu);
+  for (auto& k : sd::g_knobs)
+    if (!strcmp(k.key, key)) {
+      k.value = value;
+      k.set = true;
+      return SD_OK;
+    }
+  return sd::fail(SD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
+}
+
+extern "C" int sd_get_tuning(const char* key, int* value) {
+  if (!key || !value) return sd::fail(SD_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(sd::g_mu);
+  for (auto& k : sd::g_knobs)
+    if (!strcmp(k.key, key)) {
+      *value = k.set ? k.value : -1;
+      return SD_OK;
+    }
+  return sd::fail(SD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
+}

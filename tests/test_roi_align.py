@@ -1,0 +1,294 @@
+"""ROIAlign_v2 / fused FPN RoIAlign: oracle self-checks (CPU) and HIP-vs-oracle parity (GPU).
+
+Reference: operator_cxx/contrib/roi_align_v2{-inl.h,.cc,.cu}, models/FPN/builder.py:567-610.
+Bars: forward is compared BIT-EXACTLY (values and float argmax; both sides are built with
+-ffp-contract=off and IEEE divide), backward within 1e-4 (north_star tolerance; summation order of
+the scatter differs).
+"""
+import numpy as np
+import pytest
+
+from simpledet_amd import synth
+
+from . import pyref
+
+STRIDES = list(synth.FPN_STRIDES)
+
+
+def small_case(seed, B=2, C=3, H=13, W=17, R=9, stride=16):
+    rs = np.random.RandomState(seed)
+    data = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    rois = synth.random_rois(seed, B, R, H * stride, W * stride, degenerate=False,
+                             min_size=8, max_size=200)
+    d = synth.degenerate_rois(H * stride, W * stride)
+    rois[0, :4] = d[[0, 1, 2, 7]]
+    rois[1, :3] = d[[3, 8, 9]]
+    return data, rois
+
+
+# ------------------------------------------------------------------------------------------ CPU --
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_matches_python_restatement(oracle, seed):
+    data, rois = small_case(seed)
+    o, ax, ay = oracle.roi_align_v2_fwd(data, rois, (7, 7), 1 / 16.0)
+    po, pax, pay = pyref.roi_align_v2_fwd(data, rois, (7, 7), 1 / 16.0)
+    np.testing.assert_array_equal(o, po)
+    np.testing.assert_array_equal(ax, pax)
+    np.testing.assert_array_equal(ay, pay)
+
+
+def test_oracle_empty_and_degenerate_bins(oracle):
+    data, rois = small_case(3)
+    o, ax, ay = oracle.roi_align_v2_fwd(data, rois, (7, 7), 1 / 16.0)
+    # zero box / outside / inverted boxes pool nothing: value 0, argmax -1
+    for b, r in [(0, 0), (0, 1), (1, 0), (1, 1)]:
+        assert np.all(o[b, r] == 0) and np.all(ax[b, r] == -1) and np.all(ay[b, r] == -1)
+    # a pooled bin stores the float coordinates of its arg-max sample inside the feature map
+    v = ax != -1
+    assert v.any()
+    assert ax[v].min() >= 0 and ax[v].max() <= data.shape[3] - 1
+    assert ay[v].min() >= 0 and ay[v].max() <= data.shape[2] - 1
+    assert np.all((ax == -1) == (ay == -1))
+
+
+def test_oracle_backward_is_adjoint_of_forward_selection(oracle):
+    """dX.sum() == sum of dY over pooled bins (bilinear weights sum to 1)."""
+    data, rois = small_case(4)
+    o, ax, ay = oracle.roi_align_v2_fwd(data, rois, (7, 7), 1 / 16.0)
+    dy = np.random.RandomState(0).standard_normal(o.shape).astype(np.float32)
+    dx = oracle.roi_align_v2_bwd(dy, ax, ay, data.shape)
+    np.testing.assert_allclose(dx.sum(dtype=np.float64), dy[ax != -1].sum(dtype=np.float64),
+                               rtol=1e-4, atol=1e-3)
+    # kAddTo accumulates on top of the existing gradient
+    dx2 = oracle.roi_align_v2_bwd(dy, ax, ay, data.shape, req=3, dx=dx.copy())
+    np.testing.assert_allclose(dx2, 2 * dx, rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_cpu_gather_backward_diverges_on_degenerate_bins(oracle):
+    """the reference's CPU backward is NOT the spec (the GPU scatter is).  On a
+    RoI whose samples sit exactly on integer rows (hlow == hhigh) the CPU if/else-if chain drops
+    half of the gradient; on ordinary RoIs the two agree."""
+    rs = np.random.RandomState(0)
+    data = rs.standard_normal((1, 1, 12, 12)).astype(np.float32)
+    ok = np.array([[[17.3, 20.9, 130.2, 150.4]]], np.float32)
+    o, ax, ay = oracle.roi_align_v2_fwd(data, ok, (7, 7), 1 / 16.0)
+    dy = np.ones_like(o)
+    g = oracle.roi_align_v2_bwd(dy, ax, ay, data.shape)
+    c = oracle.roi_align_v2_bwd_cpu_gather(dy, ok, ax, ay, data.shape, 1 / 16.0)
+    np.testing.assert_allclose(g, c, rtol=1e-5, atol=1e-6)
+    # integer-aligned samples: 21 px tall bins of 3 px -> samples at integer + {1, 2}
+    al = np.array([[[16.0, 16.0, 16.0 + 21 * 16, 16.0 + 21 * 16]]], np.float32)
+    data2 = rs.standard_normal((1, 1, 40, 40)).astype(np.float32)
+    o, ax, ay = oracle.roi_align_v2_fwd(data2, al, (7, 7), 1 / 16.0)
+    assert np.all(ay == np.floor(ay)) and np.all(ax == np.floor(ax))
+    dy = np.ones_like(o)
+    g = oracle.roi_align_v2_bwd(dy, ax, ay, data2.shape)
+    c = oracle.roi_align_v2_bwd_cpu_gather(dy, al, ax, ay, data2.shape, 1 / 16.0)
+    assert abs(g.sum() - 49.0) < 1e-3          # spec: all of dY arrives
+    assert c.sum() < 0.6 * g.sum()             # CPU gather drops the duplicate-corner terms
+
+
+def test_oracle_fpn_assign_levels(oracle):
+    # sqrt(area) = 224 -> level 4 (stride 16); 112 -> 3 (stride 8); tiny -> stride 4; huge -> 32
+    def box(s):
+        return [10, 10, 10 + s - 1, 10 + s - 1]
+    rois = np.array([[box(224), box(112), box(20), box(1000), box(447), box(449), [5, 5, 1, 1],
+                      [0, 0, 0, 0]]], np.float32)
+    per, lvl = oracle.fpn_roi_assign(rois, STRIDES)
+    assert lvl.tolist() == [[2, 1, 0, 3, 2, 3, 0, 0]]
+    for l in range(4):
+        m = lvl[0] == l
+        np.testing.assert_array_equal(per[l][0][m], rois[0][m])
+        assert np.all(per[l][0][~m] == 0)
+    # negative area -> sqrt = nan -> matches no stride (all outputs zero)
+    _, lvl = oracle.fpn_roi_assign(np.array([[[50, 50, 10, 200]]], np.float32), STRIDES)
+    assert lvl.tolist() == [[-1]]
+
+
+def test_oracle_fpn_equals_assigned_level(oracle):
+    feats = synth.feature_maps(0, batch=1, channels=2)
+    rois = synth.random_rois(5, 1, 24)
+    out, ax, ay = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (7, 7))
+    _, lvl = oracle.fpn_roi_assign(rois, STRIDES)
+    for l, s in enumerate(STRIDES):
+        o, x, y = oracle.roi_align_v2_fwd(feats[l], rois, (7, 7), 1.0 / s)
+        m = lvl[0] == l
+        np.testing.assert_array_equal(out[0][m], o[0][m] + np.float32(0))
+        np.testing.assert_array_equal(ax[0][m], x[0][m])
+        np.testing.assert_array_equal(ay[0][m], y[0][m])
+
+
+# ------------------------------------------------------------------------------------------ GPU --
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _assert_bwd_close(got, want, tol=1e-4):
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= tol * scale, "max abs err %g (scale %g)" % (err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("case", ["small", "c4", "p2", "mask14", "odd_pool"])
+def test_single_level_forward_bit_exact(ops, oracle, case, variant):
+    from simpledet_amd._lib import lib
+    lib().set_tuning("roi_align_fwd", variant)
+    try:
+        if case == "small":
+            data, rois = small_case(0, C=8)
+            pooled, scale = (7, 7), 1 / 16.0
+        elif case == "c4":   # single-level C4 family (config/faster_r50v1c4_c5_512roi_1x.py)
+            data = synth.feature_maps(1, 2, 64, ((50, 84),))[0]
+            rois = synth.random_rois(1, 2, 128)
+            pooled, scale = (7, 7), 1 / 16.0
+        elif case == "p2":   # large RoIs on the finest level: sparse sample grid
+            data = synth.feature_maps(2, 1, 16, ((200, 334),))[0]
+            rois = synth.random_rois(2, 1, 96)
+            pooled, scale = (7, 7), 1 / 4.0
+        elif case == "mask14":
+            data = synth.feature_maps(3, 1, 8, ((50, 84),))[0]
+            rois = synth.random_rois(3, 1, 64)
+            pooled, scale = (14, 14), 1 / 16.0
+        else:                # generic pooled size -> naive kernel
+            data = synth.feature_maps(4, 1, 5, ((25, 42),))[0]
+            rois = synth.random_rois(4, 1, 40)
+            pooled, scale = (3, 5), 1 / 32.0
+        want = oracle.roi_align_v2_fwd(data, rois, pooled, scale, nthreads=8)
+        got = ops.roi_align_v2_forward(_t(data), _t(rois), pooled, scale)
+        for g, w, name in zip(got, want, ("output", "maxidx_x", "maxidx_y")):
+            np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=name)
+    finally:
+        lib().set_tuning("roi_align_fwd", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("case", ["small", "p2_bands", "c4", "mask14", "odd_pool"])
+def test_single_level_backward(ops, oracle, case, variant):
+    from simpledet_amd._lib import lib
+    lib().set_tuning("roi_align_bwd", variant)
+    try:
+        if case == "small":
+            data, rois = small_case(0, C=8)
+            pooled, scale = (7, 7), 1 / 16.0
+        elif case == "p2_bands":   # plane larger than LDS -> row bands
+            data = synth.feature_maps(2, 2, 8, ((200, 334),))[0]
+            rois = synth.random_rois(2, 2, 96)
+            pooled, scale = (7, 7), 1 / 4.0
+        elif case == "c4":
+            data = synth.feature_maps(1, 2, 64, ((50, 84),))[0]
+            rois = synth.random_rois(1, 2, 128)
+            pooled, scale = (7, 7), 1 / 16.0
+        elif case == "mask14":
+            data = synth.feature_maps(3, 1, 8, ((50, 84),))[0]
+            rois = synth.random_rois(3, 1, 64)
+            pooled, scale = (14, 14), 1 / 16.0
+        else:
+            data = synth.feature_maps(4, 1, 5, ((25, 42),))[0]
+            rois = synth.random_rois(4, 1, 40)
+            pooled, scale = (3, 5), 1 / 32.0
+        o, ax, ay = oracle.roi_align_v2_fwd(data, rois, pooled, scale, nthreads=8)
+        dy = np.random.RandomState(7).standard_normal(o.shape).astype(np.float32)
+        want = oracle.roi_align_v2_bwd(dy, ax, ay, data.shape)
+        got, d_rois = ops.roi_align_v2_backward(_t(dy), _t(rois), _t(ax), _t(ay), data.shape, scale)
+        _assert_bwd_close(got.cpu().numpy(), want)
+        assert d_rois.shape == rois.shape and float(d_rois.abs().max()) == 0.0
+        # kAddTo on top of a non-zero gradient (roi_align_v2.cu:130-133)
+        import torch
+        base = np.random.RandomState(8).standard_normal(data.shape).astype(np.float32)
+        acc = _t(base)
+        ops.roi_align_v2_backward(_t(dy), _t(rois), _t(ax), _t(ay), data.shape, scale,
+                                  req_data="add", req_rois="null", d_data=acc)
+        torch.cuda.synchronize()
+        _assert_bwd_close(acc.cpu().numpy(), want + base)
+    finally:
+        lib().set_tuning("roi_align_bwd", 1)
+
+
+@pytest.mark.gpu
+def test_backward_rejects_write_inplace(ops):
+    import torch
+    from simpledet_amd._lib import SimpleDetOpsError
+    z = torch.zeros((1, 1, 1, 7, 7), device="cuda")
+    r = torch.zeros((1, 1, 4), device="cuda")
+    with pytest.raises(SimpleDetOpsError, match="kWriteInplace"):
+        ops.roi_align_v2_backward(z, r, z, z, (1, 1, 8, 8), 0.25, req_data=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rois_kind", ["random", "balanced"])
+def test_fpn_fused_forward_backward_small(ops, oracle, rois_kind):
+    feats = synth.feature_maps(0, batch=2, channels=16)
+    rois = (synth.random_rois(1, 2, 64) if rois_kind == "random"
+            else synth.level_balanced_rois(1, 2, 16))
+    want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (7, 7), nthreads=8)
+    tf = [_t(f) for f in feats]
+    got = ops.fpn_roi_align_forward(tf, _t(rois), STRIDES, (7, 7))
+    for g, w, name in zip(got, want, ("output", "maxidx_x", "maxidx_y")):
+        np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=name)
+    dy = np.random.RandomState(3).standard_normal(want[0].shape).astype(np.float32)
+    wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], [f.shape for f in feats], STRIDES)
+    gd = ops.fpn_roi_align_backward(_t(dy), _t(rois), got[1], got[2], [f.shape for f in feats],
+                                    STRIDES)
+    for g, w in zip(gd, wd):
+        _assert_bwd_close(g.cpu().numpy(), w)
+
+
+@pytest.mark.gpu
+def test_fpn_fused_equals_reference_graph_of_four_ops(ops, oracle):
+    """The fused op == fpn_roi_assign -> 4 x ROIAlign_v2 -> add_n (models/FPN/builder.py:573-605),
+    all on the GPU through the drop-in per-level ops."""
+    import torch
+    feats = [_t(f) for f in synth.feature_maps(5, batch=2, channels=16)]
+    rois = _t(synth.random_rois(6, 2, 64))
+    per, level = ops.fpn_roi_assign(rois, STRIDES)
+    _, olvl = oracle.fpn_roi_assign(rois.cpu().numpy(), STRIDES)
+    np.testing.assert_array_equal(level.cpu().numpy(), olvl)
+    total = None
+    for f, p, s in zip(feats, per, STRIDES):
+        o, _, _ = ops.roi_align_v2_forward(f, p.contiguous(), (7, 7), 1.0 / s)
+        total = o if total is None else total + o
+    fused, _, _ = ops.fpn_roi_align_forward(feats, rois, STRIDES, (7, 7))
+    assert torch.equal(fused, total)
+
+
+@pytest.mark.gpu
+def test_fpn_full_size_baseline_config(ops, oracle):
+    """BASELINE config: P2-P5, 256 ch, 800x1333, N=2, 512 RoIs/img, 7x7 -- bit-exact forward,
+    1e-4 backward, at full size (the CPU oracle needs a few seconds on 8 cores)."""
+    import torch
+    feats = synth.feature_maps(0)
+    rois = synth.random_rois(0)
+    want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (7, 7), nthreads=8)
+    tf = [_t(f) for f in feats]
+    got = ops.fpn_roi_align_forward(tf, _t(rois), STRIDES, (7, 7))
+    for g, w, name in zip(got, want, ("output", "maxidx_x", "maxidx_y")):
+        np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=name)
+    dy = np.random.RandomState(11).standard_normal(want[0].shape).astype(np.float32)
+    wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], [f.shape for f in feats], STRIDES)
+    gd = ops.fpn_roi_align_backward(_t(dy), _t(rois), got[1], got[2], [f.shape for f in feats],
+                                    STRIDES)
+    for g, w in zip(gd, wd):
+        _assert_bwd_close(g.cpu().numpy(), w)
+    # size-independent property: every pooled bin's gradient mass arrives exactly once
+    mass = sum(float(g.double().sum()) for g in gd)
+    want_mass = float(dy[want[1] != -1].astype(np.float64).sum())
+    assert abs(mass - want_mass) <= 1e-3 * max(1.0, abs(want_mass))
+    # the naive (reference-structure) kernels agree with the tiled/LDS ones
+    from simpledet_amd._lib import lib
+    lib().set_tuning("roi_align_fwd", 0)
+    lib().set_tuning("roi_align_bwd", 0)
+    try:
+        got0 = ops.fpn_roi_align_forward(tf, _t(rois), STRIDES, (7, 7))
+        for a, b in zip(got, got0):
+            assert torch.equal(a, b)
+        gd0 = ops.fpn_roi_align_backward(_t(dy), _t(rois), got[1], got[2],
+                                         [f.shape for f in feats], STRIDES)
+        for g, w in zip(gd0, wd):
+            _assert_bwd_close(g.cpu().numpy(), w)
+    finally:
+        lib().set_tuning("roi_align_fwd", 1)
+        lib().set_tuning("roi_align_bwd", 1)
