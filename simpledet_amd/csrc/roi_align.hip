@@ -115,7 +115,7 @@ struct FwdArgs {
   float* ax;
   float* ay;
   int B, C, R, PH, PW;
-  int map;  // block -> (roi, channel group) ordering
+  int nslice;  // channel slices per RoI (one workgroup each)
 };
 
 __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
@@ -147,18 +147,29 @@ __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // tiled forward
 // ------------------------------------------------------------------------------------------------
+// One workgroup = one RoI x a slice of the channels, processed G channels at a time.
+//   tables   (once per workgroup) axis sample lists -> row/col offsets; per (bin,k,l) the four
+//            bilinear weight products and the sample coordinates, shared by every channel
+//   pipeline for each group of G channels: the NEXT group's tile is loaded into registers
+//            (ITER independent global loads per lane) while the CURRENT group is computed out of
+//            LDS and stored; one LDS tile, two barriers per group
 template <int PH, int PW, int G>
 struct FwdSmem {
-  static constexpr int NR = 4 * PH, NC = 4 * PW, CELLS = NR * NC;
+  static constexpr int NR = 4 * PH, NC = 4 * PW, CELLS = NR * NC, PP = PH * PW;
   float tile[G * CELLS];
-  int rowoff[NR];  // row * W, or -1 for an unused slot
+  float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab   (kl = 2k + l)
+  float2 coord[4 * PP];   // [kl][bin]: (w, h) of the sample
+  int rowoff[NR];         // row * W, or -1 for an unused slot
   int coloff[NC];
   float hval[2 * PH], alpha[2 * PH];
   float wval[2 * PW], beta[2 * PW];
-  int hcnt[PH], wcnt[PW];
+  int hcnt[PH], wcnt[PW];  // -1: empty axis bin (end <= start); else sample-loop iterations
+  int binflag[PP];         // 1: the bin pools something (reference !is_empty)
 };
 
 // sample table of one axis bin; returns the number of loop iterations (reference loop, capped at 3)
+// (float)((double)x / 3.0) == x / 3.0f exactly (double rounding is innocuous for one IEEE division
+// when the wide format has >= 2p+2 bits), so the stride uses the float divide.
 __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, float end_c,
                                             float scale, int size, int mul, float* val, float* frac,
                                             int* off) {
@@ -170,10 +181,11 @@ __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, fl
   float hi = (float)(p + 1) * bin;
   lo = fminr(fmaxr(lo + roi_start, 0.f), (float)(size - 1));
   hi = fminr(fmaxr(hi + roi_start, 0.f), (float)(size - 1));
-  int cnt = 0;
+  int cnt = -1;
   off[0] = off[1] = off[2] = off[3] = -1;
   if (!(hi <= lo)) {
-    float stride = (float)((double)(hi - lo) / 3.0);
+    cnt = 0;
+    float stride = (hi - lo) / 3.0f;
     double lim = (double)(hi - stride) + 0.01;
     float step = fmaxr(stride, 0.01f);
     for (float v = lo + stride; (double)v <= lim; v += step) {
@@ -196,30 +208,27 @@ template <int PH, int PW, int G, int THREADS>
 __global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
   using S = FwdSmem<PH, PW, G>;
   constexpr int NR = S::NR, NC = S::NC, CELLS = S::CELLS, PP = PH * PW;
-  static_assert(THREADS % NC == 0, "each lane keeps one tile column");
+  constexpr int RPI = THREADS / NC;                 // tile rows filled per iteration
+  constexpr int ITER = (G * NR) / RPI;              // loads per lane per channel group
+  static_assert(THREADS % NC == 0 && (G * NR) % RPI == 0, "tile fill must divide evenly");
   __shared__ S s;
 
   const int tid = threadIdx.x;
-  const int ncg = a.C / G;
-  const int nroi = a.B * a.R;
-  int n, cg;
-  if (a.map == 1) {  // XCD x owns channel groups {x, x+8, ...}: its L2 only ever sees those planes
-    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
-    cg = xcd + kNumXCD * (j / nroi);
-    n = j % nroi;
-  } else {
-    n = blockIdx.x / ncg;
-    cg = blockIdx.x % ncg;
-  }
-  const int c0 = cg * G;
+  // block -> (roi, channel slice).  Consecutive blocks are the slices of one RoI, so with
+  // nslice a multiple/divisor of 8 every XCD (block b runs on XCD b % 8) only ever touches its
+  // own channel slice and keeps it in its private L2.
+  const int nslice = a.nslice;
+  const int n = blockIdx.x / nslice, slice = blockIdx.x % nslice;
+  const int ngroups = a.C / G / nslice;
+  const int cbeg = slice * ngroups * G;
   const float* r = a.rois + (long)n * 4;
   const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
   int lvl = 0;
   if (a.L.nlvl > 1) lvl = __builtin_amdgcn_readfirstlane(fpn_level(x1, y1, x2, y2, a.L));
 
-  const long obase = ((long)n * a.C + c0) * PP;
+  const long obase = ((long)n * a.C + cbeg) * PP;
   if (lvl < 0) {  // assigned to no level: every per-level op sees a zero box
-    for (int e = tid; e < G * PP; e += THREADS) {
+    for (int e = tid; e < ngroups * G * PP; e += THREADS) {
       a.out[obase + e] = 0.f;
       a.ax[obase + e] = -1.f;
       a.ay[obase + e] = -1.f;
@@ -228,7 +237,8 @@ __global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
   }
   const int H = a.L.H[lvl], W = a.L.W[lvl];
   const float scale = a.L.scale[lvl];
-  const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + c0) * H * W;
+  const long plane = (long)H * W;
+  const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
 
   // ---- per-RoI sample tables (one lane per axis bin) ----
   int my_cnt = 0;
@@ -246,9 +256,9 @@ __global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
   const int fallback = __syncthreads_or(my_cnt >= 3);
 
   if (fallback) {
-    for (int e = tid; e < G * PP; e += THREADS) {
+    for (int e = tid; e < ngroups * G * PP; e += THREADS) {
       const int c = e / PP, bin = e % PP;
-      FwdOut o = roi_align_fwd_elem(base + (long)c * H * W, H, W, x1, y1, x2, y2, scale, bin / PW,
+      FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, x1, y1, x2, y2, scale, bin / PW,
                                     bin % PW, PH, PW);
       if (a.L.nlvl > 1) o.val = o.val + 0.0f;
       a.out[obase + e] = o.val;
@@ -258,54 +268,81 @@ __global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
     return;
   }
 
-  // ---- tile fill: lane keeps its column, walks rows/channels; all loads independent ----
-  {
-    const int co = s.coloff[tid % NC];
-    const long plane = (long)H * W;
-#pragma unroll
-    for (int it = 0; it < (G * CELLS + THREADS - 1) / THREADS; ++it) {
-      const int cell = tid + it * THREADS;
-      if ((G * CELLS) % THREADS == 0 || cell < G * CELLS) {
-        const int c = cell / CELLS;
-        const int ro = s.rowoff[(cell % CELLS) / NC];
-        float v = 0.f;
-        if (ro >= 0 && co >= 0) v = base[c * plane + ro + co];
-        s.tile[cell] = v;
-      }
-    }
+  // ---- per (bin, k, l): weight products and coordinates, shared by all channels ----
+  int any_valid = 0;
+  for (int t = tid; t < 4 * PP; t += THREADS) {
+    const int kl = t / PP, bin = t % PP, p = bin / PW, q = bin % PW, k = kl >> 1, l = kl & 1;
+    const bool valid = k < s.hcnt[p] && l < s.wcnt[q];
+    const float al = s.alpha[2 * p + k], be = s.beta[2 * q + l];
+    float4 w;
+    w.x = (1 - al) * (1 - be);
+    w.y = al * (1 - be);
+    w.z = (1 - al) * be;
+    w.w = al * be;
+    if (!valid) w.x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
+    s.wts[t] = w;
+    s.coord[t] = make_float2(s.wval[2 * q + l], s.hval[2 * p + k]);
+    if (kl == 0) s.binflag[bin] = (s.hcnt[p] >= 0 && s.wcnt[q] >= 0) ? 1 : 0;
+    any_valid |= valid;
   }
-  __syncthreads();
+  any_valid = __syncthreads_or(any_valid);
 
-  // ---- one lane per (channel, bin): 2x2 samples x 4 taps from LDS, contiguous stores ----
-  for (int e = tid; e < G * PP; e += THREADS) {
-    const int c = e / PP, bin = e % PP, p = bin / PW, q = bin % PW;
-    const int hc = s.hcnt[p], wc = s.wcnt[q];
-    float maxval = 0.f, mx = -1.f, my = -1.f;
-    if (hc > 0 && wc > 0) {
-      maxval = -FLT_MAX;
-      const float* t0 = &s.tile[c * CELLS + (4 * p) * NC + 4 * q];
-      for (int k = 0; k < hc; ++k) {
-        const float alpha = s.alpha[2 * p + k];
-        const float hv = s.hval[2 * p + k];
-        for (int l = 0; l < wc; ++l) {
-          const float beta = s.beta[2 * q + l];
-          const float* t = t0 + (2 * k) * NC + 2 * l;
-          const float2 top = *reinterpret_cast<const float2*>(t);
-          const float2 bot = *reinterpret_cast<const float2*>(t + NC);
-          float value = (1 - alpha) * (1 - beta) * top.x + alpha * (1 - beta) * bot.x +
-                        (1 - alpha) * beta * top.y + alpha * beta * bot.y;
-          if (value > maxval) {
-            maxval = value;
-            mx = s.wval[2 * q + l];
-            my = hv;
+  // ---- tile fill bookkeeping: lane keeps its column; rows advance by RPI per iteration ----
+  const int j = tid % NC, r0 = tid / NC;
+  const int co = s.coloff[j];
+  int goff[ITER];   // offset of this lane's ITER cells within one channel group (-1: unused)
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    int rr = (it * RPI) % NR + r0, c = (it * RPI) / NR;
+    if (rr >= NR) { rr -= NR; c += 1; }
+    const int ro = s.rowoff[rr];
+    goff[it] = (ro >= 0 && co >= 0) ? c * (int)plane + ro + co : -1;
+  }
+
+  float nxt[ITER];
+  auto load_group = [&](int g) {
+    const float* gb = base + (long)g * G * plane;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) nxt[it] = goff[it] >= 0 ? gb[goff[it]] : 0.f;
+  };
+  if (any_valid) load_group(0);
+
+  for (int g = 0; g < ngroups; ++g) {
+    if (any_valid) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) s.tile[tid + it * THREADS] = nxt[it];
+    }
+    __syncthreads();
+    if (any_valid && g + 1 < ngroups) load_group(g + 1);   // in flight during the compute below
+
+    // one lane per (channel, bin): <= 2x2 samples x 4 taps from LDS, contiguous stores
+    const long ob = obase + (long)g * G * PP;
+    for (int e = tid; e < G * PP; e += THREADS) {
+      const int c = e / PP, bin = e % PP, p = bin / PW, q = bin % PW;
+      float maxval = s.binflag[bin] ? -FLT_MAX : 0.f;
+      int best = -1;
+      if (any_valid) {
+        const float* t0 = &s.tile[c * CELLS + (4 * p) * NC + 4 * q];
+#pragma unroll
+        for (int kl = 0; kl < 4; ++kl) {
+          const float4 w = s.wts[kl * PP + bin];
+          if (w.x == w.x) {
+            const float* t = t0 + (2 * (kl >> 1)) * NC + 2 * (kl & 1);
+            const float2 top = *reinterpret_cast<const float2*>(t);
+            const float2 bot = *reinterpret_cast<const float2*>(t + NC);
+            const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
+            if (value > maxval) { maxval = value; best = kl; }
           }
         }
       }
+      float2 xy = make_float2(-1.f, -1.f);
+      if (best >= 0) xy = s.coord[best * PP + bin];
+      if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+      a.out[ob + e] = maxval;
+      a.ax[ob + e] = xy.x;
+      a.ay[ob + e] = xy.y;
     }
-    if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-    a.out[obase + e] = maxval;
-    a.ax[obase + e] = mx;
-    a.ay[obase + e] = my;
+    __syncthreads();
   }
 }
 
@@ -364,10 +401,12 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 template <int PP, int CPB, int THREADS>
 __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int U = 4;  // items per lane per trip: 3*U independent global loads in flight
   const int tid = threadIdx.x;
   const int H = a.H, W = a.W;
   const int ncb = a.C / CPB;
-  // block -> (unit = image x band, channel block); channel blocks of one unit are contiguous per XCD
+  // block -> (unit = image x band, channel block); channel blocks of one unit are contiguous per
+  // XCD so the dY/argmax lines two neighbouring channels share are fetched into one L2 only
   int u, cb;
   if (ncb % kNumXCD == 0) {
     const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD, per = ncb / kNumXCD;
@@ -383,98 +422,99 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   const int band_elems = (row1 - row0) * W;  // per channel
   const int c0 = cb * CPB;
 
-  float* plane = smem;                                   // CPB * band_elems (rounded up to 4)
+  float* plane = smem;  // CPB * band_elems floats (rounded up to 4), then the RoI list
   const int plane_total = CPB * band_elems;
-  int* list = reinterpret_cast<int*>(smem + ((plane_total + 3) & ~3));  // R entries
+  const int plane_pad = (plane_total + 3) & ~3;
+  int* list = reinterpret_cast<int*>(smem + plane_pad);  // R entries + counter
   int* nlist = list + a.R;
 
-  for (int i = tid; i < plane_total; i += THREADS) plane[i] = 0.f;
+  {
+    float4* p4 = reinterpret_cast<float4*>(plane);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
+  }
   if (tid == 0) *nlist = 0;
   __syncthreads();
 
   // ---- RoIs of this image that can touch this band (and belong to this level) ----
   for (int r = tid; r < a.R; r += THREADS) {
-    const float* rp = a.rois + ((long)img * a.R + r) * 4;
-    const float x1 = rp[0], y1 = rp[1], x2 = rp[2], y2 = rp[3];
+    const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
     bool take = true;
-    if (a.filter_lvl >= 0) take = fpn_level(x1, y1, x2, y2, a.L) == a.filter_lvl;
+    if (a.filter_lvl >= 0) take = fpn_level(rb.x, rb.y, rb.z, rb.w, a.L) == a.filter_lvl;
     if (take && a.nbands > 1) {
       // conservative row range of every tap of this RoI (taps lie within the clipped bins +-1)
-      float s = fminr(fmaxr(y1 * a.scale, 0.f), (float)(H - 1));
-      float e = fminr(fmaxr(y2 * a.scale, 0.f), (float)(H - 1));
+      float s = fminr(fmaxr(rb.y * a.scale, 0.f), (float)(H - 1));
+      float e = fminr(fmaxr(rb.w * a.scale, 0.f), (float)(H - 1));
       float lo = fminr(s, e) - 2.f, hi = fmaxr(s, e) + 2.f;
       if (hi < (float)row0 || lo > (float)(row1 - 1)) take = false;
     }
     if (take) list[atomicAdd(nlist, 1)] = r;
   }
   __syncthreads();
-  const int nl = *nlist;
+  const int nitems = *nlist * (CPB * PP);
 
   // ---- scatter bins into the LDS planes ----
   const long roi_stride = (long)a.C * PP;
   const long img_base = (long)img * a.R * roi_stride + (long)c0 * PP;
-  for (int it = tid; it < nl * (CPB * PP); it += THREADS) {
-    const int li = it / (CPB * PP), rem = it % (CPB * PP);
-    const long idx = img_base + (long)list[li] * roi_stride + rem;
-    const float a_x = a.ax[idx], a_y = a.ay[idx];
-    const float g = a.dy[idx];  // issued with the argmax loads, not behind the test
-    if (a_x != -1.f && a_y != -1.f) {
-      int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
-      int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
-      int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
-      int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
-      float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
-      float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
-      float* pl = plane + (rem / PP) * band_elems;
-      if (hlow >= row0 && hlow < row1) {
-        lds_add(pl + (hlow - row0) * W + wleft, g * (1 - alpha) * (1 - beta));
-        lds_add(pl + (hlow - row0) * W + wright, g * (1 - alpha) * beta);
+  for (int it0 = tid; it0 < nitems; it0 += U * THREADS) {
+    float vx[U], vy[U], vg[U];
+    int rem[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int it = it0 + k * THREADS;
+      vx[k] = -1.f;
+      if (it < nitems) {
+        const int li = it / (CPB * PP);
+        rem[k] = it % (CPB * PP);
+        const long idx = img_base + (long)list[li] * roi_stride + rem[k];
+        vx[k] = a.ax[idx];
+        vy[k] = a.ay[idx];
+        vg[k] = a.dy[idx];
       }
-      if (hhigh >= row0 && hhigh < row1) {
-        lds_add(pl + (hhigh - row0) * W + wleft, g * alpha * (1 - beta));
-        lds_add(pl + (hhigh - row0) * W + wright, g * alpha * beta);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const float a_x = vx[k], a_y = vy[k];
+      if (a_x != -1.f && a_y != -1.f) {
+        const float g = vg[k];
+        int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+        int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+        int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+        int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+        float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
+        float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
+        float* pl = plane + (rem[k] / PP) * band_elems;
+        if (hlow >= row0 && hlow < row1) {
+          lds_add(pl + (hlow - row0) * W + wleft, g * (1 - alpha) * (1 - beta));
+          lds_add(pl + (hlow - row0) * W + wright, g * (1 - alpha) * beta);
+        }
+        if (hhigh >= row0 && hhigh < row1) {
+          lds_add(pl + (hhigh - row0) * W + wleft, g * alpha * (1 - beta));
+          lds_add(pl + (hhigh - row0) * W + wright, g * alpha * beta);
+        }
       }
     }
   }
   __syncthreads();
 
-  // ---- write the band out once; CPB planes are contiguous in HBM when nbands == 1 ----
-  if (a.nbands == 1) {
-    float* dst = a.dx + ((long)img * a.C + c0) * H * W;
-    const long off = ((long)img * a.C + c0) * H * W;
-    if (((off | plane_total) & 3) == 0) {
-      float4* d4 = reinterpret_cast<float4*>(dst);
-      const float4* p4 = reinterpret_cast<const float4*>(plane);
-      for (int i = tid; i < plane_total / 4; i += THREADS) {
-        float4 v = p4[i];
-        if (a.req == SD_REQ_ADD) {
-          float4 o = d4[i];
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        d4[i] = v;
+  // ---- write the band out once.  With one band the CPB planes are contiguous in HBM; with
+  // several bands CPB == 1 and rows [row0,row1) of one plane are contiguous ----
+  const long off = (((long)img * a.C + c0) * H + row0) * W;
+  float* dst = a.dx + off;
+  if (((off | plane_total) & 3) == 0) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* p4 = reinterpret_cast<const float4*>(plane);
+    for (int i = tid; i < plane_total / 4; i += THREADS) {
+      float4 v = p4[i];
+      if (a.req == SD_REQ_ADD) {
+        const float4 o = d4[i];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
       }
-    } else {
-      for (int i = tid; i < plane_total; i += THREADS)
-        dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
+      d4[i] = v;
     }
-  } else {  // CPB == 1 by construction
-    const long off = (((long)img * a.C + c0) * H + row0) * W;
-    float* dst = a.dx + off;
-    if (((off | band_elems) & 3) == 0) {
-      float4* d4 = reinterpret_cast<float4*>(dst);
-      const float4* p4 = reinterpret_cast<const float4*>(plane);
-      for (int i = tid; i < band_elems / 4; i += THREADS) {
-        float4 v = p4[i];
-        if (a.req == SD_REQ_ADD) {
-          float4 o = d4[i];
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        d4[i] = v;
-      }
-    } else {
-      for (int i = tid; i < band_elems; i += THREADS)
-        dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
-    }
+  } else {
+    for (int i = tid; i < plane_total; i += THREADS)
+      dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
   }
 }
 
@@ -524,17 +564,22 @@ static int launch_fwd(FwdArgs& a, hipStream_t st) {
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
   const int variant = tuning("roi_align_fwd", 1);  // 0 naive, 1 tiled
-  a.map = tuning("roi_align_fwd_map", 1);
   const int nroi = a.B * a.R;
+  auto pick_slices = [&](int ngroups) {  // largest divisor of ngroups not above the knob
+    int want = tuning("roi_align_fwd_slices", 8);
+    if (want < 1) want = 1;
+    int ns = 1;
+    for (int d = 1; d <= ngroups && d <= want; ++d)
+      if (ngroups % d == 0) ns = d;
+    return ns;
+  };
   if (variant == 1 && a.PH == 7 && a.PW == 7 && a.C % 8 == 0) {
-    constexpr int G = 8;
-    if ((a.C / G) % kNumXCD != 0) a.map = 0;
-    hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, G, 448>), dim3(nroi * (a.C / G)), dim3(448), 0,
+    a.nslice = pick_slices(a.C / 8);
+    hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 8, 448>), dim3(nroi * a.nslice), dim3(448), 0,
                        st, a);
   } else if (variant == 1 && a.PH == 14 && a.PW == 14 && a.C % 4 == 0) {
-    constexpr int G = 4;
-    if ((a.C / G) % kNumXCD != 0) a.map = 0;
-    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, G, 448>), dim3(nroi * (a.C / G)), dim3(448), 0,
+    a.nslice = pick_slices(a.C / 4);
+    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 4, 448>), dim3(nroi * a.nslice), dim3(448), 0,
                        st, a);
   } else {
     const int grid = (int)((count + 255) / 256 < 65536 * 16 ? (count + 255) / 256 : 65536 * 16);
@@ -546,30 +591,32 @@ static int launch_fwd(FwdArgs& a, hipStream_t st) {
 
 template <int PP>
 static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
-  // LDS budget: small planes share a CU between several workgroups; a plane larger than the
-  // budget is cut into row bands of <= 140 KB (one workgroup per CU)
+  // LDS budget per workgroup: a plane larger than it is cut into row bands; several small planes
+  // (CPB channels) share a workgroup only while that still leaves >= 1024 workgroups
   const long plane_bytes = (long)a.H * a.W * 4;
   const long budget = (long)tuning("roi_align_bwd_lds_kb", 72) * 1024;
-  const long maxb = 140 * 1024;
   int cpb = 1;
   a.nbands = 1;
   a.band_rows = a.H;
   if (plane_bytes <= budget) {
     for (int c : {8, 4, 2})
-      if (c * plane_bytes <= budget && a.C % c == 0) {
+      if (c * plane_bytes <= budget && a.C % c == 0 && (long)a.B * a.C / c >= 1024) {
         cpb = c;
         break;
       }
-  } else if (plane_bytes > maxb) {
-    a.nbands = (int)((plane_bytes + maxb - 1) / maxb);
+  } else {
+    a.nbands = (int)((plane_bytes + budget - 1) / budget);
     a.band_rows = (a.H + a.nbands - 1) / a.nbands;
     a.nbands = (a.H + a.band_rows - 1) / a.band_rows;
   }
   const long band_elems = (long)a.band_rows * a.W;
   const size_t lds = (size_t)(((cpb * band_elems + 3) & ~3L) + a.R + 4) * 4;
-  SD_REQUIRE(lds <= 160 * 1024, "RoIAlign backward needs %zu B of LDS (R=%d too large)", lds, a.R);
+  SD_REQUIRE(lds <= 160 * 1024, "RoIAlign backward needs %zu B of LDS (W=%d R=%d too large)", lds,
+             a.W, a.R);
   const int grid = a.B * a.nbands * (a.C / cpb);
-  const bool big = lds > 80 * 1024;
+  int threads = tuning("roi_align_bwd_threads", 0);
+  if (threads != 256 && threads != 512 && threads != 1024)
+    threads = lds > 96 * 1024 ? 1024 : (lds > 24 * 1024 ? 512 : 256);
 #define SD_BWD_LAUNCH(CPB, T)                                                                   \
   do {                                                                                          \
     auto k = roi_align_bwd_plane<PP, CPB, T>;                                                   \
@@ -578,17 +625,17 @@ static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
                                        (int)lds));                                              \
     hipLaunchKernelGGL(k, dim3(grid), dim3(T), lds, st, a);                                     \
   } while (0)
-  if (big) {
-    if (cpb == 1) SD_BWD_LAUNCH(1, 1024);
-    else if (cpb == 2) SD_BWD_LAUNCH(2, 1024);
-    else if (cpb == 4) SD_BWD_LAUNCH(4, 1024);
-    else SD_BWD_LAUNCH(8, 1024);
-  } else {
-    if (cpb == 1) SD_BWD_LAUNCH(1, 256);
-    else if (cpb == 2) SD_BWD_LAUNCH(2, 256);
-    else if (cpb == 4) SD_BWD_LAUNCH(4, 256);
-    else SD_BWD_LAUNCH(8, 256);
-  }
+#define SD_BWD_T(CPB)                                  \
+  do {                                                 \
+    if (threads == 1024) SD_BWD_LAUNCH(CPB, 1024);     \
+    else if (threads == 512) SD_BWD_LAUNCH(CPB, 512);  \
+    else SD_BWD_LAUNCH(CPB, 256);                      \
+  } while (0)
+  if (cpb == 1) SD_BWD_T(1);
+  else if (cpb == 2) SD_BWD_T(2);
+  else if (cpb == 4) SD_BWD_T(4);
+  else SD_BWD_T(8);
+#undef SD_BWD_T
 #undef SD_BWD_LAUNCH
   SD_LAUNCH_CHECK();
   return SD_OK;
