@@ -116,6 +116,7 @@ struct FwdArgs {
   float* ay;
   int B, C, R, PH, PW;
   int nslice;  // channel slices per RoI (one workgroup each)
+  int ablate;  // profiling only: 1 stop after tables, 2 no tile loads, 4 no stores
 };
 
 __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
@@ -147,17 +148,25 @@ __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // tiled forward
 // ------------------------------------------------------------------------------------------------
-// One workgroup = one RoI x a slice of the channels, processed G channels at a time.
+// One workgroup (8 waves) = one RoI x a slice of the channels.
 //   tables   (once per workgroup) axis sample lists -> row/col offsets; per (bin,k,l) the four
 //            bilinear weight products and the sample coordinates, shared by every channel
-//   pipeline for each group of G channels: the NEXT group's tile is loaded into registers
-//            (ITER independent global loads per lane) while the CURRENT group is computed out of
-//            LDS and stored; one LDS tile, two barriers per group
-template <int PH, int PW, int G>
+//   waves    after the tables there is NO workgroup barrier: wave w owns channels w, w+8, ... of
+//            the slice and a private LDS tile.  Per channel it stages the RoI's taps
+//            tile[row][col] = data[c][rowidx[row]][colidx[col]] with line-friendly global loads
+//            (two tile rows per wave instruction), then lanes 0..PP-1 each own one bin: 4 samples x
+//            4 taps out of LDS, max + argmax, one contiguous store per output tensor.
+//            The next channel's loads are issued before the current channel is computed.
+template <int PH, int PW>
 struct FwdSmem {
-  static constexpr int NR = 4 * PH, NC = 4 * PW, CELLS = NR * NC, PP = PH * PW;
-  float tile[G * CELLS];
-  float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab   (kl = 2k + l)
+  static constexpr int NR = 4 * PH, NC = 4 * PW, PP = PH * PW, NWAVE = 8;
+  // Tile layout T[k][dh][l][p][q][dw] (tap of sample (k,l) of bin (p,q), corner (dh,dw)): for a
+  // fixed sample the 8-byte (dw=0,1) pairs of consecutive bins are contiguous, so the compute
+  // phase's ds_read_b64 is bank-conflict free; LS (stride of one [p][q][dw] block) is 16 mod 32
+  // banks so the fill's ds_write_b32 of one tile row does not collide between l=0 and l=1.
+  static constexpr int LS = ((2 * PP + 15) / 32) * 32 + 16, CH = 8 * LS;
+  float tile[NWAVE * CH];
+  float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab   (kl = 2k + l); x = NaN: none
   float2 coord[4 * PP];   // [kl][bin]: (w, h) of the sample
   int rowoff[NR];         // row * W, or -1 for an unused slot
   int coloff[NC];
@@ -165,6 +174,7 @@ struct FwdSmem {
   float wval[2 * PW], beta[2 * PW];
   int hcnt[PH], wcnt[PW];  // -1: empty axis bin (end <= start); else sample-loop iterations
   int binflag[PP];         // 1: the bin pools something (reference !is_empty)
+  int lvl;
 };
 
 // sample table of one axis bin; returns the number of loop iterations (reference loop, capped at 3)
@@ -204,31 +214,58 @@ __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, fl
   return cnt;
 }
 
-template <int PH, int PW, int G, int THREADS>
-__global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
-  using S = FwdSmem<PH, PW, G>;
-  constexpr int NR = S::NR, NC = S::NC, CELLS = S::CELLS, PP = PH * PW;
-  constexpr int RPI = THREADS / NC;                 // tile rows filled per iteration
-  constexpr int ITER = (G * NR) / RPI;              // loads per lane per channel group
-  static_assert(THREADS % NC == 0 && (G * NR) % RPI == 0, "tile fill must divide evenly");
+template <int PH, int PW>
+__global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
+  using S = FwdSmem<PH, PW>;
+  constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, LS = S::LS, CH = S::CH, NWAVE = S::NWAVE;
+  constexpr int THREADS = NWAVE * kWave;
+  constexpr int RPW = kWave / NC >= 1 ? kWave / NC : 1;  // tile rows per wave instruction
+  static_assert(NC <= kWave, "one tile row must fit a wave");
+  constexpr int ACT = RPW * NC;                 // active lanes in the fill
+  constexpr int ITER = (NR + RPW - 1) / RPW;    // fill instructions per channel
+  constexpr int CHUNK = ITER < 14 ? ITER : 14;  // loads kept in flight per lane
+  constexpr int NI = (PP + kWave - 1) / kWave;  // bins per lane
   __shared__ S s;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   // block -> (roi, channel slice).  Consecutive blocks are the slices of one RoI, so with
   // nslice a multiple/divisor of 8 every XCD (block b runs on XCD b % 8) only ever touches its
   // own channel slice and keeps it in its private L2.
   const int nslice = a.nslice;
   const int n = blockIdx.x / nslice, slice = blockIdx.x % nslice;
-  const int ngroups = a.C / G / nslice;
-  const int cbeg = slice * ngroups * G;
+  const int nch = a.C / nslice;  // channels of this workgroup
+  const int cbeg = slice * nch;
   const float* r = a.rois + (long)n * 4;
   const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-  int lvl = 0;
-  if (a.L.nlvl > 1) lvl = __builtin_amdgcn_readfirstlane(fpn_level(x1, y1, x2, y2, a.L));
-
   const long obase = ((long)n * a.C + cbeg) * PP;
+
+  // ---- per-RoI sample tables: wave 0 rows, wave 1 columns (one lane per axis bin) ----
+  int my_cnt = 0;
+  if (wave < 2) {
+    int lvl = 0;
+    if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
+    if (tid == 0) s.lvl = lvl;
+    if (lvl >= 0) {
+      const int H = a.L.H[lvl], W = a.L.W[lvl];
+      const float scale = a.L.scale[lvl];
+      if (wave == 0 && lane < PH) {
+        my_cnt = axis_samples(lane, PH, y1, y2, scale, H, W, &s.hval[2 * lane],
+                              &s.alpha[2 * lane], &s.rowoff[4 * lane]);
+        s.hcnt[lane] = my_cnt;
+      } else if (wave == 1 && lane < PW) {
+        my_cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &s.wval[2 * lane], &s.beta[2 * lane],
+                              &s.coloff[4 * lane]);
+        s.wcnt[lane] = my_cnt;
+      }
+    }
+  }
+  // a 3-iteration sample loop (stride within an ulp of 0.01) does not fit the 2x2 tile layout
+  const int fallback = __syncthreads_or(my_cnt >= 3);
+  const int lvl = s.lvl;
+
   if (lvl < 0) {  // assigned to no level: every per-level op sees a zero box
-    for (int e = tid; e < ngroups * G * PP; e += THREADS) {
+    for (int e = tid; e < nch * PP; e += THREADS) {
       a.out[obase + e] = 0.f;
       a.ax[obase + e] = -1.f;
       a.ay[obase + e] = -1.f;
@@ -240,23 +277,8 @@ __global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
   const long plane = (long)H * W;
   const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
 
-  // ---- per-RoI sample tables (one lane per axis bin) ----
-  int my_cnt = 0;
-  if (tid < PH) {
-    my_cnt = axis_samples(tid, PH, y1, y2, scale, H, W, &s.hval[2 * tid], &s.alpha[2 * tid],
-                          &s.rowoff[4 * tid]);
-    s.hcnt[tid] = my_cnt;
-  } else if (tid >= kWave && tid < kWave + PW) {
-    const int q = tid - kWave;
-    my_cnt = axis_samples(q, PW, x1, x2, scale, W, 1, &s.wval[2 * q], &s.beta[2 * q],
-                          &s.coloff[4 * q]);
-    s.wcnt[q] = my_cnt;
-  }
-  // a 3-iteration sample loop (stride within an ulp of 0.01) does not fit the 2x2 tile layout
-  const int fallback = __syncthreads_or(my_cnt >= 3);
-
   if (fallback) {
-    for (int e = tid; e < ngroups * G * PP; e += THREADS) {
+    for (int e = tid; e < nch * PP; e += THREADS) {
       const int c = e / PP, bin = e % PP;
       FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, x1, y1, x2, y2, scale, bin / PW,
                                     bin % PW, PH, PW);
@@ -286,63 +308,105 @@ __global__ __launch_bounds__(THREADS) void roi_align_fwd_tiled(FwdArgs a) {
     any_valid |= valid;
   }
   any_valid = __syncthreads_or(any_valid);
+  if (a.ablate & 1) return;
 
-  // ---- tile fill bookkeeping: lane keeps its column; rows advance by RPI per iteration ----
-  const int j = tid % NC, r0 = tid / NC;
-  const int co = s.coloff[j];
-  int goff[ITER];   // offset of this lane's ITER cells within one channel group (-1: unused)
+  // ===== from here on every wave runs on its own: no workgroup barrier =====
+  float* tile = s.tile + wave * CH;
+  // fill: lane -> (row r0 of the RPW rows of this instruction, column j); j is fixed per lane
+  const bool fill_lane = lane < ACT;
+  const int j = lane % NC, r0 = lane / NC;
+  const int co = fill_lane ? s.coloff[j] : -1;
+  const int colpart = ((j >> 1) & 1) * LS + 2 * (j >> 2) + (j & 1);
+  // LDS offset of tile row rr: T[k][dh][.][p][..] with rr = 4p + 2k + dh
+  auto rowpart = [&](int rr) {
+    return ((rr >> 1) & 1) * (4 * LS) + (rr & 1) * (2 * LS) + (rr >> 2) * (2 * PW);
+  };
+  // global offset of this lane's cell of fill instruction `it` within one channel plane; unused
+  // slots read element 0 of the plane (always in bounds, never consumed).  Cached in registers
+  // when the tile is small (7x7: 14 values), recomputed from the LDS table otherwise.
+  constexpr bool CACHE_GOFF = ITER <= 16;
+  auto calc_goff = [&](int it) {
+    const int rr = it * RPW + r0;
+    const int ro = (fill_lane && rr < NR) ? s.rowoff[rr] : -1;
+    return (ro >= 0 && co >= 0) ? ro + co : 0;
+  };
+  int goff[CACHE_GOFF ? ITER : 1];
+  if (CACHE_GOFF) {
 #pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    int rr = (it * RPI) % NR + r0, c = (it * RPI) / NR;
-    if (rr >= NR) { rr -= NR; c += 1; }
-    const int ro = s.rowoff[rr];
-    goff[it] = (ro >= 0 && co >= 0) ? c * (int)plane + ro + co : -1;
+    for (int it = 0; it < ITER; ++it) goff[it] = calc_goff(it);
   }
 
-  float nxt[ITER];
-  auto load_group = [&](int g) {
-    const float* gb = base + (long)g * G * plane;
+  // per-lane bin constants (kept in registers across channels)
+  int bflag[NI];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) nxt[it] = goff[it] >= 0 ? gb[goff[it]] : 0.f;
-  };
-  if (any_valid) load_group(0);
+  for (int i = 0; i < NI; ++i) {
+    const int bin = lane + i * kWave;
+    bflag[i] = bin < PP ? s.binflag[bin] : 0;
+  }
 
-  for (int g = 0; g < ngroups; ++g) {
-    if (any_valid) {
+  float nxt[CHUNK];
+  auto issue = [&](const float* pl, int chunk) {
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) s.tile[tid + it * THREADS] = nxt[it];
+    for (int u = 0; u < CHUNK; ++u) {
+      const int it = chunk * CHUNK + u;
+      if (it < ITER) nxt[u] = (a.ablate & 2) ? 0.f : pl[CACHE_GOFF ? goff[it] : calc_goff(it)];
     }
-    __syncthreads();
-    if (any_valid && g + 1 < ngroups) load_group(g + 1);   // in flight during the compute below
-
-    // one lane per (channel, bin): <= 2x2 samples x 4 taps from LDS, contiguous stores
-    const long ob = obase + (long)g * G * PP;
-    for (int e = tid; e < G * PP; e += THREADS) {
-      const int c = e / PP, bin = e % PP, p = bin / PW, q = bin % PW;
-      float maxval = s.binflag[bin] ? -FLT_MAX : 0.f;
-      int best = -1;
-      if (any_valid) {
-        const float* t0 = &s.tile[c * CELLS + (4 * p) * NC + 4 * q];
+  };
+  auto commit = [&](int chunk) {
 #pragma unroll
-        for (int kl = 0; kl < 4; ++kl) {
-          const float4 w = s.wts[kl * PP + bin];
-          if (w.x == w.x) {
-            const float* t = t0 + (2 * (kl >> 1)) * NC + 2 * (kl & 1);
-            const float2 top = *reinterpret_cast<const float2*>(t);
-            const float2 bot = *reinterpret_cast<const float2*>(t + NC);
-            const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
-            if (value > maxval) { maxval = value; best = kl; }
+    for (int u = 0; u < CHUNK; ++u) {
+      const int it = chunk * CHUNK + u;
+      const int rr = it * RPW + r0;
+      if (it < ITER && fill_lane && rr < NR) tile[rowpart(rr) + colpart] = nxt[u];
+    }
+  };
+  constexpr int NCHUNK = (ITER + CHUNK - 1) / CHUNK;
+
+  // wave w handles channels w, w+NWAVE, ... of the slice
+  int c = wave;
+  if (any_valid && c < nch) issue(base + (long)c * plane, 0);
+  for (; c < nch; c += NWAVE) {
+    const float* pl = base + (long)c * plane;
+    if (any_valid) {
+      commit(0);
+#pragma unroll
+      for (int ch = 1; ch < NCHUNK; ++ch) {
+        issue(pl, ch);
+        commit(ch);
+      }
+      if (c + NWAVE < nch) issue(pl + (long)NWAVE * plane, 0);  // next channel, in flight below
+    }
+    const long ob = obase + (long)c * PP;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int bin = lane + i * kWave;
+      if (bin < PP) {
+        float maxval = bflag[i] ? -FLT_MAX : 0.f;
+        int best = -1;
+        if (any_valid) {
+          const float* t0 = tile + 2 * bin;
+#pragma unroll
+          for (int kl = 0; kl < 4; ++kl) {
+            const float4 w = s.wts[kl * PP + bin];
+            if (w.x == w.x) {
+              const float* t = t0 + (kl >> 1) * (4 * LS) + (kl & 1) * LS;
+              const float2 top = *reinterpret_cast<const float2*>(t);
+              const float2 bot = *reinterpret_cast<const float2*>(t + 2 * LS);
+              const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
+              if (value > maxval) { maxval = value; best = kl; }
+            }
           }
         }
+        float2 xy = make_float2(-1.f, -1.f);
+        if (best >= 0) xy = s.coord[best * PP + bin];
+        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+        if (!(a.ablate & 4)) {
+          a.out[ob + bin] = maxval;
+          a.ax[ob + bin] = xy.x;
+          a.ay[ob + bin] = xy.y;
+        }
       }
-      float2 xy = make_float2(-1.f, -1.f);
-      if (best >= 0) xy = s.coord[best * PP + bin];
-      if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-      a.out[ob + e] = maxval;
-      a.ax[ob + e] = xy.x;
-      a.ay[ob + e] = xy.y;
     }
-    __syncthreads();
   }
 }
 
@@ -361,6 +425,7 @@ struct BwdArgs {
   int filter_lvl;     // >= 0: only RoIs assigned to this level contribute (fused FPN); -1: all
   int band_rows, nbands;
   int req;            // 1 write, 3 add
+  int ablate;         // profiling only: 1 skip scatter, 2 skip write-out, 4 skip list build
 };
 
 // reference structure: zero-fill (by the caller) + 4 global atomics per output element
@@ -393,15 +458,37 @@ __global__ __launch_bounds__(256) void roi_align_bwd_atomic(BwdArgs a) {
   }
 }
 
-__device__ __forceinline__ void lds_add(float* p, float v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// ds_add_f32 runs at ~0.33 lane-ops/clk/CU on gfx950 (measured, tools/lds_atomic_bench.hip) while
+// the integer LDS atomics (32 and 64 bit) run at ~4: more than 12x faster.  The gradient planes
+// are therefore accumulated in 64-bit fixed point with a per-workgroup power-of-two scale chosen
+// from max|dY| of the workgroup's own items (no overflow by construction).  Every tap value is
+// still computed in float exactly as the reference does (g*(1-a)*(1-b) ...); only the summation is
+// exact instead of float-in-arbitrary-order, which also makes the backward bit-reproducible.
+// Non-finite dY (inf/nan must propagate) falls back to float accumulation with a CAS loop.
+__device__ __forceinline__ void lds_add_cas(float* p, float v) {
+  int* ip = reinterpret_cast<int*>(p);
+  int old = *ip;
+  while (true) {
+    const int assumed = old;
+    old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + v));
+    if (old == assumed) break;
+  }
+}
+
+__device__ __forceinline__ void lds_add_fx(long long* p, float v, double scale) {
+  const long long q = __double2ll_rn((double)v * scale);
+  __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // One workgroup owns CPB channel planes (rows [row0,row1) of them) of one image in LDS.
-template <int PP, int CPB, int THREADS>
+//   FX = true : int64 fixed-point planes (8 B per pixel), float-CAS fallback on non-finite dY
+//   FX = false: float planes (4 B per pixel) with a CAS loop (A/B variant)
+template <int PP, int CPB, int THREADS, bool FX>
 __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int U = 4;  // items per lane per trip: 3*U independent global loads in flight
+  constexpr int ESZ = FX ? 2 : 1;  // plane element size in floats
   const int tid = threadIdx.x;
   const int H = a.H, W = a.W;
   const int ncb = a.C / CPB;
@@ -422,22 +509,30 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   const int band_elems = (row1 - row0) * W;  // per channel
   const int c0 = cb * CPB;
 
-  float* plane = smem;  // CPB * band_elems floats (rounded up to 4), then the RoI list
+  // LDS: [plane: CPB*band_elems elements, padded to 4][RoI list: R ints][counter][gmax bits][flag]
   const int plane_total = CPB * band_elems;
   const int plane_pad = (plane_total + 3) & ~3;
-  int* list = reinterpret_cast<int*>(smem + plane_pad);  // R entries + counter
+  float* planef = smem;
+  long long* planeq = reinterpret_cast<long long*>(smem);
+  int* list = reinterpret_cast<int*>(smem + (size_t)plane_pad * ESZ);
   int* nlist = list + a.R;
+  unsigned* gmax_bits = reinterpret_cast<unsigned*>(nlist + 1);
+  int* nonfinite = nlist + 2;
 
   {
-    float4* p4 = reinterpret_cast<float4*>(plane);
+    float4* p4 = reinterpret_cast<float4*>(smem);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
+    for (int i = tid; i < plane_pad * ESZ / 4; i += THREADS) p4[i] = z;
   }
-  if (tid == 0) *nlist = 0;
+  if (tid == 0) {
+    *nlist = 0;
+    *gmax_bits = 0u;
+    *nonfinite = 0;
+  }
   __syncthreads();
 
   // ---- RoIs of this image that can touch this band (and belong to this level) ----
-  for (int r = tid; r < a.R; r += THREADS) {
+  for (int r = tid; r < ((a.ablate & 4) ? 0 : a.R); r += THREADS) {
     const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
     bool take = true;
     if (a.filter_lvl >= 0) take = fpn_level(rb.x, rb.y, rb.z, rb.w, a.L) == a.filter_lvl;
@@ -451,11 +546,42 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
     if (take) list[atomicAdd(nlist, 1)] = r;
   }
   __syncthreads();
-  const int nitems = *nlist * (CPB * PP);
+  int nitems = *nlist * (CPB * PP);
+  if (a.ablate & 1) nitems = 0;
 
-  // ---- scatter bins into the LDS planes ----
   const long roi_stride = (long)a.C * PP;
   const long img_base = (long)img * a.R * roi_stride + (long)c0 * PP;
+
+  // ---- fixed-point scale: 2^S * (sum of |taps| on any pixel) < 2^62 ----
+  double fx_scale = 0.0, fx_inv = 0.0;
+  bool use_fx = FX;
+  if (FX) {
+    float m = 0.f;
+    int bad = 0;
+    for (int it = tid; it < nitems; it += THREADS) {
+      const int li = it / (CPB * PP);
+      const float g = a.dy[img_base + (long)list[li] * roi_stride + it % (CPB * PP)];
+      const float ag = fabsf(g);
+      bad |= !(ag <= FLT_MAX);
+      m = fmaxr(m, ag);
+    }
+    if (bad) atomicOr(nonfinite, 1);
+    atomicMax(gmax_bits, __float_as_uint(m));  // non-negative floats order like their bit patterns
+    __syncthreads();
+    const float gmax = __uint_as_float(*gmax_bits);
+    if (*nonfinite) {
+      use_fx = false;  // planes are zero in both representations
+    } else if (gmax == 0.f) {
+      nitems = 0;
+    } else {
+      int e;
+      frexp((double)gmax * (double)(nitems / CPB), &e);  // bound < 2^e
+      fx_scale = ldexp(1.0, 61 - e);
+      fx_inv = ldexp(1.0, e - 61);
+    }
+  }
+
+  // ---- scatter bins into the LDS planes ----
   for (int it0 = tid; it0 < nitems; it0 += U * THREADS) {
     float vx[U], vy[U], vg[U];
     int rem[U];
@@ -483,14 +609,29 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
         int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
         float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
         float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
-        float* pl = plane + (rem[k] / PP) * band_elems;
-        if (hlow >= row0 && hlow < row1) {
-          lds_add(pl + (hlow - row0) * W + wleft, g * (1 - alpha) * (1 - beta));
-          lds_add(pl + (hlow - row0) * W + wright, g * (1 - alpha) * beta);
-        }
-        if (hhigh >= row0 && hhigh < row1) {
-          lds_add(pl + (hhigh - row0) * W + wleft, g * alpha * (1 - beta));
-          lds_add(pl + (hhigh - row0) * W + wright, g * alpha * beta);
+        const int pb = (rem[k] / PP) * band_elems;
+        const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
+        const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
+        const bool top = hlow >= row0 && hlow < row1, bot = hhigh >= row0 && hhigh < row1;
+        const int o0 = pb + (hlow - row0) * W, o1 = pb + (hhigh - row0) * W;
+        if (use_fx) {
+          if (top) {
+            lds_add_fx(planeq + o0 + wleft, w00, fx_scale);
+            lds_add_fx(planeq + o0 + wright, w01, fx_scale);
+          }
+          if (bot) {
+            lds_add_fx(planeq + o1 + wleft, w10, fx_scale);
+            lds_add_fx(planeq + o1 + wright, w11, fx_scale);
+          }
+        } else {
+          if (top) {
+            lds_add_cas(planef + o0 + wleft, w00);
+            lds_add_cas(planef + o0 + wright, w01);
+          }
+          if (bot) {
+            lds_add_cas(planef + o1 + wleft, w10);
+            lds_add_cas(planef + o1 + wright, w11);
+          }
         }
       }
     }
@@ -499,13 +640,24 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
 
   // ---- write the band out once.  With one band the CPB planes are contiguous in HBM; with
   // several bands CPB == 1 and rows [row0,row1) of one plane are contiguous ----
+  if (a.ablate & 2) return;
   const long off = (((long)img * a.C + c0) * H + row0) * W;
   float* dst = a.dx + off;
+  auto get = [&](int i) -> float {
+    return use_fx ? (float)((double)planeq[i] * fx_inv) : planef[i];
+  };
   if (((off | plane_total) & 3) == 0) {
     float4* d4 = reinterpret_cast<float4*>(dst);
-    const float4* p4 = reinterpret_cast<const float4*>(plane);
     for (int i = tid; i < plane_total / 4; i += THREADS) {
-      float4 v = p4[i];
+      float4 v;
+      if (use_fx) {
+        const longlong2 q0 = reinterpret_cast<const longlong2*>(planeq)[2 * i];
+        const longlong2 q1 = reinterpret_cast<const longlong2*>(planeq)[2 * i + 1];
+        v = make_float4((float)((double)q0.x * fx_inv), (float)((double)q0.y * fx_inv),
+                        (float)((double)q1.x * fx_inv), (float)((double)q1.y * fx_inv));
+      } else {
+        v = reinterpret_cast<const float4*>(planef)[i];
+      }
       if (a.req == SD_REQ_ADD) {
         const float4 o = d4[i];
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -514,7 +666,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
     }
   } else {
     for (int i = tid; i < plane_total; i += THREADS)
-      dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
+      dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + get(i) : get(i);
   }
 }
 
@@ -564,23 +716,18 @@ static int launch_fwd(FwdArgs& a, hipStream_t st) {
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
   const int variant = tuning("roi_align_fwd", 1);  // 0 naive, 1 tiled
+  a.ablate = tuning("roi_align_fwd_ablate", 0);
   const int nroi = a.B * a.R;
-  auto pick_slices = [&](int ngroups) {  // largest divisor of ngroups not above the knob
-    int want = tuning("roi_align_fwd_slices", 8);
-    if (want < 1) want = 1;
-    int ns = 1;
-    for (int d = 1; d <= ngroups && d <= want; ++d)
-      if (ngroups % d == 0) ns = d;
-    return ns;
-  };
-  if (variant == 1 && a.PH == 7 && a.PW == 7 && a.C % 8 == 0) {
-    a.nslice = pick_slices(a.C / 8);
-    hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 8, 448>), dim3(nroi * a.nslice), dim3(448), 0,
-                       st, a);
-  } else if (variant == 1 && a.PH == 14 && a.PW == 14 && a.C % 4 == 0) {
-    a.nslice = pick_slices(a.C / 4);
-    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 4, 448>), dim3(nroi * a.nslice), dim3(448), 0,
-                       st, a);
+  // channel slices (workgroups) per RoI: largest divisor of C not above the knob
+  int want = tuning("roi_align_fwd_slices", 8);
+  if (want < 1) want = 1;
+  a.nslice = 1;
+  for (int d = 1; d <= a.C && d <= want; ++d)
+    if (a.C % d == 0) a.nslice = d;
+  if (variant == 1 && a.PH == 7 && a.PW == 7) {
+    hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
+  } else if (variant == 1 && a.PH == 14 && a.PW == 14) {
+    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
   } else {
     const int grid = (int)((count + 255) / 256 < 65536 * 16 ? (count + 255) / 256 : 65536 * 16);
     hipLaunchKernelGGL(roi_align_fwd_naive, dim3(grid), dim3(256), 0, st, a);
@@ -593,7 +740,9 @@ template <int PP>
 static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
   // LDS budget per workgroup: a plane larger than it is cut into row bands; several small planes
   // (CPB channels) share a workgroup only while that still leaves >= 1024 workgroups
-  const long plane_bytes = (long)a.H * a.W * 4;
+  const bool fx = tuning("roi_align_bwd_accum", 1) == 1;  // 1 int64 fixed point, 0 float CAS
+  const long esz = fx ? 8 : 4;
+  const long plane_bytes = (long)a.H * a.W * esz;
   const long budget = (long)tuning("roi_align_bwd_lds_kb", 72) * 1024;
   int cpb = 1;
   a.nbands = 1;
@@ -610,31 +759,37 @@ static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
     a.nbands = (a.H + a.band_rows - 1) / a.band_rows;
   }
   const long band_elems = (long)a.band_rows * a.W;
-  const size_t lds = (size_t)(((cpb * band_elems + 3) & ~3L) + a.R + 4) * 4;
+  const size_t lds = (size_t)(((cpb * band_elems + 3) & ~3L) * esz) + (size_t)(a.R + 4) * 4;
   SD_REQUIRE(lds <= 160 * 1024, "RoIAlign backward needs %zu B of LDS (W=%d R=%d too large)", lds,
              a.W, a.R);
   const int grid = a.B * a.nbands * (a.C / cpb);
   int threads = tuning("roi_align_bwd_threads", 0);
   if (threads != 256 && threads != 512 && threads != 1024)
     threads = lds > 96 * 1024 ? 1024 : (lds > 24 * 1024 ? 512 : 256);
-#define SD_BWD_LAUNCH(CPB, T)                                                                   \
+#define SD_BWD_LAUNCH(CPB, T, FX)                                                               \
   do {                                                                                          \
-    auto k = roi_align_bwd_plane<PP, CPB, T>;                                                   \
+    auto k = roi_align_bwd_plane<PP, CPB, T, FX>;                                               \
     if (lds > 64 * 1024)                                                                        \
       SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)lds));                                              \
     hipLaunchKernelGGL(k, dim3(grid), dim3(T), lds, st, a);                                     \
   } while (0)
-#define SD_BWD_T(CPB)                                  \
-  do {                                                 \
-    if (threads == 1024) SD_BWD_LAUNCH(CPB, 1024);     \
-    else if (threads == 512) SD_BWD_LAUNCH(CPB, 512);  \
-    else SD_BWD_LAUNCH(CPB, 256);                      \
+#define SD_BWD_T(CPB, FX)                                  \
+  do {                                                     \
+    if (threads == 1024) SD_BWD_LAUNCH(CPB, 1024, FX);     \
+    else if (threads == 512) SD_BWD_LAUNCH(CPB, 512, FX);  \
+    else SD_BWD_LAUNCH(CPB, 256, FX);                      \
   } while (0)
-  if (cpb == 1) SD_BWD_T(1);
-  else if (cpb == 2) SD_BWD_T(2);
-  else if (cpb == 4) SD_BWD_T(4);
-  else SD_BWD_T(8);
+#define SD_BWD_C(FX)                   \
+  do {                                 \
+    if (cpb == 1) SD_BWD_T(1, FX);     \
+    else if (cpb == 2) SD_BWD_T(2, FX); \
+    else if (cpb == 4) SD_BWD_T(4, FX); \
+    else SD_BWD_T(8, FX);              \
+  } while (0)
+  if (fx) SD_BWD_C(true);
+  else SD_BWD_C(false);
+#undef SD_BWD_C
 #undef SD_BWD_T
 #undef SD_BWD_LAUNCH
   SD_LAUNCH_CHECK();
@@ -646,6 +801,7 @@ static int launch_bwd(BwdArgs& a, hipStream_t st) {
   const size_t dx_bytes = (size_t)a.B * a.C * a.H * a.W * 4;
   if (dx_bytes == 0) return SD_OK;
   const int variant = tuning("roi_align_bwd", 1);  // 0 global atomics, 1 LDS planes
+  a.ablate = tuning("roi_align_bwd_ablate", 0);
   const size_t list_bytes = (size_t)(a.R + 8) * 4;
   if (variant == 1 && (a.PP == 49 || a.PP == 196) && list_bytes < 20 * 1024 && count > 0) {
     return a.PP == 49 ? launch_bwd_plane<49>(a, st) : launch_bwd_plane<196>(a, st);

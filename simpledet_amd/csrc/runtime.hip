@@ -28,9 +28,12 @@ struct Knob {
 // every knob a kernel launcher reads must be listed here (sd_set_tuning rejects unknown keys)
 Knob g_knobs[] = {
     {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default)
+    {"roi_align_fwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
     {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
     {"roi_align_bwd", 0, false},         // 0 global atomics, 1 LDS planes (default)
     {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 72
+    {"roi_align_bwd_accum", 0, false},   // 1 int64 fixed-point LDS planes (default), 0 float CAS
+    {"roi_align_bwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
     {"roi_align_bwd_threads", 0, false}, // 256/512/1024, default by LDS size
     {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes (default)
     {"nms_scan", 0, false},              // 0 single-wave scan, 1 (default) block scan
