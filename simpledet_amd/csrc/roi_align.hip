@@ -148,38 +148,45 @@ __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // tiled forward
 // ------------------------------------------------------------------------------------------------
-// One workgroup (8 waves) = one RoI x a slice of the channels.
-//   tables   (once per workgroup) axis sample lists -> row/col offsets; per (bin,k,l) the four
+// One workgroup (8 waves) = NROI consecutive RoIs x a slice of the channels.
+//   tables   (once per workgroup, all NROI RoIs at the same time: wave pair (2i, 2i+1) does the
+//            row / column sample lists of RoI i) -> row/col offsets; per (bin,k,l) the four
 //            bilinear weight products and the sample coordinates, shared by every channel
 //   waves    after the tables there is NO workgroup barrier: wave w owns channels w, w+8, ... of
-//            the slice and a private LDS tile.  Per channel it stages the RoI's taps
-//            tile[row][col] = data[c][rowidx[row]][colidx[col]] with line-friendly global loads
-//            (two tile rows per wave instruction), then lanes 0..PP-1 each own one bin: 4 samples x
-//            4 taps out of LDS, max + argmax, one contiguous store per output tensor.
+//            the slice and a private LDS tile.  Per (RoI, channel) it stages the RoI's taps
+//            tile[row][col] = data[c][rowidx[row]][colidx[col]] with line-friendly 8-byte global
+//            loads (several tile rows per wave instruction), then lanes 0..PP-1 each own one bin:
+//            4 samples x 4 taps out of LDS, max + argmax, one contiguous store per output tensor.
 //            The next channel's loads are issued before the current channel is computed.
-template <int PH, int PW>
+template <int PH, int PW, int NROI>
 struct FwdSmem {
   static constexpr int NR = 4 * PH, NC = 4 * PW, PP = PH * PW, NWAVE = 8;
   // Tile layout T[k][dh][l][p][q][dw] (tap of sample (k,l) of bin (p,q), corner (dh,dw)): for a
   // fixed sample the 8-byte (dw=0,1) pairs of consecutive bins are contiguous, so the compute
   // phase's ds_read_b64 is bank-conflict free; LS (stride of one [p][q][dw] block) is 16 mod 32
-  // banks so the fill's ds_write_b32 of one tile row does not collide between l=0 and l=1.
+  // banks so the fill's writes of one tile row do not collide between l=0 and l=1.
   static constexpr int LS = ((2 * PP + 15) / 32) * 32 + 16, CH = 8 * LS;
   float tile[NWAVE * CH];
-  float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab   (kl = 2k + l); x = NaN: none
-  float2 coord[4 * PP];   // [kl][bin]: (w, h) of the sample
-  int rowoff[NR];         // row * W, or -1 for an unused slot
-  int coloff[NC];
-  float hval[2 * PH], alpha[2 * PH];
-  float wval[2 * PW], beta[2 * PW];
-  int hcnt[PH], wcnt[PW];  // -1: empty axis bin (end <= start); else sample-loop iterations
-  int binflag[PP];         // 1: the bin pools something (reference !is_empty)
-  int lvl;
+  struct Roi {
+    float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab  (kl = 2k+l); x = NaN: none
+    float2 coord[4 * PP];   // [kl][bin]: (w, h) of the sample
+    int rowoff[NR];         // row * W, or -1 for an unused slot
+    int coloff[NC];
+    float hval[2 * PH], alpha[2 * PH];
+    float wval[2 * PW], beta[2 * PW];
+    int hcnt[PH], wcnt[PW];  // -1: empty axis bin (end <= start); else sample-loop iterations
+    int binflag[PP];         // 1: the bin pools something (reference !is_empty)
+    int lvl;                 // assigned level, -1 none, -2 RoI index past the end
+    int fb_row, fb_col;      // a sample loop ran 3 times -> exact per-element fallback
+    int any_valid;
+    float box[4];
+  } roi[NROI];
 };
 
 // sample table of one axis bin; returns the number of loop iterations (reference loop, capped at 3)
 // (float)((double)x / 3.0) == x / 3.0f exactly (double rounding is innocuous for one IEEE division
-// when the wide format has >= 2p+2 bits), so the stride uses the float divide.
+// when the wide format has >= 2p+2 bits), so the stride uses the float divide; high - low is 0 or 1
+// so the reference's division by (high - low) is the identity.
 __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, float end_c,
                                             float scale, int size, int mul, float* val, float* frac,
                                             int* off) {
@@ -203,7 +210,7 @@ __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, fl
         int low = iminr(imaxr((int)floorf(v), 0), size - 1);
         int high = iminr(imaxr((int)ceilf(v), 0), size - 1);
         val[cnt] = v;
-        frac[cnt] = (low == high) ? 0.5f : (v - (float)low) / (float)(high - low);
+        frac[cnt] = (low == high) ? 0.5f : (v - (float)low);
         off[2 * cnt] = low * mul;
         off[2 * cnt + 1] = high * mul;
       }
@@ -214,196 +221,259 @@ __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, fl
   return cnt;
 }
 
-template <int PH, int PW>
+template <int PH, int PW, int NROI>
 __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
-  using S = FwdSmem<PH, PW>;
+  using S = FwdSmem<PH, PW, NROI>;
   constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, LS = S::LS, CH = S::CH, NWAVE = S::NWAVE;
   constexpr int THREADS = NWAVE * kWave;
-  constexpr int RPW = kWave / NC >= 1 ? kWave / NC : 1;  // tile rows per wave instruction
-  static_assert(NC <= kWave, "one tile row must fit a wave");
-  constexpr int ACT = RPW * NC;                 // active lanes in the fill
-  constexpr int ITER = (NR + RPW - 1) / RPW;    // fill instructions per channel
-  constexpr int CHUNK = ITER < 14 ? ITER : 14;  // loads kept in flight per lane
+  static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
+  constexpr int NPAIR = NC / 2;                 // (left,right) column pairs per tile row
+  constexpr int RPW = kWave / NPAIR >= 1 ? kWave / NPAIR : 1;  // tile rows per wave instruction
+  static_assert(NPAIR <= kWave, "one tile row must fit a wave");
+  constexpr int ACT = RPW * NPAIR;              // active lanes in the fill
+  constexpr int ITER = (NR + RPW - 1) / RPW;    // fill instructions (8-byte loads) per channel
+  constexpr int CHUNK = ITER < 8 ? ITER : 8;    // loads kept in flight per lane
+  constexpr int NCHUNK = (ITER + CHUNK - 1) / CHUNK;
   constexpr int NI = (PP + kWave - 1) / kWave;  // bins per lane
+  constexpr bool REGW = NI == 1;                // keep the bin's 16 weights in registers
+  constexpr bool CACHE_GOFF = ITER <= 8;        // keep the fill offsets in registers
   __shared__ S s;
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-  // block -> (roi, channel slice).  Consecutive blocks are the slices of one RoI, so with
-  // nslice a multiple/divisor of 8 every XCD (block b runs on XCD b % 8) only ever touches its
-  // own channel slice and keeps it in its private L2.
+  // block -> (RoI group, channel slice).  Consecutive blocks are the slices of one RoI group, so
+  // with nslice a multiple/divisor of 8 every XCD (block b runs on XCD b % 8) only ever touches
+  // its own channel slice.
   const int nslice = a.nslice;
-  const int n = blockIdx.x / nslice, slice = blockIdx.x % nslice;
+  const int grp = blockIdx.x / nslice, slice = blockIdx.x % nslice;
+  const int nroi_total = a.B * a.R;
   const int nch = a.C / nslice;  // channels of this workgroup
   const int cbeg = slice * nch;
-  const float* r = a.rois + (long)n * 4;
-  const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-  const long obase = ((long)n * a.C + cbeg) * PP;
 
-  // ---- per-RoI sample tables: wave 0 rows, wave 1 columns (one lane per axis bin) ----
-  int my_cnt = 0;
-  if (wave < 2) {
-    int lvl = 0;
-    if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
-    if (tid == 0) s.lvl = lvl;
-    if (lvl >= 0) {
-      const int H = a.L.H[lvl], W = a.L.W[lvl];
-      const float scale = a.L.scale[lvl];
-      if (wave == 0 && lane < PH) {
-        my_cnt = axis_samples(lane, PH, y1, y2, scale, H, W, &s.hval[2 * lane],
-                              &s.alpha[2 * lane], &s.rowoff[4 * lane]);
-        s.hcnt[lane] = my_cnt;
-      } else if (wave == 1 && lane < PW) {
-        my_cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &s.wval[2 * lane], &s.beta[2 * lane],
-                              &s.coloff[4 * lane]);
-        s.wcnt[lane] = my_cnt;
+  // ---- per-RoI sample tables: wave 2i rows, wave 2i+1 columns of RoI i ----
+  if (wave < 2 * NROI) {
+    const int i = wave >> 1, n = grp * NROI + i;
+    typename S::Roi& t = s.roi[i];
+    int lvl = -2, cnt = 0;
+    if (n < nroi_total) {
+      const float* r = a.rois + (long)n * 4;
+      const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+      lvl = 0;
+      if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
+      if (lvl >= 0) {
+        const int H = a.L.H[lvl], W = a.L.W[lvl];
+        const float scale = a.L.scale[lvl];
+        if ((wave & 1) == 0 && lane < PH) {
+          cnt = axis_samples(lane, PH, y1, y2, scale, H, W, &t.hval[2 * lane], &t.alpha[2 * lane],
+                             &t.rowoff[4 * lane]);
+          t.hcnt[lane] = cnt;
+        } else if ((wave & 1) == 1 && lane < PW) {
+          cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
+                             &t.coloff[4 * lane]);
+          t.wcnt[lane] = cnt;
+        }
+      }
+      if ((wave & 1) == 0 && lane == 0) {
+        t.box[0] = x1; t.box[1] = y1; t.box[2] = x2; t.box[3] = y2;
       }
     }
-  }
-  // a 3-iteration sample loop (stride within an ulp of 0.01) does not fit the 2x2 tile layout
-  const int fallback = __syncthreads_or(my_cnt >= 3);
-  const int lvl = s.lvl;
-
-  if (lvl < 0) {  // assigned to no level: every per-level op sees a zero box
-    for (int e = tid; e < nch * PP; e += THREADS) {
-      a.out[obase + e] = 0.f;
-      a.ax[obase + e] = -1.f;
-      a.ay[obase + e] = -1.f;
+    // a 3-iteration sample loop (stride within an ulp of 0.01) does not fit the 2x2 tile layout
+    const int fb = __any(cnt >= 3);
+    if (lane == 0) {
+      if (wave & 1) t.fb_col = fb;
+      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; }
     }
-    return;
   }
-  const int H = a.L.H[lvl], W = a.L.W[lvl];
-  const float scale = a.L.scale[lvl];
-  const long plane = (long)H * W;
-  const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
+  __syncthreads();
 
-  if (fallback) {
-    for (int e = tid; e < nch * PP; e += THREADS) {
-      const int c = e / PP, bin = e % PP;
-      FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, x1, y1, x2, y2, scale, bin / PW,
-                                    bin % PW, PH, PW);
-      if (a.L.nlvl > 1) o.val = o.val + 0.0f;
-      a.out[obase + e] = o.val;
-      a.ax[obase + e] = o.ax;
-      a.ay[obase + e] = o.ay;
-    }
-    return;
-  }
-
-  // ---- per (bin, k, l): weight products and coordinates, shared by all channels ----
-  int any_valid = 0;
-  for (int t = tid; t < 4 * PP; t += THREADS) {
-    const int kl = t / PP, bin = t % PP, p = bin / PW, q = bin % PW, k = kl >> 1, l = kl & 1;
-    const bool valid = k < s.hcnt[p] && l < s.wcnt[q];
-    const float al = s.alpha[2 * p + k], be = s.beta[2 * q + l];
+  // ---- per (RoI, bin, k, l): weight products and coordinates, shared by all channels ----
+  for (int e = tid; e < NROI * 4 * PP; e += THREADS) {
+    const int i = e / (4 * PP), tt = e % (4 * PP);
+    typename S::Roi& t = s.roi[i];
+    if (t.lvl < 0 || t.fb_row || t.fb_col) continue;
+    const int kl = tt / PP, bin = tt % PP, p = bin / PW, q = bin % PW, k = kl >> 1, l = kl & 1;
+    const bool valid = k < t.hcnt[p] && l < t.wcnt[q];
+    const float al = t.alpha[2 * p + k], be = t.beta[2 * q + l];
     float4 w;
     w.x = (1 - al) * (1 - be);
     w.y = al * (1 - be);
     w.z = (1 - al) * be;
     w.w = al * be;
     if (!valid) w.x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
-    s.wts[t] = w;
-    s.coord[t] = make_float2(s.wval[2 * q + l], s.hval[2 * p + k]);
-    if (kl == 0) s.binflag[bin] = (s.hcnt[p] >= 0 && s.wcnt[q] >= 0) ? 1 : 0;
-    any_valid |= valid;
+    t.wts[tt] = w;
+    t.coord[tt] = make_float2(t.wval[2 * q + l], t.hval[2 * p + k]);
+    if (kl == 0) t.binflag[bin] = (t.hcnt[p] >= 0 && t.wcnt[q] >= 0) ? 1 : 0;
+    if (__any(valid) && valid) t.any_valid = 1;  // benign same-value race
   }
-  any_valid = __syncthreads_or(any_valid);
+  __syncthreads();
   if (a.ablate & 1) return;
 
   // ===== from here on every wave runs on its own: no workgroup barrier =====
   float* tile = s.tile + wave * CH;
-  // fill: lane -> (row r0 of the RPW rows of this instruction, column j); j is fixed per lane
+  // fill: lane -> (row r0 of the RPW rows of this instruction, column pair jp).  A pair is the
+  // (left,right) taps of one column sample; they are adjacent pixels, so one 8-byte load fetches
+  // both.  When they coincide (integer coordinate / clamped border) the load starts at
+  // min(left, W-2) and the register is patched (dup = 1: both .x, dup = 2: both .y).
   const bool fill_lane = lane < ACT;
-  const int j = lane % NC, r0 = lane / NC;
-  const int co = fill_lane ? s.coloff[j] : -1;
-  const int colpart = ((j >> 1) & 1) * LS + 2 * (j >> 2) + (j & 1);
+  const int jp = lane % NPAIR, r0 = lane / NPAIR;
+  const int colpart = (jp & 1) * LS + 2 * (jp >> 1);
   // LDS offset of tile row rr: T[k][dh][.][p][..] with rr = 4p + 2k + dh
   auto rowpart = [&](int rr) {
     return ((rr >> 1) & 1) * (4 * LS) + (rr & 1) * (2 * LS) + (rr >> 2) * (2 * PW);
   };
-  // global offset of this lane's cell of fill instruction `it` within one channel plane; unused
-  // slots read element 0 of the plane (always in bounds, never consumed).  Cached in registers
-  // when the tile is small (7x7: 14 values), recomputed from the LDS table otherwise.
-  constexpr bool CACHE_GOFF = ITER <= 16;
-  auto calc_goff = [&](int it) {
-    const int rr = it * RPW + r0;
-    const int ro = (fill_lane && rr < NR) ? s.rowoff[rr] : -1;
-    return (ro >= 0 && co >= 0) ? ro + co : 0;
-  };
-  int goff[CACHE_GOFF ? ITER : 1];
-  if (CACHE_GOFF) {
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) goff[it] = calc_goff(it);
-  }
 
-  // per-lane bin constants (kept in registers across channels)
-  int bflag[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int bin = lane + i * kWave;
-    bflag[i] = bin < PP ? s.binflag[bin] : 0;
-  }
-
-  float nxt[CHUNK];
-  auto issue = [&](const float* pl, int chunk) {
-#pragma unroll
-    for (int u = 0; u < CHUNK; ++u) {
-      const int it = chunk * CHUNK + u;
-      if (it < ITER) nxt[u] = (a.ablate & 2) ? 0.f : pl[CACHE_GOFF ? goff[it] : calc_goff(it)];
-    }
-  };
-  auto commit = [&](int chunk) {
-#pragma unroll
-    for (int u = 0; u < CHUNK; ++u) {
-      const int it = chunk * CHUNK + u;
-      const int rr = it * RPW + r0;
-      if (it < ITER && fill_lane && rr < NR) tile[rowpart(rr) + colpart] = nxt[u];
-    }
-  };
-  constexpr int NCHUNK = (ITER + CHUNK - 1) / CHUNK;
-
-  // wave w handles channels w, w+NWAVE, ... of the slice
-  int c = wave;
-  if (any_valid && c < nch) issue(base + (long)c * plane, 0);
-  for (; c < nch; c += NWAVE) {
-    const float* pl = base + (long)c * plane;
-    if (any_valid) {
-      commit(0);
-#pragma unroll
-      for (int ch = 1; ch < NCHUNK; ++ch) {
-        issue(pl, ch);
-        commit(ch);
+  // rare RoIs first (assigned to no level, or a 3-iteration sample loop), exact and simple
+#pragma unroll 1
+  for (int i = 0; i < NROI; ++i) {
+    const typename S::Roi& t = s.roi[i];
+    const int n = grp * NROI + i;
+    const int lvl = t.lvl;
+    if (lvl == -2) break;
+    const long obase = ((long)n * a.C + cbeg) * PP;
+    if (lvl < 0) {  // every per-level op sees a zero box
+      for (int e = tid; e < nch * PP; e += THREADS) {
+        a.out[obase + e] = 0.f;
+        a.ax[obase + e] = -1.f;
+        a.ay[obase + e] = -1.f;
       }
-      if (c + NWAVE < nch) issue(pl + (long)NWAVE * plane, 0);  // next channel, in flight below
+    } else if (t.fb_row || t.fb_col) {
+      const int H = a.L.H[lvl], W = a.L.W[lvl];
+      const long plane = (long)H * W;
+      const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
+      const float scale = a.L.scale[lvl];
+      for (int e = tid; e < nch * PP; e += THREADS) {
+        const int c = e / PP, bin = e % PP;
+        FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, t.box[0], t.box[1], t.box[2],
+                                      t.box[3], scale, bin / PW, bin % PW, PH, PW);
+        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
+        a.out[obase + e] = o.val;
+        a.ax[obase + e] = o.ax;
+        a.ay[obase + e] = o.ay;
+      }
     }
-    const long ob = obase + (long)c * PP;
+  }
+
+#pragma unroll 1
+  for (int i = 0; i < NROI; ++i) {
+    const typename S::Roi& t = s.roi[i];
+    const int n = grp * NROI + i;
+    const int lvl = t.lvl;
+    if (lvl == -2) break;
+    if (lvl < 0 || t.fb_row || t.fb_col) continue;
+    const long obase = ((long)n * a.C + cbeg) * PP;
+    const int W = a.L.W[lvl];
+    const long plane = (long)a.L.H[lvl] * W;
+    const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
+    const int any_valid = t.any_valid;
+
+    // per-lane constants of this RoI (kept in registers across channels)
+    int co = -1, dup = 0;
+    if (fill_lane) {
+      const int cl = t.coloff[2 * jp], cr = t.coloff[2 * jp + 1];
+      if (cl >= 0) {
+        co = cl == cr ? (cl < W - 1 ? cl : W - 2) : cl;
+        dup = cl == cr ? (co == cl ? 1 : 2) : 0;
+      }
+    }
+    const bool any_dup = __any(dup != 0);
+    // global offset of this lane's pair of fill instruction `it` within one channel plane; unused
+    // slots read elements 0,1 of the plane (always in bounds, never consumed)
+    auto calc_goff = [&](int it) {
+      const int rr = it * RPW + r0;
+      const int ro = (fill_lane && rr < NR) ? t.rowoff[rr] : -1;
+      return (ro >= 0 && co >= 0) ? ro + co : 0;
+    };
+    int goff[CACHE_GOFF ? ITER : 1];
+    if (CACHE_GOFF) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int bin = lane + i * kWave;
-      if (bin < PP) {
-        float maxval = bflag[i] ? -FLT_MAX : 0.f;
-        int best = -1;
-        if (any_valid) {
-          const float* t0 = tile + 2 * bin;
+      for (int it = 0; it < ITER; ++it) goff[it] = calc_goff(it);
+    }
+    int bflag[NI];
+    float4 wreg[REGW ? 4 : 1];
 #pragma unroll
-          for (int kl = 0; kl < 4; ++kl) {
-            const float4 w = s.wts[kl * PP + bin];
-            if (w.x == w.x) {
-              const float* t = t0 + (kl >> 1) * (4 * LS) + (kl & 1) * LS;
-              const float2 top = *reinterpret_cast<const float2*>(t);
-              const float2 bot = *reinterpret_cast<const float2*>(t + 2 * LS);
-              const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
-              if (value > maxval) { maxval = value; best = kl; }
-            }
+    for (int b = 0; b < NI; ++b) {
+      const int bin = lane + b * kWave;
+      bflag[b] = bin < PP ? t.binflag[bin] : 0;
+    }
+    if (REGW && lane < PP) {
+#pragma unroll
+      for (int kl = 0; kl < 4; ++kl) wreg[kl] = t.wts[kl * PP + lane];
+    }
+
+    float2 nxt[CHUNK];
+    auto issue = [&](const float* pl, int chunk) {
+#pragma unroll
+      for (int u = 0; u < CHUNK; ++u) {
+        const int it = chunk * CHUNK + u;
+        if (it < ITER) {
+          const int g = CACHE_GOFF ? goff[it] : calc_goff(it);
+          if (a.ablate & 2) nxt[u] = make_float2(0.f, 0.f);
+          else {  // two dword loads the compiler merges into one global_load_dwordx2
+            nxt[u].x = pl[g];
+            nxt[u].y = pl[g + 1];
           }
         }
-        float2 xy = make_float2(-1.f, -1.f);
-        if (best >= 0) xy = s.coord[best * PP + bin];
-        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-        if (!(a.ablate & 4)) {
-          a.out[ob + bin] = maxval;
-          a.ax[ob + bin] = xy.x;
-          a.ay[ob + bin] = xy.y;
+      }
+    };
+    auto commit = [&](int chunk) {
+#pragma unroll
+      for (int u = 0; u < CHUNK; ++u) {
+        const int it = chunk * CHUNK + u;
+        const int rr = it * RPW + r0;
+        if (it < ITER && fill_lane && rr < NR) {
+          float2 v = nxt[u];
+          if (any_dup) {
+            if (dup == 1) v.y = v.x;
+            if (dup == 2) v.x = v.y;
+          }
+          *reinterpret_cast<float2*>(tile + rowpart(rr) + colpart) = v;
+        }
+      }
+    };
+
+    // wave w handles channels w, w+NWAVE, ... of the slice
+    int c = wave;
+    if (any_valid && c < nch) issue(base + (long)c * plane, 0);
+    for (; c < nch; c += NWAVE) {
+      const float* pl = base + (long)c * plane;
+      if (any_valid) {
+        commit(0);
+#pragma unroll
+        for (int ch = 1; ch < NCHUNK; ++ch) {
+          issue(pl, ch);
+          commit(ch);
+        }
+        if (c + NWAVE < nch) issue(pl + (long)NWAVE * plane, 0);  // next channel, in flight below
+      }
+      const long ob = obase + (long)c * PP;
+#pragma unroll
+      for (int b = 0; b < NI; ++b) {
+        const int bin = lane + b * kWave;
+        if (bin < PP) {
+          float maxval = bflag[b] ? -FLT_MAX : 0.f;
+          int best = -1;
+          if (any_valid) {
+            const float* t0 = tile + 2 * bin;
+#pragma unroll
+            for (int kl = 0; kl < 4; ++kl) {
+              const float4 w = REGW ? wreg[kl] : t.wts[kl * PP + bin];
+              if (w.x == w.x) {
+                const float* tp = t0 + (kl >> 1) * (4 * LS) + (kl & 1) * LS;
+                const float2 top = *reinterpret_cast<const float2*>(tp);
+                const float2 bot = *reinterpret_cast<const float2*>(tp + 2 * LS);
+                const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
+                if (value > maxval) { maxval = value; best = kl; }
+              }
+            }
+          }
+          float2 xy = make_float2(-1.f, -1.f);
+          if (best >= 0) xy = t.coord[best * PP + bin];
+          if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+          if (!(a.ablate & 4)) {
+            a.out[ob + bin] = maxval;
+            a.ax[ob + bin] = xy.x;
+            a.ay[ob + bin] = xy.y;
+          }
         }
       }
     }
@@ -724,10 +794,22 @@ static int launch_fwd(FwdArgs& a, hipStream_t st) {
   a.nslice = 1;
   for (int d = 1; d <= a.C && d <= want; ++d)
     if (a.C % d == 0) a.nslice = d;
-  if (variant == 1 && a.PH == 7 && a.PW == 7) {
-    hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
-  } else if (variant == 1 && a.PH == 14 && a.PW == 14) {
-    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
+  // the tiled kernels fetch (left,right) column pairs with one 8-byte load: needs W >= 2
+  bool wide = true;
+  for (int l = 0; l < a.L.nlvl; ++l)
+    if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
+  const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
+  if (variant == 1 && wide && a.PH == 7 && a.PW == 7) {
+    if (rpw >= 4)
+      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 4>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512),
+                         0, st, a);
+    else if (rpw >= 2)
+      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 2>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512),
+                         0, st, a);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 1>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
+  } else if (variant == 1 && wide && a.PH == 14 && a.PW == 14) {
+    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
   } else {
     const int grid = (int)((count + 255) / 256 < 65536 * 16 ? (count + 255) / 256 : 65536 * 16);
     hipLaunchKernelGGL(roi_align_fwd_naive, dim3(grid), dim3(256), 0, st, a);

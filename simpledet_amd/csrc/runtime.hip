@@ -29,6 +29,7 @@ struct Knob {
 Knob g_knobs[] = {
     {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default)
     {"roi_align_fwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
+    {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 4)
     {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
     {"roi_align_bwd", 0, false},         // 0 global atomics, 1 LDS planes (default)
     {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 72
