@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--grad-allreduce", type=float, default=0.0,
                     help="MB of fp32 gradients all-reduced (RCCL) per step, overlapped; 0 = off")
     ap.add_argument("--tuning", action="append", default=[], help="key=value kernel knob (A/B)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also run the known-size HBM stream copies (measured peak + PMC calibration)")
     ap.add_argument("--extra", action="store_true", help="also time the un-fused 4-op graph path")
     return ap.parse_args()
 
@@ -162,21 +164,53 @@ def main():
         torch.cuda.synchronize()
         extra["unfused_4op_fwd_ms"] = e0.elapsed_time(e1) / 10
 
+    if args.calibrate and rank == 0:
+        import ctypes
+        nbytes = 1 << 30  # 1 GiB src + 1 GiB dst: far past the 256 MiB Infinity Cache
+        src = torch.empty(nbytes // 4, device="cuda", dtype=torch.float32).normal_()
+        dst = torch.empty_like(src)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        cal = {}
+        for width in (16, 8, 4):
+            for _ in range(2):
+                lib().call("sd_hbm_stream_copy", ctypes.c_void_p(src.data_ptr()),
+                           ctypes.c_void_p(dst.data_ptr()), nbytes, width, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                lib().call("sd_hbm_stream_copy", ctypes.c_void_p(src.data_ptr()),
+                           ctypes.c_void_p(dst.data_ptr()), nbytes, width, st)
+            e1.record()
+            torch.cuda.synchronize()
+            cal["copy%dB_GBs" % width] = 2 * nbytes / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
+        cal["bytes_read_per_launch"] = nbytes
+        cal["bytes_written_per_launch"] = nbytes
+        extra["hbm_stream_copy"] = cal
+        del src, dst
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
     alg = algorithmic_bytes(args.images, args.rois, args.channels, shapes)
+    # HBM-side bytes per forward launch from the committed PMC profile of this same command
+    # (profiles/*_pmc_summary.json, tools/profile_round.sh): 2 x FETCH_SIZE (gfx950 correction,
+    # confirmed on the known-size hbm_stream_copy in the same profile) + WRITE_SIZE
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "roi_align_fwd_pmc.json")
-    if os.path.exists(pmc_path):
+    import glob
+    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))[::-1]:
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            ks = json.load(open(pmc_path))["kernels"]
+            for name, d in ks.items():
+                if "roi_align_fwd_tiled" in name and "fetch_bytes_x2_gfx950" in d:
+                    traffic = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
+            if traffic is not None:
+                break
         except Exception:
             traffic = None
     roofline = {
-        "kernel": "roi_align_fwd_tiled<7,7,8,448> (fused FPN forward, 1 launch/step)",
+        "kernel": "sd::roi_align_fwd_tiled<7,7,4> (fused FPN forward, 1 launch/step)",
         "bound": "hbm",
         "achieved": alg / (fwd_ms * 1e-3) / 1e9,
         "peak": PEAK_HBM_GBS,

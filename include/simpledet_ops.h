@@ -49,6 +49,11 @@ int sd_abi_version(void);
 int sd_set_tuning(const char* key, int value);
 int sd_get_tuning(const char* key, int* value);
 
+/* HBM streaming copy (measurement aid, no reference counterpart): dst[i] = src[i] with
+ * width_bytes (4, 8 or 16) per lane.  bench.py uses it to report the achievable HBM rate next to
+ * the 8 TB/s spec peak and to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count */
+int sd_hbm_stream_copy(const void* src, void* dst, size_t bytes, int width_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ROIAlign_v2  (mx.sym.contrib.ROIAlign_v2, registered as _contrib_ROIAlign_v2)
  *   replaces ROIAlignForward_v2<gpu>  operator_cxx/contrib/roi_align_v2-inl.h:157-195

@@ -54,6 +54,36 @@ int tuning(const char* key, int dflt) {
 
 }  // namespace sd
 
+namespace sd {
+// HBM streaming copy: the measured-peak companion of the 8 TB/s spec figure and the known-byte
+// calibration stream for rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM).
+template <typename T>
+__global__ __launch_bounds__(256) void hbm_stream_copy(const T* __restrict__ src,
+                                                       T* __restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace sd
+
+extern "C" int sd_hbm_stream_copy(const void* src, void* dst, size_t bytes, int width_bytes,
+                                  void* stream) {
+  SD_REQUIRE(src && dst, "null buffer");
+  SD_REQUIRE(width_bytes == 4 || width_bytes == 8 || width_bytes == 16, "width must be 4, 8, 16");
+  SD_REQUIRE(bytes % width_bytes == 0, "bytes must be a multiple of the access width");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = bytes / width_bytes;
+  const int grid = sd::kNumCU * 8;
+  if (width_bytes == 16)
+    sd::hbm_stream_copy<float4><<<grid, 256, 0, st>>>((const float4*)src, (float4*)dst, n);
+  else if (width_bytes == 8)
+    sd::hbm_stream_copy<float2><<<grid, 256, 0, st>>>((const float2*)src, (float2*)dst, n);
+  else
+    sd::hbm_stream_copy<float><<<grid, 256, 0, st>>>((const float*)src, (float*)dst, n);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
 extern "C" const char* sd_last_error(void) { return sd::err_buf(); }
 extern "C" int sd_abi_version(void) { return 1; }
 
