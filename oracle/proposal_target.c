@@ -1,0 +1,242 @@
+/*
+ * ORACLE (test infrastructure, not product code) -- CPU restatement of ProposalTarget.
+ *
+ * Follows (DType = float, index_t = unsigned):
+ *   op        operator_cxx/proposal_target-inl.h:123-256 (ProposalTargetOp::Forward: gt clean-up
+ *             :155-162, roi clean-up + gt append :169-187, fg_rois_per_image truncation :194)
+ *   sampling  operator_cxx/proposal_target.cc:21-163 (SampleROI), :165-185 (BBoxOverlap),
+ *             :187-202 (ExpandBboxRegressionTargets), :204-227 (NonLinearTransformAndNormalization)
+ *   RNG       std::random_shuffle (libstdc++ bits/stl_algo.h: for i in [1,n): swap(a[i],
+ *             a[rand() % (i+1)])) over libc rand() (glibc random_r.c TYPE_3: degree 31, separation 3,
+ *             r[i] = r[i-3] + r[i-31], output >> 1, 310 warm-up draws after srandom_r's LCG fill)
+ * The RNG restatement is pinned against the real libc rand() and the real std::random_shuffle
+ * (oracle/shuffle_ref.cc) in tests/test_proposal_target.py.
+ *
+ * Reference undefined behaviour, defined here: an image with no valid gt box makes
+ * the reference read IOUs[i][0] out of bounds; here such an image yields max_overlap 0 / label 0
+ * for every roi and the function returns -1.  Output rows past kept_indexes.size() stay zero.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- glibc rand(): stdlib/random_r.c (TYPE_3) ---- */
+void orc_glibc_srand(orc_glibc_rand* st, unsigned seed) {
+  int32_t* r = st->r;
+  if (seed == 0) seed = 1; /* __srandom_r: "We must make sure the seed is not 0" */
+  r[0] = (int32_t)seed;
+  int32_t word = (int32_t)seed;
+  for (int i = 1; i < 31; ++i) { /* word = 16807 * hi ... Schrage, no overflow */
+    long hi = word / 127773;
+    long lo = word % 127773;
+    long w = 16807 * lo - 2836 * hi;
+    if (w < 0) w += 2147483647;
+    word = (int32_t)w;
+    r[i] = word;
+  }
+  st->f = 3; /* fptr = &state[rand_sep] */
+  st->b = 0; /* rptr = &state[0] */
+  for (int i = 0; i < 310; ++i) (void)orc_glibc_rand_next(st); /* kc = rand_deg * 10 discards */
+}
+
+int orc_glibc_rand_next(orc_glibc_rand* st) {
+  uint32_t* r = (uint32_t*)st->r;
+  uint32_t val = r[st->f] += r[st->b];
+  int result = (int)(val >> 1);
+  if (++st->f >= 31) st->f = 0;
+  if (++st->b >= 31) st->b = 0;
+  return result;
+}
+
+typedef int (*rand_fn)(void*);
+static int rand_state(void* p) { return orc_glibc_rand_next((orc_glibc_rand*)p); }
+static int rand_libc(void* p) { (void)p; return rand(); }
+
+/* libstdc++ std::random_shuffle(first, last) */
+static void shuffle(unsigned* a, size_t n, rand_fn rf, void* rs) {
+  for (size_t i = 1; i < n; ++i) {
+    size_t j = (size_t)(rf(rs) % (int)(i + 1));
+    if (i != j) { unsigned t = a[i]; a[i] = a[j]; a[j] = t; }
+  }
+}
+
+static inline float fmin2(float a, float b) { return b < a ? b : a; } /* std::min */
+static inline float fmax2(float a, float b) { return a < b ? b : a; } /* std::max */
+
+static int sample_roi(const float* all_rois, unsigned n_rois, const float* gt_boxes, unsigned n_gt,
+                      const orc_proposal_target_param* p, unsigned fg_rois_per_image,
+                      unsigned rois_per_image, rand_fn rf, void* rs, float* rois, float* labels,
+                      float* bbox_targets, float* bbox_weights, float* match_gt_ious,
+                      int* kept_out) {
+  int ub = 0;
+  float* max_overlaps = (float*)calloc(n_rois + 1, sizeof(float));
+  float* all_labels = (float*)calloc(n_rois + 1, sizeof(float));
+  unsigned* gt_assignment = (unsigned*)calloc(n_rois + 1, sizeof(unsigned));
+  if (n_gt == 0) {
+    ub = -1;
+  } else {
+    /* BBoxOverlap :165-185 + row arg-max :47-61 (first maximum wins: strict <) */
+    float* iou = (float*)calloc((size_t)n_rois * n_gt + 1, sizeof(float));
+    for (unsigned j = 0; j < n_gt; ++j) {
+      const float* q = gt_boxes + j * 5;
+      float query_box_area = (q[2] - q[0] + 1.f) * (q[3] - q[1] + 1.f);
+      for (unsigned i = 0; i < n_rois; ++i) {
+        const float* b = all_rois + i * 4;
+        float iw = fmin2(b[2], q[2]) - fmax2(b[0], q[0]) + 1.f;
+        if (iw > 0) {
+          float ih = fmin2(b[3], q[3]) - fmax2(b[1], q[1]) + 1.f;
+          if (ih > 0) {
+            float box_area = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+            float union_area = box_area + query_box_area - iw * ih;
+            iou[(size_t)i * n_gt + j] = iw * ih / union_area;
+          }
+        }
+      }
+    }
+    for (unsigned i = 0; i < n_rois; ++i) {
+      float max_value = iou[(size_t)i * n_gt];
+      unsigned max_index = 0;
+      for (unsigned j = 1; j < n_gt; ++j)
+        if (max_value < iou[(size_t)i * n_gt + j]) {
+          max_value = iou[(size_t)i * n_gt + j];
+          max_index = j;
+        }
+      gt_assignment[i] = max_index;
+      max_overlaps[i] = max_value;
+      all_labels[i] = gt_boxes[max_index * 5 + 4];
+    }
+    free(iou);
+  }
+  /* :67-79 */
+  unsigned* fg = (unsigned*)malloc(sizeof(unsigned) * (n_rois + 1));
+  unsigned* neg = (unsigned*)malloc(sizeof(unsigned) * (n_rois + 1));
+  unsigned* bg = (unsigned*)malloc(sizeof(unsigned) * (n_rois + 1));
+  unsigned* kept = (unsigned*)malloc(sizeof(unsigned) * (rois_per_image + n_rois + 1));
+  size_t nfg = 0, nneg = 0, nbg = 0, nkept = 0;
+  for (unsigned i = 0; i < n_rois; ++i) {
+    if (max_overlaps[i] >= p->fg_thresh) fg[nfg++] = i;
+    else neg[nneg++] = i;
+  }
+  /* :81-86 */
+  unsigned fg_this = fg_rois_per_image < nfg ? fg_rois_per_image : (unsigned)nfg;
+  if (nfg > fg_this) {
+    shuffle(fg, nfg, rf, rs);
+    nfg = fg_this;
+  }
+  /* :94-104 */
+  for (unsigned i = 0; i < n_rois; ++i)
+    if (max_overlaps[i] >= p->bg_thresh_lo && max_overlaps[i] < p->bg_thresh_hi) bg[nbg++] = i;
+  unsigned want_bg = rois_per_image - fg_this;
+  unsigned bg_this = want_bg < nbg ? want_bg : (unsigned)nbg;
+  if (nbg > bg_this) {
+    shuffle(bg, nbg, rf, rs);
+    nbg = bg_this;
+  }
+  for (unsigned i = 0; i < fg_this; ++i) kept[nkept++] = fg[i];
+  for (unsigned i = 0; i < bg_this; ++i) kept[nkept++] = bg[i];
+  /* :116-122 */
+  while (nkept < rois_per_image && nneg > 0) {
+    unsigned gap = rois_per_image - (unsigned)nkept;
+    shuffle(neg, nneg, rf, rs);
+    for (unsigned idx = 0; idx < gap && idx < nneg; ++idx) kept[nkept++] = neg[idx];
+  }
+  /* :128-135 */
+  for (size_t i = 0; i < nkept; ++i) {
+    if (i < fg_this) labels[i] = all_labels[kept[i]];
+    memcpy(rois + i * 4, all_rois + (size_t)kept[i] * 4, 4 * sizeof(float));
+    match_gt_ious[i] = max_overlaps[kept[i]];
+    if (kept_out) kept_out[i] = (int)kept[i];
+  }
+  /* :138-161: targets for every output row; rows >= nkept read garbage in the reference and end up
+   * zero because their label is 0, so they are skipped here */
+  const unsigned K4 = 4 * (unsigned)p->num_classes;
+  for (size_t i = 0; i < nkept && n_gt > 0; ++i) {
+    const float* ex = rois + i * 4;
+    const float* gt = gt_boxes + (size_t)gt_assignment[kept[i]] * 5;
+    /* NonLinearTransformAndNormalization :204-227; "0.5 *" is a double expression */
+    float ex_width = ex[2] - ex[0] + 1.f;
+    float ex_height = ex[3] - ex[1] + 1.f;
+    float ex_ctr_x = (float)(ex[0] + 0.5 * (ex_width - 1.f));
+    float ex_ctr_y = (float)(ex[1] + 0.5 * (ex_height - 1.f));
+    float gt_width = gt[2] - gt[0] + 1.f;
+    float gt_height = gt[3] - gt[1] + 1.f;
+    float gt_ctr_x = (float)(gt[0] + 0.5 * (gt_width - 1.f));
+    float gt_ctr_y = (float)(gt[1] + 0.5 * (gt_height - 1.f));
+    float t[4];
+    t[0] = (gt_ctr_x - ex_ctr_x) / (ex_width + 1e-14f);
+    t[1] = (gt_ctr_y - ex_ctr_y) / (ex_height + 1e-14f);
+    t[2] = logf(gt_width / ex_width); /* using std::log; log(float) -> float overload */
+    t[3] = logf(gt_height / ex_height);
+    for (int k = 0; k < 4; ++k) t[k] -= p->bbox_mean[k];
+    for (int k = 0; k < 4; ++k) t[k] /= p->bbox_std[k];
+    float cls_f = labels[i];
+    if (p->class_agnostic) cls_f = labels[i] < 1.f ? labels[i] : 1.f; /* :151-154 */
+    if (cls_f > 0) { /* ExpandBboxRegressionTargets :187-202 */
+      unsigned cls = (unsigned)cls_f;
+      unsigned start = 4 * cls;
+      if (start + 4 <= K4) {
+        memcpy(bbox_targets + i * K4 + start, t, 4 * sizeof(float));
+        memcpy(bbox_weights + i * K4 + start, p->bbox_weight, 4 * sizeof(float));
+      }
+    }
+  }
+  free(max_overlaps); free(all_labels); free(gt_assignment);
+  free(fg); free(neg); free(bg); free(kept);
+  return ub;
+}
+
+static int proposal_target_impl(const float* rois, const float* gt_boxes, int N, int M,
+                                const orc_proposal_target_param* p, rand_fn rf, void* rs,
+                                float* roi_out, float* label, float* bbox_target,
+                                float* bbox_weight, float* match_gt_iou, int* kept_index) {
+  const int B = p->batch_images, S = p->image_rois, K4 = 4 * p->num_classes;
+  int rc = 0;
+  /* outputs are zero-initialised containers (proposal_target-inl.h:189-193) */
+  memset(roi_out, 0, sizeof(float) * (size_t)B * S * 4);
+  memset(label, 0, sizeof(float) * (size_t)B * S);
+  memset(bbox_target, 0, sizeof(float) * (size_t)B * S * K4);
+  memset(bbox_weight, 0, sizeof(float) * (size_t)B * S * K4);
+  memset(match_gt_iou, 0, sizeof(float) * (size_t)B * S);
+  if (kept_index)
+    for (long i = 0; i < (long)B * S; ++i) kept_index[i] = -1;
+  unsigned fg_rois_per_image = (unsigned)(S * p->fg_fraction); /* :194 static_cast truncation */
+  float* kept_rois = (float*)malloc(sizeof(float) * 4 * (size_t)(N + M + 1));
+  float* kept_gt = (float*)malloc(sizeof(float) * 5 * (size_t)(M + 1));
+  for (int i = 0; i < B; ++i) {
+    unsigned n_gt = 0, n_rois = 0;
+    for (int j = 0; j < M; ++j) { /* :155-162 */
+      const float* g = gt_boxes + ((size_t)i * M + j) * 5;
+      if (g[4] != -1) memcpy(kept_gt + 5 * n_gt++, g, 5 * sizeof(float));
+    }
+    for (int j = 0; j < N; ++j) { /* :171-175, y2 == 0 indicates padding */
+      const float* r = rois + ((size_t)i * N + j) * 4;
+      if (r[3] > 0) memcpy(kept_rois + 4 * n_rois++, r, 4 * sizeof(float));
+    }
+    if (!p->proposal_without_gt) /* :177-185 */
+      for (unsigned j = 0; j < n_gt; ++j) memcpy(kept_rois + 4 * n_rois++, kept_gt + 5 * j, 4 * sizeof(float));
+    int e = sample_roi(kept_rois, n_rois, kept_gt, n_gt, p, fg_rois_per_image, (unsigned)S, rf, rs,
+                       roi_out + (size_t)i * S * 4, label + (size_t)i * S,
+                       bbox_target + (size_t)i * S * K4, bbox_weight + (size_t)i * S * K4,
+                       match_gt_iou + (size_t)i * S, kept_index ? kept_index + (size_t)i * S : NULL);
+    if (e) rc = e;
+  }
+  free(kept_rois); free(kept_gt);
+  return rc;
+}
+
+int orc_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
+                        const orc_proposal_target_param* p, orc_glibc_rand* rng, float* roi_out,
+                        float* label, float* bbox_target, float* bbox_weight, float* match_gt_iou,
+                        int* kept_index) {
+  return proposal_target_impl(rois, gt_boxes, N, M, p, rand_state, rng, roi_out, label,
+                              bbox_target, bbox_weight, match_gt_iou, kept_index);
+}
+
+int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, int M,
+                             const orc_proposal_target_param* p, float* roi_out, float* label,
+                             float* bbox_target, float* bbox_weight, float* match_gt_iou,
+                             int* kept_index) {
+  return proposal_target_impl(rois, gt_boxes, N, M, p, rand_libc, NULL, roi_out, label,
+                              bbox_target, bbox_weight, match_gt_iou, kept_index);
+}

@@ -124,3 +124,178 @@ def fpn_roi_align_bwd(dy, rois, ax, ay, feat_shapes, strides, canonical_scale=22
                                  R, ph, pw, ctypes.c_float(canonical_scale),
                                  ctypes.c_float(canonical_level), int(req), int(nthreads))
     return dfeats
+
+
+# ------------------------------------------------------------------------------------------------
+# ROIPooling_v1
+# ------------------------------------------------------------------------------------------------
+def roi_pool_v1_fwd(data, rois, pooled_size, spatial_scale):
+    data, pd = _f(data)
+    rois, pr = _f(rois)
+    B, C, H, W = data.shape
+    K = rois.shape[0]
+    ph, pw = pooled_size
+    out = np.empty((K, C, ph, pw), np.float32)
+    idx = np.empty_like(out)
+    cdll().orc_roi_pool_v1_fwd(pd, pr, out.ctypes, idx.ctypes, B, C, H, W, K, ph, pw,
+                               ctypes.c_float(spatial_scale))
+    return out, idx
+
+
+def roi_pool_v1_bwd(dy, rois, maxidx, data_shape, spatial_scale, req=1, dx=None, gather=False):
+    dy, pdy = _f(dy)
+    rois, pr = _f(rois)
+    maxidx, pm = _f(maxidx)
+    B, C, H, W = data_shape
+    K, _, ph, pw = dy.shape
+    if dx is None:
+        dx = np.zeros((B, C, H, W), np.float32)
+    fn = cdll().orc_roi_pool_v1_bwd_cpu_gather if gather else cdll().orc_roi_pool_v1_bwd
+    fn(pdy, pr, pm, dx.ctypes, B, C, H, W, K, ph, pw, ctypes.c_float(spatial_scale), int(req))
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# GenAnchor
+# ------------------------------------------------------------------------------------------------
+def _d(vals):
+    return (ctypes.c_double * len(vals))(*[float(v) for v in vals])
+
+
+def gen_base_anchors(stride, scales, ratios):
+    base = np.empty((len(ratios) * len(scales), 4), np.float64)
+    cdll().orc_gen_base_anchors(int(stride), _d(scales), len(scales), _d(ratios), len(ratios),
+                                base.ctypes)
+    return base
+
+
+def gen_anchor(H, W, stride, scales, ratios):
+    out = np.empty((H * W * len(scales) * len(ratios), 4), np.float32)
+    cdll().orc_gen_anchor(out.ctypes, int(H), int(W), int(stride), _d(scales), len(scales),
+                          _d(ratios), len(ratios))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# ProposalTarget
+# ------------------------------------------------------------------------------------------------
+class ProposalTargetParam(ctypes.Structure):
+    _fields_ = [("num_classes", ctypes.c_int), ("batch_images", ctypes.c_int),
+                ("image_rois", ctypes.c_int), ("fg_fraction", ctypes.c_float),
+                ("fg_thresh", ctypes.c_float), ("bg_thresh_hi", ctypes.c_float),
+                ("bg_thresh_lo", ctypes.c_float), ("proposal_without_gt", ctypes.c_int),
+                ("class_agnostic", ctypes.c_int), ("bbox_mean", ctypes.c_float * 4),
+                ("bbox_std", ctypes.c_float * 4), ("bbox_weight", ctypes.c_float * 4)]
+
+
+class GlibcRand(ctypes.Structure):
+    """glibc TYPE_3 rand() state (orc_glibc_rand)."""
+    _fields_ = [("r", ctypes.c_int32 * 34), ("f", ctypes.c_int32), ("b", ctypes.c_int32)]
+
+    def __init__(self, seed=1):
+        super().__init__()
+        cdll().orc_glibc_srand(ctypes.byref(self), ctypes.c_uint(seed))
+
+    def next(self):
+        return int(cdll().orc_glibc_rand_next(ctypes.byref(self)))
+
+    def state_words(self):
+        """(ring of 31 words, f, b) -- the layout sd_proposal_target's rng_state uses."""
+        return np.array(list(self.r)[:31] + [self.f, self.b], np.int32)
+
+
+def make_pt_param(num_classes, batch_images, image_rois, fg_fraction=0.25, fg_thresh=0.5,
+                  bg_thresh_hi=0.5, bg_thresh_lo=0.0, proposal_without_gt=False,
+                  class_agnostic=False, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2),
+                  bbox_weight=(1, 1, 1, 1)):
+    p = ProposalTargetParam()
+    p.num_classes, p.batch_images, p.image_rois = int(num_classes), int(batch_images), int(image_rois)
+    p.fg_fraction, p.fg_thresh = fg_fraction, fg_thresh
+    p.bg_thresh_hi, p.bg_thresh_lo = bg_thresh_hi, bg_thresh_lo
+    p.proposal_without_gt, p.class_agnostic = int(proposal_without_gt), int(class_agnostic)
+    for i in range(4):
+        p.bbox_mean[i], p.bbox_std[i], p.bbox_weight[i] = bbox_mean[i], bbox_std[i], bbox_weight[i]
+    return p
+
+
+def proposal_target(rois, gt_boxes, param, rng=None, use_libc=False):
+    """Returns (rois_out, label, bbox_target, bbox_weight, match_gt_iou, kept_index, rc)."""
+    rois, pr = _f(rois)
+    gt, pg = _f(gt_boxes)
+    B, N, _ = rois.shape
+    M = gt.shape[1]
+    S, K4 = param.image_rois, 4 * param.num_classes
+    ro = np.empty((B, S, 4), np.float32)
+    lb = np.empty((B, S), np.float32)
+    bt = np.empty((B, S, K4), np.float32)
+    bw = np.empty((B, S, K4), np.float32)
+    iou = np.empty((B, S), np.float32)
+    kept = np.empty((B, S), np.int32)
+    if use_libc:
+        rc = cdll().orc_proposal_target_libc(pr, pg, N, M, ctypes.byref(param), ro.ctypes,
+                                             lb.ctypes, bt.ctypes, bw.ctypes, iou.ctypes,
+                                             kept.ctypes)
+    else:
+        if rng is None:
+            rng = GlibcRand(1)
+        rc = cdll().orc_proposal_target(pr, pg, N, M, ctypes.byref(param), ctypes.byref(rng),
+                                        ro.ctypes, lb.ctypes, bt.ctypes, bw.ctypes, iou.ctypes,
+                                        kept.ctypes)
+    return ro, lb, bt, bw, iou, kept, rc
+
+
+def std_random_shuffle(a):
+    a = np.ascontiguousarray(a, np.uint32).copy()
+    cdll().orc_std_random_shuffle(a.ctypes, len(a))
+    return a
+
+
+def libc_srand(seed):
+    cdll().orc_libc_srand(ctypes.c_uint(seed))
+
+
+def libc_rand():
+    return int(cdll().orc_libc_rand())
+
+
+# ------------------------------------------------------------------------------------------------
+# NMS family
+# ------------------------------------------------------------------------------------------------
+def nms(dets, pre_nms_top_n, post_nms_top_n, threshold, already_sorted=False):
+    """_contrib_NMS (GPU path).  dets (B,N,5) -> out (B,post,4), score (B,post,1), keep (B,post)."""
+    dets, pd = _f(dets)
+    B, N, _ = dets.shape
+    pre = pre_nms_top_n if pre_nms_top_n > 0 else N
+    pre = min(pre, N)
+    post = min(post_nms_top_n, pre)
+    out = np.zeros((B, post, 4), np.float32)
+    score = np.zeros((B, post, 1), np.float32)
+    keep = np.zeros((B, post), np.int32)
+    cdll().orc_nms(pd, B, N, int(pre_nms_top_n), int(post_nms_top_n), ctypes.c_float(threshold),
+                   int(already_sorted), out.ctypes, score.ctypes, keep.ctypes)
+    return out, score, keep
+
+
+def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    boxes = np.array(boxes, dtype=np.float32, order="C", copy=True)
+    n = boxes.shape[0]
+    inds = np.empty(n, np.int64)
+    cdll().orc_soft_nms.restype = ctypes.c_int
+    N = cdll().orc_soft_nms(boxes.ctypes, inds.ctypes, n, ctypes.c_float(sigma),
+                            ctypes.c_float(Nt), ctypes.c_float(threshold), ctypes.c_uint(method))
+    return boxes[:N], inds[:N]
+
+
+def greedy_nms(dets, thresh):
+    dets, pd = _f(dets)
+    keep = np.empty(dets.shape[0], np.int64)
+    n = cdll().orc_greedy_nms(pd, dets.shape[0], ctypes.c_float(thresh), keep.ctypes)
+    return keep[:n]
+
+
+def bbox_overlaps(boxes, query):
+    boxes, pb = _f(boxes)
+    query, pq = _f(query)
+    ov = np.empty((boxes.shape[0], query.shape[0]), np.float32)
+    cdll().orc_bbox_overlaps(pb, boxes.shape[0], pq, query.shape[0], ov.ctypes)
+    return ov

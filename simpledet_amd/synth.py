@@ -159,3 +159,13 @@ def nms_dets(seed, num=1000, img_h=IMG_H, img_w=IMG_W, mode="clustered"):
         boxes[:, 1::2] = np.clip(boxes[:, 1::2], 0, img_h - 1)
     scores = rs.uniform(0.05, 1.0, (num, 1))
     return np.concatenate([boxes, scores], 1).astype(np.float32)
+
+
+def proposal_target_inputs(seed, batch=2, num=2000, max_gt=100, n_gt=None):
+    """(rois (B,num,4), gt (B,max_gt,5)) for ProposalTarget; n_gt fixes the gt count per image."""
+    if n_gt is None:
+        gt = gt_boxes(seed, batch, max_gt)
+    else:
+        gt = np.concatenate([gt_boxes(seed + 101 * b, 1, max_gt, min_n=n, max_n=n)
+                             for b, n in enumerate(n_gt)], 0)
+    return proposals(seed + 1, gt, num, pad_rows=max(1, num // 50)), gt

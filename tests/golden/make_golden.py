@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container (needs /root/reference and oracle/_ref built by oracle/build_ref.py):
+    python tests/golden/make_golden.py
+The fixtures are small .npz files committed next to this script; tests only read the .npz files
+(/root/reference does not exist on the GPU box).
+
+What is executed from the reference (no source is copied; functions are loaded from the files
+where they lie):
+  anchors.npz      symbol/builder.py:904-938  add_anchor_to_arg  (numpy; `mx.nd.array` stubbed
+                   with the identity because mxnet is not installed)
+  fpn_assign.npz   models/FPN/assign_layer_fpn.py:17-41  AssignLayerFPNOperator.forward, run with a
+                   float32 numpy shim of the eight mx.nd functions it calls (sqrt, floor, log2,
+                   clip, zeros_like, expand_dims, broadcast_like, where)
+  py_nms.npz       operator_py/nms.py:41-75   nms  (pure numpy hard NMS, suppress IoU > thresh)
+  cython_nms.npz   operator_py/cython/cpu_nms.pyx soft_nms / greedy_nms and bbox.pyx
+                   bbox_overlaps_cython, compiled by oracle/build_ref.py into oracle/_ref
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SIMPLEDET_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+
+def load_defs(path, names, env):
+    """exec only the named top-level defs/classes of a reference file into env."""
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body
+            if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert len(body) == len(names), (path, names)
+    mod = ast.Module(body=body, type_ignores=[])
+    exec(compile(mod, path, "exec"), env)
+    return env
+
+
+def clustered_dets(seed, n, ncl=25, extent=600.0):
+    rs = np.random.RandomState(seed)
+    c = rs.rand(ncl, 2) * extent
+    ctr = c[rs.randint(0, ncl, n)] + rs.randn(n, 2) * 6
+    wh = rs.rand(n, 2) * 80 + 12
+    sc = rs.permutation(n).astype(np.float32) / n * 0.95 + 0.05  # distinct scores
+    return np.concatenate([ctr - wh / 2, ctr + wh / 2, sc[:, None]], 1).astype(np.float32)
+
+
+def make_anchors():
+    class _ND:
+        @staticmethod
+        def array(x):
+            return x
+    mx = types.SimpleNamespace(nd=_ND)
+    env = load_defs(os.path.join(REF, "symbol", "builder.py"), ["add_anchor_to_arg"], {"mx": mx})
+    out = {}
+    # config/faster_r50v1_fpn_1x.py:49-53,149-154: strides (4..64), scale 8, ratios .5/1/2 (max_side
+    # 320 instead of 1400 keeps the fixture small; the grid code is size independent)
+    args = {}
+    env["add_anchor_to_arg"](None, args, None, 320, (4, 8, 16, 32, 64), (8,), (0.5, 1.0, 2.0))
+    for k, v in args.items():
+        out["fpn_" + k] = np.asarray(v, np.float32)
+    # C4 setting: stride 16, scales 2..32
+    args = {}
+    env["add_anchor_to_arg"](None, args, None, 320, 16, (2, 4, 8, 16, 32), (0.5, 1.0, 2.0))
+    for k, v in args.items():
+        out["c4_" + k] = np.asarray(v, np.float32)
+    np.savez_compressed(os.path.join(HERE, "anchors.npz"), **out)
+
+
+def make_fpn_assign():
+    f32 = np.float32
+
+    class _Arr(np.ndarray):
+        """float32 ndarray whose ** and astype behave like mx.nd (fp32 compute)."""
+        def astype(self, t, *a, **k):
+            return np.asarray(self).astype(t).view(_Arr) if t != "uint8" else \
+                np.asarray(self).astype(np.uint8).view(_Arr)
+
+    def A(x):
+        return np.asarray(x, f32).view(_Arr)
+
+    class _ND:
+        sqrt = staticmethod(lambda x: A(np.sqrt(np.asarray(x, f32))))
+        floor = staticmethod(lambda x: A(np.floor(np.asarray(x, f32))))
+        log2 = staticmethod(lambda x: A(np.log2(np.asarray(x, f32))))
+        clip = staticmethod(lambda x, lo, hi: A(np.clip(np.asarray(x, f32), f32(lo), f32(hi))))
+        zeros_like = staticmethod(lambda x: A(np.zeros_like(np.asarray(x, f32))))
+        expand_dims = staticmethod(lambda x, axis: np.expand_dims(np.asarray(x), axis).view(_Arr))
+        broadcast_like = staticmethod(lambda x, y: A(np.broadcast_to(np.asarray(x), y.shape)))
+        where = staticmethod(lambda c, a, b: A(np.where(np.asarray(c) != 0, a, b)))
+
+    class _CustomOp:
+        def __init__(self):
+            pass
+
+        def assign(self, dst, req, src):
+            dst[...] = src
+
+    class _Operator:
+        CustomOp = _CustomOp
+        CustomOpProp = object
+
+        @staticmethod
+        def register(name):
+            return lambda c: c
+    mx = types.SimpleNamespace(nd=_ND, operator=_Operator)
+    env = load_defs(os.path.join(REF, "models", "FPN", "assign_layer_fpn.py"),
+                    ["AssignLayerFPNOperator"], {"mx": mx, "np": np})
+    from simpledet_amd import synth
+    rois = np.concatenate([synth.random_rois(s, 1, 256) for s in range(4)], 0)  # (4,256,4)
+    # sizes straddling every level boundary exactly (sqrt(area) = 112, 224, 448 +- 1 px)
+    edge = []
+    for s in (56, 111, 112, 113, 223, 224, 225, 447, 448, 449, 900):
+        edge.append([10, 20, 10 + s - 1, 20 + s - 1])
+    rois[0, :len(edge)] = np.asarray(edge, f32)
+    strides = (4, 8, 16, 32)
+    op = env["AssignLayerFPNOperator"](strides, 224, 4)
+    outs = [np.zeros_like(rois) for _ in strides]
+    op.forward(True, ["write"] * 4, [A(rois)], outs, [])
+    np.savez_compressed(os.path.join(HERE, "fpn_assign.npz"), rois=rois,
+                        strides=np.asarray(strides), per_level=np.stack(outs))
+
+
+def make_py_nms():
+    env = load_defs(os.path.join(REF, "operator_py", "nms.py"), ["nms"], {"np": np})
+    out = {}
+    for seed in range(3):
+        d = clustered_dets(seed, 300)
+        out["dets%d" % seed] = d
+        out["kept%d" % seed] = env["nms"](d, 0.5)
+    np.savez_compressed(os.path.join(HERE, "py_nms.npz"), **out)
+
+
+def make_cython_nms():
+    from oracle._ref import bbox, cpu_nms
+    out = {}
+    for seed in range(3):
+        d = clustered_dets(10 + seed, 250)
+        out["dets%d" % seed] = d
+        for m, name in ((0, "hard"), (1, "linear"), (2, "gaussian")):
+            b, i = cpu_nms.soft_nms(d, np.float32(0.5), np.float32(0.3), np.float32(0.05),
+                                    np.uint8(m))
+            out["soft_%s_boxes%d" % (name, seed)] = b
+            out["soft_%s_inds%d" % (name, seed)] = np.asarray(i, np.int64)
+        out["greedy%d" % seed] = np.asarray(cpu_nms.greedy_nms(d, np.float32(0.45)), np.int64)
+        out["overlaps%d" % seed] = bbox.bbox_overlaps_cython(d[:, :4].copy(), d[:40, :4].copy())
+    np.savez_compressed(os.path.join(HERE, "cython_nms.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_anchors()
+    make_fpn_assign()
+    make_py_nms()
+    make_cython_nms()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
