@@ -99,6 +99,94 @@ int sd_fpn_roi_assign(const float* rois, int n_rois, const int* strides_host, in
                       float roi_canonical_scale, float roi_canonical_level, float* rois_per_level,
                       int32_t* level, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ROIPooling_v1  (mx.sym.ROIPooling_v1)
+ *   replaces ROIPoolForward (GPU)  operator_cxx/roi_pooling_v1.cu:48-113 / ROIPoolForward_v1 (CPU)
+ *            roi_pooling_v1.cc:39-126, op wrapper roi_pooling_v1-inl.h:70-94
+ *   data (B,C,H,W)  rois (K,5) [batch_index,x1,y1,x2,y2]  out, maxidx (K,C,ph,pw)
+ *   maxidx holds the flat argmax h*W+w as a float, -1 for an empty bin.
+ * ---------------------------------------------------------------------------------------------- */
+int sd_roi_pool_v1_fwd(const float* data, const float* rois, float* out, float* maxidx, int B,
+                       int C, int H, int W, int K, int pooled_h, int pooled_w, float spatial_scale,
+                       void* stream);
+/*   replaces ROIPoolBackward  roi_pooling_v1.cu:115-152, wrapper roi_pooling_v1-inl.h:96-133
+ *   (d_data honours req_data: write = zero first, add = accumulate; d_rois zeroed on write) */
+int sd_roi_pool_v1_bwd(const float* out_grad, const float* rois, const float* maxidx,
+                       float* d_data, float* d_rois, int req_data, int req_rois, int B, int C,
+                       int H, int W, int K, int pooled_h, int pooled_w, float spatial_scale,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * _contrib_GenAnchor  (mx.sym.contrib.GenAnchor)
+ *   replaces GenAnchorGPUOp::Forward  operator_cxx/contrib/generate_anchor.cu:97-153
+ *            (base anchors generate_anchor-inl.h:140-181 in double on the host, grid kernel :61-81)
+ *   out (H*W*A, 4) fp32, A = n_ratios*n_scales (ratio-major), row (h*W + w)*A + a.
+ *   The same grid with H = W = max_side/stride is symbol/builder.py:904-938 add_anchor_to_arg.
+ * ---------------------------------------------------------------------------------------------- */
+int sd_gen_anchor(float* out, int H, int W, int feature_stride, const double* scales_host,
+                  int n_scales, const double* ratios_host, int n_ratios, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ProposalTarget  (mx.sym.ProposalTarget)
+ *   replaces ProposalTargetOp::Forward  operator_cxx/proposal_target-inl.h:123-256 and SampleROI
+ *            operator_cxx/proposal_target.cc:21-227 -- which copy to the host and run single
+ *            threaded; here everything stays on the device.
+ *   rois (B,N,4)  gt_boxes (B,M,5) [x1,y1,x2,y2,cls], cls == -1 padding
+ *   roi_output (B,S,4)  label (B,S)  bbox_target, bbox_weight (B,S,4*num_classes)
+ *   match_gt_iou (B,S)   (S = image_rois; all outputs are written, kWriteTo semantics)
+ *   kept_index (B,S) int32, optional (may be NULL): index into the image's candidate list
+ *   [rois with y2 > 0 in order, then the valid gt boxes] of every output row, -1 = unfilled.
+ *   rng_state: DEVICE array of 33 int32 = glibc rand() TYPE_3 state (31-word ring, front index,
+ *   rear index); advanced in place exactly as the reference advances libc's global state through
+ *   std::random_shuffle.  Fill a host copy with sd_glibc_srand_host (seed 1 == never-seeded libc).
+ *   workspace: DEVICE scratch of sd_proposal_target_workspace_bytes(B, N, M) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int num_classes, batch_images, image_rois;
+  float fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo;
+  int proposal_without_gt, class_agnostic;
+  float bbox_mean[4], bbox_std[4], bbox_weight[4];
+} sd_proposal_target_param;
+#define SD_GLIBC_RAND_STATE_WORDS 33
+int sd_glibc_srand_host(uint32_t seed, int32_t* state_host);
+size_t sd_proposal_target_workspace_bytes(int B, int N, int M);
+int sd_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
+                       const sd_proposal_target_param* param_host, int32_t* rng_state,
+                       float* roi_output, float* label, float* bbox_target, float* bbox_weight,
+                       float* match_gt_iou, int32_t* kept_index, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * _contrib_NMS  (mx.sym.contrib.NMS; the same kernel is embedded in Proposal_v3)
+ *   replaces NMSGPUOp::Forward  operator_cxx/contrib/nms.cu:249-365 (nms_kernel :102-147, host
+ *            scan _nms :149-202 with its D2H/H2D copies, PrepareOutput :207-233)
+ *   dets (B,N,5) [x1,y1,x2,y2,score].  pre = pre_nms_top_n > 0 ? min(pre_nms_top_n, N) : N,
+ *   post = min(post_nms_top_n, pre).  out (B,post,4), score (B,post): kept boxes in score order,
+ *   zero padded.  keep_index (B,post) int32 optional: original row of every kept box, -1 pad.
+ *   threshold_ge = 0: suppress IoU > threshold (nms.cu:140); 1: IoU >= threshold
+ *   (proposal_v3.cu:319).  The sort is stable (ties keep the lower input row first).
+ *   workspace: DEVICE scratch of sd_nms_workspace_bytes(B, N, pre_nms_top_n) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sd_nms_workspace_bytes(int B, int N, int pre_nms_top_n);
+int sd_nms(const float* dets, int B, int N, int pre_nms_top_n, int post_nms_top_n, float threshold,
+           int threshold_ge, int already_sorted, float* out, float* score, int32_t* keep_index,
+           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * soft_nms, batched  (operator_py/cython/cpu_nms.pyx:98-203 through operator_py/nms.py:5-16; the
+ *   reference runs one Python-object loop per (image, class) in a process pool,
+ *   detection_test.py:233-267)
+ *   dets (P,Nmax,5): problem p uses rows [0, counts[p]).  method 0 hard, 1 linear, 2 gaussian.
+ *   out_dets (P,Nmax,5) / out_inds (P,Nmax): the surviving boxes with their decayed scores and
+ *   their input rows, in selection order; out_counts (P).  Rows past out_counts[p] are unspecified.
+ * ---------------------------------------------------------------------------------------------- */
+int sd_soft_nms_batched(const float* dets, const int32_t* counts, int P, int Nmax, float sigma,
+                        float Nt, float threshold, int method, float* out_dets, int32_t* out_inds,
+                        int32_t* out_counts, void* stream);
+/* bbox_overlaps_cython  (operator_py/cython/bbox.pyx:31-72): overlaps (n,k) */
+int sd_bbox_overlaps(const float* boxes, int n, const float* query_boxes, int k, float* overlaps,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

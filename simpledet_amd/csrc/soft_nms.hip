@@ -1,0 +1,285 @@
+// Batched soft-NMS (and bbox_overlaps) for gfx950.
+//   reference: operator_py/cython/cpu_nms.pyx:98-203 (soft_nms: in-place selection sort with
+//              score decay and swap-with-last removal), operator_py/nms.py:5-16 (wrapper),
+//              detection_test.py:233-267 (one call per (image, class), process pool);
+//              operator_py/cython/bbox.pyx:31-72 (bbox_overlaps_cython).
+// The algorithm is N dependent steps per problem, so throughput comes from running 1000+ problems
+// at once, each entirely on-chip: one workgroup per problem, boxes as six SoA planes in LDS
+// (24 B/box), and per step only two workgroup barriers:
+//   read the arg-max (already reduced during the previous step's rescoring pass) -> barrier ->
+//   rescore every remaining box against it, fold the NEXT arg-max into the same pass, ballot the
+//   "fell below threshold" flags -> barrier.
+// Removal keeps the reference's exact order semantics (hole filled by the last box, which is then
+// examined in the hole): because every box's decay depends only on the selected box, all flags are
+// computed in parallel and the reference's two-pointer walk is replayed on the 64-bit flag words by
+// one wave, moving only the boxes that really move.
+// Arithmetic follows the Cython-generated C expression by expression: "+ 1" is a DOUBLE add there
+// (the literal becomes 1.0), products of two such terms are double products narrowed on assignment.
+#include "common.h"
+#include "../../include/simpledet_ops.h"
+#include <math.h>
+
+namespace sd {
+
+struct SoftArgs {
+  const float* dets;
+  const int* counts;
+  float* out_dets;
+  int* out_inds;
+  int* out_counts;
+  int P, Nmax;
+  float sigma, Nt, thr;
+  int method;
+};
+
+__device__ __forceinline__ float pmin(float a, float b) { return a <= b ? a : b; }  // cpu_nms.pyx:27
+__device__ __forceinline__ float pmax(float a, float b) { return a >= b ? a : b; }  // cpu_nms.pyx:30
+
+struct Cand {
+  float s;
+  int pos;  // -1: none
+};
+// "maxscore < boxes[pos, 4]" scanning upward from i: the first maximum wins, NaN never wins
+__device__ __forceinline__ Cand better(Cand a, Cand b) {
+  if (b.pos < 0) return a;
+  if (a.pos < 0) return b;
+  if (b.s > a.s || (b.s == a.s && b.pos < a.pos)) return b;
+  return a;
+}
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Cand d;
+    d.s = __shfl_xor(c.s, o);
+    d.pos = __shfl_xor(c.pos, o);
+    c = better(c, d);
+  }
+  return c;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
+  constexpr int NW = THREADS / kWave;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int p = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int Nmax = a.Nmax;
+  float* X1 = smem;
+  float* Y1 = X1 + Nmax;
+  float* X2 = Y1 + Nmax;
+  float* Y2 = X2 + Nmax;
+  float* S = Y2 + Nmax;
+  int* IND = reinterpret_cast<int*>(S + Nmax);
+  // after the six planes: flag words, per-wave partial arg-max, control words
+  unsigned long long* FW = reinterpret_cast<unsigned long long*>(smem + (((size_t)6 * Nmax + 1) & ~(size_t)1));
+  const int nwords = (Nmax + 63) / 64 + 1;
+  float* PS = reinterpret_cast<float*>(FW + nwords);
+  int* PP = reinterpret_cast<int*>(PS + NW);
+  int* CTRL = PP + NW;  // [0] = N, [1] = iteration stamp of the last removal
+
+  int n = a.counts ? a.counts[p] : Nmax;
+  n = n < 0 ? 0 : (n > Nmax ? Nmax : n);
+  const float* src = a.dets + (long)p * Nmax * 5;
+  for (int e = tid; e < n * 5; e += THREADS) {
+    const int pos = e / 5, k = e % 5;
+    smem[k * Nmax + pos] = src[e];
+  }
+  for (int pos = tid; pos < n; pos += THREADS) IND[pos] = pos;
+  if (tid == 0) {
+    CTRL[0] = n;
+    CTRL[1] = -1;
+  }
+  __syncthreads();
+
+  int N = n;
+  bool have_best = false;
+  for (int i = 0; i < n; ++i) {  // range(N) is evaluated once (cpu_nms.pyx:115)
+    if (i >= N) break;
+    if (!have_best) {
+      Cand c{0.f, -1};
+      for (int pos = i + wave * kWave + lane; pos < N; pos += THREADS) {
+        const float sc = S[pos];
+        if (sc == sc) c = better(c, Cand{sc, pos});
+      }
+      c = wave_best(c);
+      if (lane == 0) {
+        PS[wave] = c.s;
+        PP[wave] = c.pos;
+      }
+      __syncthreads();
+    }
+    // ---- selected box: arg-max over [i, N), box i wins ties and is immune to NaN comparisons ----
+    Cand best{0.f, -1};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) best = better(best, Cand{PS[w], PP[w]});
+    const float si = S[i];
+    int maxpos = best.pos;
+    if (maxpos < 0 || !(si == si) || !(si < best.s)) maxpos = i;
+    // registers: the selected box (t*) and the old box i, which goes to position maxpos
+    const float tx1 = X1[maxpos], ty1 = Y1[maxpos], tx2 = X2[maxpos], ty2 = Y2[maxpos];
+    const float ts = S[maxpos];
+    const int ti = IND[maxpos];
+    const float ix1 = X1[i], iy1 = Y1[i], ix2 = X2[i], iy2 = Y2[i];
+    const int ii = IND[i];
+    __syncthreads();  // everyone holds t* / old i before anybody overwrites them
+    if (tid == 0 && maxpos != i) {
+      X1[i] = tx1; Y1[i] = ty1; X2[i] = tx2; Y2[i] = ty2; S[i] = ts; IND[i] = ti;
+    }
+    const double tarea = ((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0);
+
+    // ---- decay every remaining box; fold the next arg-max and the removal flags into the pass ----
+    Cand c{0.f, -1};
+    bool any_removed = false;
+    const int M = N - (i + 1);
+    for (int chunk = wave; chunk * kWave < M; chunk += NW) {
+      const int rel = chunk * kWave + lane;
+      const int pos = i + 1 + rel;
+      bool removed = false;
+      if (rel < M) {
+        float x1, y1, x2, y2, s;
+        if (pos == maxpos) {  // receives the old box i (the swap of cpu_nms.pyx:136-150)
+          x1 = ix1; y1 = iy1; x2 = ix2; y2 = iy2; s = si;
+          X1[pos] = x1; Y1[pos] = y1; X2[pos] = x2; Y2[pos] = y2; IND[pos] = ii;
+        } else {
+          x1 = X1[pos]; y1 = Y1[pos]; x2 = X2[pos]; y2 = Y2[pos]; s = S[pos];
+        }
+        const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+        const float iw = (float)((double)(pmin(tx2, x2) - pmax(tx1, x1)) + 1.0);
+        float ns = s;
+        if (iw > 0) {
+          const float ih = (float)((double)(pmin(ty2, y2) - pmax(ty1, y1)) + 1.0);
+          if (ih > 0) {
+            const float ua = (float)((tarea + (double)area) - (double)(iw * ih));
+            const float ov = iw * ih / ua;
+            float weight;
+            if (a.method == 1) weight = ov > a.Nt ? (float)(1.0 - (double)ov) : 1.f;
+            else if (a.method == 2) weight = (float)exp((double)(-(ov * ov) / a.sigma));
+            else weight = ov > a.Nt ? 0.f : 1.f;
+            ns = weight * s;
+            removed = ns < a.thr;
+          }
+        }
+        if (pos == maxpos || ns != s || !(ns == ns)) S[pos] = ns;
+        if (!removed && ns == ns) c = better(c, Cand{ns, pos});
+      }
+      const unsigned long long fw = __ballot(removed);
+      if (lane == 0) FW[chunk] = fw;
+      any_removed |= fw != 0;
+    }
+    c = wave_best(c);
+    if (lane == 0) {
+      PS[wave] = c.s;
+      PP[wave] = c.pos;
+      if (any_removed) CTRL[1] = i;
+    }
+    __syncthreads();
+    have_best = true;
+    if (CTRL[1] == i) {
+      // ---- replay "swap with the last box, shrink, re-examine" on the flag words (one wave) ----
+      if (wave == 0) {
+        int Mc = M;
+        const int nw = (M + 63) / 64;
+        auto flag = [&](int r) { return (FW[r >> 6] >> (r & 63)) & 1ull; };
+        auto next_hole = [&](int from) {  // first flagged rel position >= from, or Mc
+          int w = from >> 6;
+          if (w >= nw) return 1 << 30;
+          unsigned long long m = FW[w] & (~0ull << (from & 63));
+          while (!m) {
+            if (++w >= nw) return 1 << 30;
+            m = FW[w];
+          }
+          return (w << 6) + __ffsll((long long)m) - 1;
+        };
+        int hole = next_hole(0);
+        while (hole < Mc) {
+          --Mc;  // the last box leaves its place
+          if (Mc == hole) break;       // the hole was the last box
+          if (flag(Mc)) continue;      // moved into the hole, examined, removed as well
+          if (lane < 6) smem[lane * Nmax + i + 1 + hole] = smem[lane * Nmax + i + 1 + Mc];
+          hole = next_hole(hole + 1);
+        }
+        if (lane == 0) CTRL[0] = i + 1 + Mc;
+      }
+      __syncthreads();
+      N = CTRL[0];
+      have_best = false;  // positions moved: recompute the arg-max from scratch
+    }
+  }
+
+  if (tid == 0) a.out_counts[p] = N;
+  float* od = a.out_dets + (long)p * Nmax * 5;
+  for (int e = tid; e < N * 5; e += THREADS) od[e] = smem[(e % 5) * Nmax + e / 5];
+  int* oi = a.out_inds + (long)p * Nmax;
+  for (int pos = tid; pos < N; pos += THREADS) oi[pos] = IND[pos];
+}
+
+__global__ __launch_bounds__(256) void bbox_overlaps_kernel(const float* boxes, int n,
+                                                            const float* query, int k,
+                                                            float* overlaps) {
+  const long count = (long)n * k;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < count;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(idx % k), nn = (int)(idx / k);
+    const float4 b = reinterpret_cast<const float4*>(boxes)[nn];
+    const float4 q = reinterpret_cast<const float4*>(query)[kk];
+    // Cython builtin min/max on C floats: min(a,b) = b < a ? b : a, max(a,b) = b > a ? b : a
+    const float box_area = (float)(((double)(q.z - q.x) + 1.0) * ((double)(q.w - q.y) + 1.0));
+    float ov = 0.f;
+    const float iw = (float)((double)((q.z < b.z ? q.z : b.z) - (q.x > b.x ? q.x : b.x)) + 1.0);
+    if (iw > 0) {
+      const float ih = (float)((double)((q.w < b.w ? q.w : b.w) - (q.y > b.y ? q.y : b.y)) + 1.0);
+      if (ih > 0) {
+        const float ua = (float)(((((double)(b.z - b.x) + 1.0) * ((double)(b.w - b.y) + 1.0)) +
+                                  (double)box_area) - (double)(iw * ih));
+        ov = iw * ih / ua;
+      }
+    }
+    overlaps[idx] = ov;
+  }
+}
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" int sd_soft_nms_batched(const float* dets, const int32_t* counts, int P, int Nmax,
+                                   float sigma, float Nt, float threshold, int method,
+                                   float* out_dets, int32_t* out_inds, int32_t* out_counts,
+                                   void* stream) {
+  SD_REQUIRE(P >= 0 && Nmax >= 0, "negative dimension");
+  SD_REQUIRE(method >= 0 && method <= 2, "Unknown soft_nms method: %d", method);
+  if (P == 0) return SD_OK;
+  SD_REQUIRE(out_counts, "out_counts is null");
+  if (Nmax == 0) {
+    SD_HIP_CHECK(hipMemsetAsync(out_counts, 0, sizeof(int) * (size_t)P, (hipStream_t)stream));
+    return SD_OK;
+  }
+  SD_REQUIRE(dets && out_dets && out_inds, "null tensor pointer");
+  constexpr int T = 256;
+  const size_t lds = (((size_t)6 * Nmax + 1) & ~(size_t)1) * 4 + ((size_t)(Nmax + 63) / 64 + 1) * 8 +
+                     (size_t)(T / kWave) * 8 + 16;
+  SD_REQUIRE(lds <= 160 * 1024, "soft_nms: Nmax=%d needs %zu B of LDS (limit 160 KB)", Nmax, lds);
+  SoftArgs a{dets, counts, out_dets, out_inds, out_counts, P, Nmax, sigma, Nt, threshold, method};
+  auto k = soft_nms_kernel<T>;
+  if (lds > 64 * 1024)
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  hipLaunchKernelGGL(k, dim3(P), dim3(T), lds, (hipStream_t)stream, a);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+extern "C" int sd_bbox_overlaps(const float* boxes, int n, const float* query_boxes, int k,
+                                float* overlaps, void* stream) {
+  SD_REQUIRE(n >= 0 && k >= 0, "negative dimension");
+  const long count = (long)n * k;
+  if (count == 0) return SD_OK;
+  SD_REQUIRE(boxes && query_boxes && overlaps, "null tensor pointer");
+  SD_REQUIRE((((uintptr_t)boxes | (uintptr_t)query_boxes) & 15) == 0, "boxes must be 16-B aligned");
+  const int grid = (int)((count + 255) / 256 < kNumCU * 16 ? (count + 255) / 256 : kNumCU * 16);
+  hipLaunchKernelGGL(bbox_overlaps_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, boxes, n,
+                     query_boxes, k, overlaps);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}

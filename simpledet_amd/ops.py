@@ -175,3 +175,188 @@ def fpn_roi_align_backward(out_grad, rois, maxidx_x, maxidx_y, feat_shapes, rcnn
                _iarr([f.shape[3] for f in d_feats]), _iarr(rcnn_stride), len(d_feats), rd, B, C, R,
                ph, pw, float(roi_canonical_scale), float(roi_canonical_level), _stream())
     return d_feats
+
+
+# --------------------------------------------------------------------------------------------------
+# ROIPooling_v1  (operator_cxx/roi_pooling_v1{-inl.h,.cc,.cu})
+# --------------------------------------------------------------------------------------------------
+def roi_pool_v1_forward(data, rois, pooled_size, spatial_scale):
+    """ROIPooling_v1 forward: data (B,C,H,W), rois (K,5) -> output, maxidx (K,C,ph,pw)
+    (shape inference roi_pooling_v1-inl.h:172-199)."""
+    _chk(data, "data", ndim=4)
+    _chk(rois, "rois", ndim=2)
+    if rois.shape[1] != 5:
+        raise ValueError("bbox should be a 2D tensor of shape [batch, 5]")
+    ph, pw = _pair(pooled_size)
+    B, C, H, W = data.shape
+    K = rois.shape[0]
+    out = torch.empty((K, C, ph, pw), device=data.device, dtype=torch.float32)
+    idx = torch.empty_like(out)
+    lib().call("sd_roi_pool_v1_fwd", _p(data), _p(rois), _p(out), _p(idx), B, C, H, W, K, ph, pw,
+               float(spatial_scale), _stream())
+    return out, idx
+
+
+def roi_pool_v1_backward(out_grad, rois, maxidx, data_shape, spatial_scale, req_data="write",
+                         req_rois="write", d_data=None):
+    """_backward_ROIPooling_v1: [dY, rois, maxidx] -> [dX, d_rois] (roi_pooling_v1-inl.h:96-133)."""
+    _chk(out_grad, "out_grad", ndim=4)
+    _chk(rois, "rois", ndim=2)
+    _chk(maxidx, "maxidx", ndim=4)
+    B, C, H, W = [int(v) for v in data_shape]
+    K, Co, ph, pw = out_grad.shape
+    if Co != C or rois.shape[0] != K:
+        raise ValueError("shape mismatch")
+    rd = REQ[req_data] if isinstance(req_data, str) else int(req_data)
+    rr = REQ[req_rois] if isinstance(req_rois, str) else int(req_rois)
+    if d_data is None:
+        if rd == REQ["add"]:
+            raise ValueError("req_data='add' needs the d_data tensor to accumulate into")
+        d_data = torch.empty((B, C, H, W), device=out_grad.device, dtype=torch.float32)
+    d_rois = torch.empty_like(rois) if rr != 0 else None
+    lib().call("sd_roi_pool_v1_bwd", _p(out_grad), _p(rois), _p(maxidx), _p(d_data), _p(d_rois), rd,
+               rr, B, C, H, W, K, ph, pw, float(spatial_scale), _stream())
+    return d_data, d_rois
+
+
+# --------------------------------------------------------------------------------------------------
+# _contrib_GenAnchor  (operator_cxx/contrib/generate_anchor{-inl.h,.cc,.cu})
+# --------------------------------------------------------------------------------------------------
+def _darr(vals):
+    return (ctypes.c_double * len(vals))(*[float(v) for v in vals])
+
+
+def gen_anchor(height, width, feature_stride, scales, ratios, device=None):
+    """GenAnchor: (H*W*A, 4) fp32 anchors, row (h*W + w)*A + a, A ratio-major
+    (generate_anchor-inl.h:176-180; shape generate_anchor-inl.h:92-106)."""
+    scales, ratios = list(scales), list(ratios)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    A = len(scales) * len(ratios)
+    out = torch.empty((int(height) * int(width) * A, 4), device=device, dtype=torch.float32)
+    lib().call("sd_gen_anchor", _p(out), int(height), int(width), int(feature_stride),
+               _darr(scales), len(scales), _darr(ratios), len(ratios), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# ProposalTarget  (operator_cxx/proposal_target{-inl.h,.cc})
+# --------------------------------------------------------------------------------------------------
+class ProposalTargetParam(ctypes.Structure):
+    """sd_proposal_target_param == ProposalTargetParam (proposal_target-inl.h:81-114)."""
+    _fields_ = [("num_classes", ctypes.c_int), ("batch_images", ctypes.c_int),
+                ("image_rois", ctypes.c_int), ("fg_fraction", ctypes.c_float),
+                ("fg_thresh", ctypes.c_float), ("bg_thresh_hi", ctypes.c_float),
+                ("bg_thresh_lo", ctypes.c_float), ("proposal_without_gt", ctypes.c_int),
+                ("class_agnostic", ctypes.c_int), ("bbox_mean", ctypes.c_float * 4),
+                ("bbox_std", ctypes.c_float * 4), ("bbox_weight", ctypes.c_float * 4)]
+
+
+def glibc_rand_state(seed=1, device=None):
+    """Device copy of libc's rand() state after srand(seed) (33 int32).  seed=1 is the state of a
+    process that never called srand -- what the reference op sees (no srand anywhere in it)."""
+    host = (ctypes.c_int32 * 33)()
+    lib().call("sd_glibc_srand_host", ctypes.c_uint32(seed), host)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    return torch.tensor(list(host), dtype=torch.int32, device=device)
+
+
+def proposal_target(rois, gt_boxes, num_classes, batch_images, image_rois, fg_fraction=0.25,
+                    fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0, proposal_without_gt=False,
+                    class_agnostic=False, bbox_mean=(0., 0., 0., 0.), bbox_std=(.1, .1, .2, .2),
+                    bbox_weight=(1., 1., 1., 1.), rng_state=None, return_index=False):
+    """ProposalTarget: rois (B,N,4), gt_boxes (B,M,5) -> roi_output (B,S,4), label (B,S),
+    bbox_target (B,S,4K), bbox_weight (B,S,4K), match_gt_iou (B,S)  (proposal_target-inl.h:297-330).
+    rng_state: int32[33] device tensor from glibc_rand_state(); advanced in place."""
+    _chk(rois, "rois", ndim=3)
+    _chk(gt_boxes, "gt_boxes", ndim=3)
+    B, N, _ = rois.shape
+    if rois.shape[2] != 4 or gt_boxes.shape[2] != 5 or gt_boxes.shape[0] != B:
+        raise ValueError("rois must be (B,N,4) and gt_boxes (B,M,5)")
+    if B != int(batch_images):
+        raise ValueError("batch_images=%d but rois has batch %d" % (batch_images, B))
+    M = gt_boxes.shape[1]
+    p = ProposalTargetParam()
+    p.num_classes, p.batch_images, p.image_rois = int(num_classes), int(batch_images), int(image_rois)
+    p.fg_fraction, p.fg_thresh = float(fg_fraction), float(fg_thresh)
+    p.bg_thresh_hi, p.bg_thresh_lo = float(bg_thresh_hi), float(bg_thresh_lo)
+    p.proposal_without_gt, p.class_agnostic = int(bool(proposal_without_gt)), int(bool(class_agnostic))
+    for i in range(4):
+        p.bbox_mean[i], p.bbox_std[i], p.bbox_weight[i] = bbox_mean[i], bbox_std[i], bbox_weight[i]
+    if rng_state is None:
+        rng_state = glibc_rand_state(1, rois.device)
+    _chk(rng_state, "rng_state", dtype=torch.int32, ndim=1)
+    S, K4 = int(image_rois), 4 * int(num_classes)
+    dev = rois.device
+    ro = torch.empty((B, S, 4), device=dev, dtype=torch.float32)
+    lb = torch.empty((B, S), device=dev, dtype=torch.float32)
+    bt = torch.empty((B, S, K4), device=dev, dtype=torch.float32)
+    bw = torch.empty((B, S, K4), device=dev, dtype=torch.float32)
+    iou = torch.empty((B, S), device=dev, dtype=torch.float32)
+    kept = torch.empty((B, S), device=dev, dtype=torch.int32) if return_index else None
+    wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    lib().call("sd_proposal_target", _p(rois), _p(gt_boxes), N, M, ctypes.byref(p), _p(rng_state),
+               _p(ro), _p(lb), _p(bt), _p(bw), _p(iou), _p(kept), _p(ws), ctypes.c_size_t(wsb),
+               _stream())
+    res = (ro, lb, bt, bw, iou)
+    return res + (kept,) if return_index else res
+
+
+# --------------------------------------------------------------------------------------------------
+# _contrib_NMS  (operator_cxx/contrib/nms{-inl.h,.cu}) and the Cython soft-NMS family
+# --------------------------------------------------------------------------------------------------
+def nms(dets, rpn_pre_nms_top_n=6000, rpn_post_nms_top_n=300, threshold=0.7, already_sorted=False,
+        threshold_ge=False, return_index=False):
+    """_contrib_NMS (GPU path nms.cu:249-365): dets (B,N,5) -> out (B,post,4), score (B,post,1)
+    (shape nms-inl.h:96-107; post = min(rpn_post_nms_top_n, pre))."""
+    _chk(dets, "dets", ndim=3)
+    if dets.shape[2] != 5:
+        raise ValueError("bbox should be (batch, rois, 5)")
+    B, N, _ = dets.shape
+    pre = int(rpn_pre_nms_top_n) if rpn_pre_nms_top_n > 0 else N
+    pre = min(pre, N)
+    post = min(int(rpn_post_nms_top_n), pre)
+    out = torch.empty((B, post, 4), device=dets.device, dtype=torch.float32)
+    score = torch.empty((B, post, 1), device=dets.device, dtype=torch.float32)
+    keep = torch.empty((B, post), device=dets.device, dtype=torch.int32) if return_index else None
+    wsb = lib().cdll.sd_nms_workspace_bytes(B, N, int(rpn_pre_nms_top_n))
+    ws = torch.empty(wsb, device=dets.device, dtype=torch.uint8)
+    lib().call("sd_nms", _p(dets), B, N, int(rpn_pre_nms_top_n), int(rpn_post_nms_top_n),
+               float(threshold), int(bool(threshold_ge)), int(bool(already_sorted)), _p(out),
+               _p(score), _p(keep), _p(ws), ctypes.c_size_t(wsb), _stream())
+    return (out, score, keep) if return_index else (out, score)
+
+
+SOFT_NMS_METHODS = {"hard": 0, "linear": 1, "gaussian": 2}
+
+
+def soft_nms_batched(dets, counts=None, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """soft_nms (cpu_nms.pyx:98-203) on P problems at once: dets (P,Nmax,5), counts (P) int32 ->
+    out_dets (P,Nmax,5), out_inds (P,Nmax) int32, out_counts (P) int32 (rows past the count are
+    unspecified)."""
+    _chk(dets, "dets", ndim=3)
+    if dets.shape[2] != 5:
+        raise ValueError("dets should be (problems, boxes, 5)")
+    P, Nmax, _ = dets.shape
+    if counts is not None:
+        _chk(counts, "counts", dtype=torch.int32, ndim=1)
+    if isinstance(method, str):
+        if method not in SOFT_NMS_METHODS:
+            raise ValueError("Unknown soft_nms method: {}".format(method))
+        method = SOFT_NMS_METHODS[method]
+    od = torch.empty_like(dets)
+    oi = torch.empty((P, Nmax), device=dets.device, dtype=torch.int32)
+    oc = torch.empty((P,), device=dets.device, dtype=torch.int32)
+    lib().call("sd_soft_nms_batched", _p(dets), _p(counts), P, Nmax, float(sigma), float(Nt),
+               float(threshold), int(method), _p(od), _p(oi), _p(oc), _stream())
+    return od, oi, oc
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """bbox_overlaps_cython (bbox.pyx:31-72): boxes (n,4), query_boxes (k,4) -> overlaps (n,k)."""
+    _chk(boxes, "boxes", ndim=2)
+    _chk(query_boxes, "query_boxes", ndim=2)
+    n, k = boxes.shape[0], query_boxes.shape[0]
+    ov = torch.empty((n, k), device=boxes.device, dtype=torch.float32)
+    lib().call("sd_bbox_overlaps", _p(boxes), n, _p(query_boxes), k, _p(ov), _stream())
+    return ov

@@ -93,7 +93,7 @@ def gt_boxes(seed, batch=2, max_gt=100, num_classes=81, img_h=IMG_H, img_w=IMG_W
     rs = np.random.RandomState(seed)
     out = -np.ones((batch, max_gt, 5), np.float32)
     for b in range(batch):
-        n = rs.randint(min_n, max_n + 1)
+        n = rs.randint(min(min_n, max_gt), min(max_n, max_gt) + 1)
         w = np.exp(rs.uniform(np.log(16), np.log(600), n))
         h = np.exp(rs.uniform(np.log(16), np.log(500), n))
         x1 = rs.uniform(0, np.maximum(img_w - w, 1))

@@ -1,0 +1,298 @@
+"""HIP-vs-oracle parity for ROIPooling_v1, GenAnchor, _contrib_NMS, soft-NMS, bbox_overlaps and
+ProposalTarget (GPU), through the C ABI.  Bars: everything integer / index / selection is bit-exact;
+floats produced by +,-,*,/ are bit-exact (IEEE ops in the reference's order); the only tolerance
+is 1e-6 relative on the two log() box deltas of ProposalTarget (device logf vs glibc logf)."""
+import os
+
+import numpy as np
+import pytest
+
+from simpledet_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------------------------- RoIPool --
+def _pool_case(seed, B=2, C=5, H=25, W=42, K=40, stride=32):
+    rs = np.random.RandomState(seed)
+    data = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    r = synth.random_rois(seed, 1, K, H * stride, W * stride)[0]
+    rois = np.concatenate([rs.randint(0, B, (K, 1)).astype(np.float32), r], 1)
+    return data, rois
+
+
+@pytest.mark.gpu
+def test_roi_pool_reference_docstring_golden_on_gpu(ops):
+    x = np.arange(48, dtype=np.float32).reshape(1, 1, 8, 6)
+    y = np.array([[0, 0, 0, 4, 4]], np.float32)
+    out, idx = ops.roi_pool_v1_forward(_t(x), _t(y), (2, 2), 1.0)
+    np.testing.assert_array_equal(out.cpu().numpy(), [[[[14, 16], [26, 28]]]])
+    out, _ = ops.roi_pool_v1_forward(_t(x), _t(y), (2, 2), 0.7)
+    np.testing.assert_array_equal(out.cpu().numpy(), [[[[7, 9], [19, 21]]]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(0, 7, 7, 1 / 32.0), (1, 7, 7, 1 / 16.0), (2, 3, 5, 1 / 32.0),
+                                  (3, 14, 14, 1 / 32.0)])
+def test_roi_pool_forward_backward(ops, oracle, case):
+    seed, ph, pw, scale = case
+    data, rois = _pool_case(seed)
+    want, widx = oracle.roi_pool_v1_fwd(data, rois, (ph, pw), scale)
+    out, idx = ops.roi_pool_v1_forward(_t(data), _t(rois), (ph, pw), scale)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    np.testing.assert_array_equal(idx.cpu().numpy(), widx)
+    dy = np.random.RandomState(9).standard_normal(want.shape).astype(np.float32)
+    wdx = oracle.roi_pool_v1_bwd(dy, rois, widx, data.shape, scale)
+    dx, drois = ops.roi_pool_v1_backward(_t(dy), _t(rois), idx, data.shape, scale)
+    np.testing.assert_allclose(dx.cpu().numpy(), wdx, rtol=1e-5, atol=1e-5)
+    assert float(drois.abs().max()) == 0
+    # kAddTo accumulates
+    dx2, _ = ops.roi_pool_v1_backward(_t(dy), _t(rois), idx, data.shape, scale, req_data="add",
+                                      req_rois="null", d_data=dx.clone())
+    np.testing.assert_allclose(dx2.cpu().numpy(), 2 * wdx, rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError, match="kWriteInplace"):
+        ops.roi_pool_v1_backward(_t(dy), _t(rois), idx, data.shape, scale, req_data=2)
+
+
+# ----------------------------------------------------------------------------------- GenAnchor --
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride,shape", [(4, (200, 334)), (8, (100, 167)), (16, (50, 84)),
+                                          (32, (25, 42)), (64, (13, 21))])
+def test_gen_anchor_fpn_levels_bit_exact(ops, oracle, stride, shape):
+    h, w = shape
+    got = ops.gen_anchor(h, w, stride, [8], [0.5, 1.0, 2.0]).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.gen_anchor(h, w, stride, [8], [0.5, 1.0, 2.0]))
+
+
+@pytest.mark.gpu
+def test_gen_anchor_matches_reference_numpy_twin_fixture(ops):
+    g = np.load(os.path.join(GOLD, "anchors.npz"))
+    for stride in (4, 8, 16, 32, 64):
+        ref = g["fpn_anchor_stride%d" % stride]
+        n = ref.shape[2]
+        got = ops.gen_anchor(n, n, stride, [8], [0.5, 1.0, 2.0]).cpu().numpy()
+        np.testing.assert_array_equal(got.reshape(ref.shape), ref)
+    ref = g["c4_anchor_stride16"]
+    n = ref.shape[2]
+    got = ops.gen_anchor(n, n, 16, [2, 4, 8, 16, 32], [0.5, 1.0, 2.0]).cpu().numpy()
+    np.testing.assert_array_equal(got.reshape(ref.shape), ref)
+
+
+@pytest.mark.gpu
+def test_gen_anchor_odd_ratios_and_errors(ops, oracle):
+    got = ops.gen_anchor(7, 9, 16, [1.5, 3, 20], [0.3, 0.77, 4.2]).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.gen_anchor(7, 9, 16, [1.5, 3, 20], [0.3, 0.77, 4.2]))
+    assert ops.gen_anchor(0, 5, 16, [8], [1.0]).shape == (0, 4)
+    with pytest.raises(RuntimeError):
+        ops.gen_anchor(4, 4, 16, [8], [-1.0])
+
+
+# ---------------------------------------------------------------------------------- hard NMS ----
+def _nms_batch(seeds, n, mode="clustered"):
+    return np.stack([synth.nms_dets(s, n, mode=mode) for s in seeds])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(n=2000, pre=-1, post=1000, thr=0.7), dict(n=2000, pre=1000, post=300, thr=0.7),
+    dict(n=1000, pre=6000, post=1000, thr=0.5), dict(n=777, pre=500, post=600, thr=0.3),
+    dict(n=64, pre=-1, post=64, thr=0.5), dict(n=65, pre=-1, post=10, thr=0.5),
+    dict(n=1, pre=-1, post=1, thr=0.5), dict(n=5000, pre=-1, post=2000, thr=0.7)])
+def test_nms_matches_oracle(ops, oracle, cfg):
+    dets = _nms_batch([1, 2, 3], cfg["n"])
+    want = oracle.nms(dets, cfg["pre"], cfg["post"], cfg["thr"])
+    out, score, keep = ops.nms(_t(dets), cfg["pre"], cfg["post"], cfg["thr"], return_index=True)
+    np.testing.assert_array_equal(keep.cpu().numpy(), want[2])
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+    np.testing.assert_array_equal(score.cpu().numpy(), want[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["no_overlap", "all_overlap"])
+def test_nms_stress_sets_and_ties(ops, oracle, mode):
+    dets = _nms_batch([4, 5], 1000, mode)
+    dets[:, :, 4] = np.round(dets[:, :, 4] * 16) / 16  # many exact score ties: stable order matters
+    want = oracle.nms(dets, -1, 1000, 0.5)
+    out, score, keep = ops.nms(_t(dets), -1, 1000, 0.5, return_index=True)
+    np.testing.assert_array_equal(keep.cpu().numpy(), want[2])
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+
+
+@pytest.mark.gpu
+def test_nms_already_sorted_and_ge_threshold(ops, oracle):
+    dets = _nms_batch([7], 600)
+    order = np.argsort(-dets[0, :, 4], kind="stable")
+    sd = dets[:, order]
+    want = oracle.nms(sd, -1, 600, 0.6, already_sorted=True)
+    out, score = ops.nms(_t(sd), -1, 600, 0.6, already_sorted=True)
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+    # >= variant (proposal_v3.cu:319 / greedy_nms): equals the reference's Cython greedy_nms set
+    g = np.load(os.path.join(GOLD, "cython_nms.npz"))
+    d = g["dets0"]
+    _, _, keep = ops.nms(_t(d[None]), -1, d.shape[0], 0.45, threshold_ge=True, return_index=True)
+    k = keep.cpu().numpy()[0]
+    np.testing.assert_array_equal(np.sort(k[k >= 0]), g["greedy0"])
+
+
+@pytest.mark.gpu
+def test_nms_matches_reference_numpy_nms_fixture(ops):
+    g = np.load(os.path.join(GOLD, "py_nms.npz"))
+    for seed in range(3):
+        d, kept = g["dets%d" % seed], g["kept%d" % seed]
+        out, score = ops.nms(_t(d[None]), -1, d.shape[0], 0.5)
+        n = kept.shape[0]
+        np.testing.assert_array_equal(out.cpu().numpy()[0, :n], kept[:, :4])
+        np.testing.assert_array_equal(score.cpu().numpy()[0, :n, 0], kept[:, 4])
+        assert float(out[0, n:].abs().max()) == 0
+
+
+@pytest.mark.gpu
+def test_nms_workspace_and_size_errors(ops):
+    import torch
+    from simpledet_amd._lib import lib, SimpleDetOpsError
+    import ctypes
+    d = _t(_nms_batch([1], 100))
+    out = torch.empty((1, 100, 4), device="cuda")
+    sc = torch.empty((1, 100), device="cuda")
+    with pytest.raises(SimpleDetOpsError, match="workspace"):
+        lib().call("sd_nms", ctypes.c_void_p(d.data_ptr()), 1, 100, -1, 100, 0.5, 0, 0,
+                   ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(sc.data_ptr()), None, None, 0,
+                   None)
+    big = torch.zeros((1, 20000, 5), device="cuda")
+    with pytest.raises(SimpleDetOpsError, match="sort capacity"):
+        ops.nms(big, -1, 10, 0.5)
+
+
+# ---------------------------------------------------------------------------------- soft NMS ----
+def _soft_expect(oracle, dets, counts, sigma, Nt, thr, method):
+    res = []
+    for p in range(dets.shape[0]):
+        res.append(oracle.soft_nms(dets[p, :counts[p]], sigma, Nt, thr, method))
+    return res
+
+
+def _soft_check(ops, oracle, dets, counts, sigma, Nt, thr, method):
+    import torch
+    od, oi, oc = ops.soft_nms_batched(_t(dets), _t(counts.astype(np.int32)), sigma, Nt, thr, method)
+    od, oi, oc = od.cpu().numpy(), oi.cpu().numpy(), oc.cpu().numpy()
+    for p, (wb, wi) in enumerate(_soft_expect(oracle, dets, counts, sigma, Nt, thr, method)):
+        assert oc[p] == len(wi), (p, oc[p], len(wi))
+        np.testing.assert_array_equal(oi[p, :oc[p]], wi)
+        np.testing.assert_array_equal(od[p, :oc[p]], wb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_soft_nms_matches_oracle(ops, oracle, method):
+    rs = np.random.RandomState(method)
+    P, Nmax = 12, 300
+    dets = np.stack([synth.nms_dets(100 + p, Nmax) for p in range(P)])
+    counts = np.array([300, 299, 257, 256, 255, 129, 64, 63, 2, 1, 0, 300])
+    _soft_check(ops, oracle, dets, counts, 0.5, 0.3, 0.05, method)
+    # reference defaults (detection_test.py: Nt=thresh 0.5, score_thresh 0.001)
+    _soft_check(ops, oracle, dets, counts, 0.5, 0.5, 0.001, method)
+
+
+@pytest.mark.gpu
+def test_soft_nms_ties_duplicates_and_full_size(ops, oracle):
+    # exact score ties + duplicated boxes: the selection order must follow position order
+    d = synth.nms_dets(3, 400)
+    d[:, 4] = np.round(d[:, 4] * 8) / 8
+    d[100:150] = d[:50]
+    dets = np.stack([d, synth.nms_dets(4, 400, mode="all_overlap"),
+                     synth.nms_dets(5, 400, mode="no_overlap")])
+    counts = np.array([400, 400, 400])
+    for method in (0, 1, 2):
+        _soft_check(ops, oracle, dets, counts, 0.5, 0.3, 0.01, method)
+    # the baseline problem size: 1000 boxes
+    big = np.stack([synth.nms_dets(50 + p, 1000) for p in range(4)])
+    _soft_check(ops, oracle, big, np.array([1000] * 4), 0.5, 0.5, 0.001, 1)
+
+
+@pytest.mark.gpu
+def test_soft_nms_matches_reference_cython_fixture(ops):
+    g = np.load(os.path.join(GOLD, "cython_nms.npz"))
+    for seed in range(3):
+        d = g["dets%d" % seed]
+        for m, name in ((0, "hard"), (1, "linear"), (2, "gaussian")):
+            od, oi, oc = ops.soft_nms_batched(_t(d[None]), None, 0.5, 0.3, 0.05, m)
+            n = int(oc[0])
+            np.testing.assert_array_equal(oi.cpu().numpy()[0, :n], g["soft_%s_inds%d" % (name, seed)])
+            np.testing.assert_array_equal(od.cpu().numpy()[0, :n], g["soft_%s_boxes%d" % (name, seed)])
+        ov = ops.bbox_overlaps(_t(d[:, :4]), _t(d[:40, :4]))
+        np.testing.assert_array_equal(ov.cpu().numpy(), g["overlaps%d" % seed])
+
+
+# ----------------------------------------------------------------------------- ProposalTarget ---
+def _pt_check(ops, oracle, rois, gt, seed=1, **kw):
+    B = rois.shape[0]
+    p = oracle.make_pt_param(kw.pop("num_classes", 81), B, kw.pop("image_rois", 512), **kw)
+    rng = oracle.GlibcRand(seed)
+    want = oracle.proposal_target(rois, gt, p, rng=rng)
+    state = ops.glibc_rand_state(seed)
+    got = ops.proposal_target(
+        _t(rois), _t(gt), p.num_classes, B, p.image_rois, p.fg_fraction, p.fg_thresh,
+        p.bg_thresh_hi, p.bg_thresh_lo, bool(p.proposal_without_gt), bool(p.class_agnostic),
+        tuple(p.bbox_mean), tuple(p.bbox_std), tuple(p.bbox_weight), rng_state=state,
+        return_index=True)
+    ro, lb, bt, bw, iou, kept = [x.cpu().numpy() for x in got]
+    np.testing.assert_array_equal(kept, want[5])     # sampled indices: bit exact
+    np.testing.assert_array_equal(ro, want[0])
+    np.testing.assert_array_equal(lb, want[1])
+    np.testing.assert_array_equal(iou, want[4])
+    np.testing.assert_array_equal(bw, want[3])
+    np.testing.assert_array_equal(bt != 0, want[2] != 0)
+    np.testing.assert_allclose(bt, want[2], rtol=1e-6, atol=1e-7)
+    # the generator state advanced by exactly the draws the reference consumes
+    np.testing.assert_array_equal(state.cpu().numpy(), rng.state_words())
+    return want
+
+
+@pytest.mark.gpu
+def test_proposal_target_baseline_config(ops, oracle):
+    rois, gt = synth.proposal_target_inputs(0, 2, 2000, 100)
+    want = _pt_check(ops, oracle, rois, gt)
+    assert want[6] == 0
+    assert (want[1] > 0).sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["few_fg", "many_fg", "no_neg_pad", "agnostic", "without_gt",
+                                  "tiny", "state_carries"])
+def test_proposal_target_cases(ops, oracle, case):
+    if case == "few_fg":       # fg list shorter than fg_per_image: no fg shuffle, bg shuffle only
+        rois, gt = synth.proposal_target_inputs(1, 2, 500, 20, n_gt=(2, 1))
+        _pt_check(ops, oracle, rois, gt, image_rois=128)
+    elif case == "many_fg":    # low fg threshold: fg shuffle + truncation
+        rois, gt = synth.proposal_target_inputs(2, 2, 800, 50, n_gt=(30, 40))
+        _pt_check(ops, oracle, rois, gt, image_rois=64, fg_thresh=0.2, bg_thresh_hi=0.2)
+    elif case == "no_neg_pad":  # bg window excludes most rois: the neg padding loop runs (repeatedly)
+        rois, gt = synth.proposal_target_inputs(3, 2, 60, 10, n_gt=(3, 4))
+        _pt_check(ops, oracle, rois, gt, image_rois=256, bg_thresh_lo=0.1)
+    elif case == "agnostic":
+        rois, gt = synth.proposal_target_inputs(4, 3, 400, 30)
+        _pt_check(ops, oracle, rois, gt, image_rois=128, class_agnostic=True, num_classes=2,
+                  bbox_mean=(0.01, -0.02, 0.03, 0.0), bbox_weight=(1, 2, 3, 4))
+    elif case == "without_gt":
+        rois, gt = synth.proposal_target_inputs(5, 2, 400, 30)
+        _pt_check(ops, oracle, rois, gt, image_rois=128, proposal_without_gt=True)
+    elif case == "tiny":
+        rois, gt = synth.proposal_target_inputs(6, 1, 8, 3, n_gt=(1,))
+        _pt_check(ops, oracle, rois, gt, image_rois=16, seed=12345)
+    else:                       # two consecutive calls share one generator state
+        rois, gt = synth.proposal_target_inputs(7, 2, 600, 40)
+        import torch
+        p = oracle.make_pt_param(81, 2, 128)
+        rng = oracle.GlibcRand(1)
+        state = ops.glibc_rand_state(1)
+        for _ in range(2):
+            want = oracle.proposal_target(rois, gt, p, rng=rng)
+            got = ops.proposal_target(_t(rois), _t(gt), 81, 2, 128, rng_state=state,
+                                      return_index=True)
+            np.testing.assert_array_equal(got[5].cpu().numpy(), want[5])
+        np.testing.assert_array_equal(state.cpu().numpy(), rng.state_words())
