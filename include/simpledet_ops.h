@@ -187,6 +187,45 @@ int sd_soft_nms_batched(const float* dets, const int32_t* counts, int P, int Nma
 int sd_bbox_overlaps(const float* boxes, int n, const float* query_boxes, int k, float* overlaps,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DeformableConvolution v1  (mx.sym.contrib.DeformableConvolution; call site models/dcn/
+ *   builder.py:14-17).  The arithmetic is upstream MXNet 1.6.0 (un-vendored third party,
+ *   src/operator/contrib/nn/deformable_im2col.cuh + deformable_convolution-inl.h): each entry point
+ *   replaces the function of the same name there.
+ *   x (N,C,H,W)  offset (N, dgroup*2*kh*kw, Ho, Wo)  weight (F, C, kh, kw)  y (N,F,Ho,Wo)
+ *   col (N, C*kh*kw, Ho*Wo), row (c*kh + i)*kw + j
+ * ---------------------------------------------------------------------------------------------- */
+int sd_deform_im2col(const float* x, const float* offset, float* col, int N, int C, int H, int W,
+                     int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                     int dil_w, int dgroup, void* stream);
+/* data gradient: d_x (N,C,H,W) (+)= scatter of col (deformable_col2im) */
+int sd_deform_col2im(const float* col, const float* offset, float* d_x, int req, int N, int C,
+                     int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                     int dil_h, int dil_w, int dgroup, void* stream);
+/* offset gradient: d_offset like offset (deformable_col2im_coord) */
+int sd_deform_col2im_coord(const float* col, const float* x, const float* offset, float* d_offset,
+                           int req, int N, int C, int H, int W, int kh, int kw, int pad_h,
+                           int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dgroup,
+                           void* stream);
+/* fp32 MFMA GEMM (row-major, batched over grid.z): C[b] = op(A[b]) . op(B[b]); op(A) is M x K.
+ * accumulate: 0 store, 1 C += product, 2 atomic add (several batches into one C: strideC = 0).
+ * Replaces the linalg_gemm calls of deformable_convolution-inl.h (cuBLAS sgemm in the reference). */
+int sd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, long strideA,
+                const float* B, int ldb, long strideB, float* C, int ldc, long strideC, int batch,
+                int accumulate, void* stream);
+size_t sd_deform_conv_workspace_bytes(int N, int C, int H, int W, int kh, int kw, int pad,
+                                      int stride, int dil);
+/* forward = im2col + GEMM, num_group = 1, no bias (the reference's configuration) */
+int sd_deform_conv_fwd(const float* x, const float* offset, const float* weight, float* y, int N,
+                       int C, int H, int W, int F, int kh, int kw, int pad, int stride, int dil,
+                       int dgroup, void* workspace, size_t workspace_bytes, void* stream);
+/* backward: d_x, d_offset, d_weight with their own req (0 null / 1 write / 3 add) */
+int sd_deform_conv_bwd(const float* out_grad, const float* x, const float* offset,
+                       const float* weight, float* d_x, float* d_offset, float* d_weight,
+                       int req_x, int req_offset, int req_weight, int N, int C, int H, int W,
+                       int F, int kh, int kw, int pad, int stride, int dil, int dgroup,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -299,3 +299,62 @@ def bbox_overlaps(boxes, query):
     ov = np.empty((boxes.shape[0], query.shape[0]), np.float32)
     cdll().orc_bbox_overlaps(pb, boxes.shape[0], pq, query.shape[0], ov.ctypes)
     return ov
+
+
+# ------------------------------------------------------------------------------------------------
+# DeformableConvolution v1 (parity unpinned: restated published algorithm, see deform_conv.c)
+# ------------------------------------------------------------------------------------------------
+def _out_hw(H, W, kh, kw, pad, stride, dil):
+    return ((H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1,
+            (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1)
+
+
+def deform_im2col(x, offset, kernel=(3, 3), pad=1, stride=1, dil=1, dgroup=1):
+    """x (C,H,W), offset (dgroup*2*kh*kw,Ho,Wo) -> col (C*kh*kw, Ho*Wo)."""
+    x, px = _f(x)
+    offset, po = _f(offset)
+    C, H, W = x.shape
+    kh, kw = kernel
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    col = np.empty((C * kh * kw, Ho * Wo), np.float32)
+    cdll().orc_deform_im2col(px, po, col.ctypes, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil,
+                             dgroup, Ho, Wo)
+    return col
+
+
+def deform_col2im(col, offset, x_shape, kernel=(3, 3), pad=1, stride=1, dil=1, dgroup=1):
+    col, pc = _f(col)
+    offset, po = _f(offset)
+    C, H, W = x_shape
+    kh, kw = kernel
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    dx = np.zeros((C, H, W), np.float32)
+    cdll().orc_deform_col2im(pc, po, dx.ctypes, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil,
+                             dgroup, Ho, Wo)
+    return dx
+
+
+def deform_col2im_coord(col, x, offset, kernel=(3, 3), pad=1, stride=1, dil=1, dgroup=1):
+    col, pc = _f(col)
+    x, px = _f(x)
+    offset, po = _f(offset)
+    C, H, W = x.shape
+    kh, kw = kernel
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    doff = np.zeros_like(offset)
+    cdll().orc_deform_col2im_coord(pc, px, po, doff.ctypes, C, H, W, kh, kw, pad, pad, stride,
+                                   stride, dil, dil, dgroup, Ho, Wo)
+    return doff
+
+
+def deform_conv_fwd(x, offset, weight, pad=1, stride=1, dil=1, dgroup=1):
+    """x (N,C,H,W), offset (N,dgroup*2*kh*kw,Ho,Wo), weight (F,C,kh,kw) -> y (N,F,Ho,Wo)."""
+    x, px = _f(x)
+    offset, po = _f(offset)
+    weight, pw = _f(weight)
+    N, C, H, W = x.shape
+    F, _, kh, kw = weight.shape
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    y = np.empty((N, F, Ho, Wo), np.float32)
+    cdll().orc_deform_conv_fwd(px, po, pw, y.ctypes, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup)
+    return y

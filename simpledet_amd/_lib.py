@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsimpledet_ops_hip.so")
 
 _SCALARS = {
     "int": ctypes.c_int,
+    "long": ctypes.c_long,
     "float": ctypes.c_float,
     "double": ctypes.c_double,
     "size_t": ctypes.c_size_t,

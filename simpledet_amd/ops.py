@@ -360,3 +360,109 @@ def bbox_overlaps(boxes, query_boxes):
     ov = torch.empty((n, k), device=boxes.device, dtype=torch.float32)
     lib().call("sd_bbox_overlaps", _p(boxes), n, _p(query_boxes), k, _p(ov), _stream())
     return ov
+
+
+# --------------------------------------------------------------------------------------------------
+# DeformableConvolution v1 (mx.sym.contrib.DeformableConvolution, models/dcn/builder.py:14-17)
+# --------------------------------------------------------------------------------------------------
+def _dcn_out_hw(H, W, kh, kw, pad, stride, dil):
+    return ((H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1,
+            (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1)
+
+
+def deform_im2col(x, offset, kernel=(3, 3), pad=1, stride=1, dilate=1, num_deformable_group=1):
+    """deformable_im2col: x (N,C,H,W), offset (N,dg*2*kh*kw,Ho,Wo) -> col (N, C*kh*kw, Ho*Wo)."""
+    _chk(x, "x", ndim=4)
+    _chk(offset, "offset", ndim=4)
+    N, C, H, W = x.shape
+    kh, kw = kernel
+    Ho, Wo = _dcn_out_hw(H, W, kh, kw, pad, stride, dilate)
+    col = torch.empty((N, C * kh * kw, Ho * Wo), device=x.device, dtype=torch.float32)
+    lib().call("sd_deform_im2col", _p(x), _p(offset), _p(col), N, C, H, W, kh, kw, pad, pad, stride,
+               stride, dilate, dilate, int(num_deformable_group), _stream())
+    return col
+
+
+def deform_col2im(col, offset, x_shape, kernel=(3, 3), pad=1, stride=1, dilate=1,
+                  num_deformable_group=1):
+    _chk(col, "col", ndim=3)
+    _chk(offset, "offset", ndim=4)
+    N, C, H, W = [int(v) for v in x_shape]
+    kh, kw = kernel
+    dx = torch.empty((N, C, H, W), device=col.device, dtype=torch.float32)
+    lib().call("sd_deform_col2im", _p(col), _p(offset), _p(dx), REQ["write"], N, C, H, W, kh, kw, pad,
+               pad, stride, stride, dilate, dilate, int(num_deformable_group), _stream())
+    return dx
+
+
+def deform_col2im_coord(col, x, offset, kernel=(3, 3), pad=1, stride=1, dilate=1,
+                        num_deformable_group=1):
+    _chk(col, "col", ndim=3)
+    _chk(x, "x", ndim=4)
+    _chk(offset, "offset", ndim=4)
+    N, C, H, W = x.shape
+    kh, kw = kernel
+    doff = torch.empty_like(offset)
+    lib().call("sd_deform_col2im_coord", _p(col), _p(x), _p(offset), _p(doff), REQ["write"], N, C, H,
+               W, kh, kw, pad, pad, stride, stride, dilate, dilate, int(num_deformable_group),
+               _stream())
+    return doff
+
+
+def gemm_f32(a, b, trans_a=False, trans_b=False, out=None, accumulate=0):
+    """Batched fp32 MFMA GEMM: a (Bt,M,K) or its transpose, b (Bt,K,N) or its transpose."""
+    _chk(a, "a", ndim=3)
+    _chk(b, "b", ndim=3)
+    Bt = a.shape[0]
+    M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    K2, N = (b.shape[2], b.shape[1]) if trans_b else (b.shape[1], b.shape[2])
+    if K != K2 or b.shape[0] != Bt:
+        raise ValueError("GEMM shape mismatch")
+    if out is None:
+        out = torch.empty((Bt, M, N), device=a.device, dtype=torch.float32)
+    lib().call("sd_gemm_f32", int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[2],
+               a.shape[1] * a.shape[2], _p(b), b.shape[2], b.shape[1] * b.shape[2], _p(out), N,
+               M * N, Bt, int(accumulate), _stream())
+    return out
+
+
+def _dcn_ws(x, kh, kw, pad, stride, dilate):
+    N, C, H, W = x.shape
+    n = lib().cdll.sd_deform_conv_workspace_bytes(N, C, H, W, kh, kw, pad, stride, dilate)
+    return torch.empty(n, device=x.device, dtype=torch.uint8), n
+
+
+def deform_conv_forward(x, offset, weight, pad=1, stride=1, dilate=1, num_deformable_group=1):
+    """DeformableConvolution forward (num_group=1, no_bias): y (N,F,Ho,Wo)."""
+    _chk(x, "data", ndim=4)
+    _chk(offset, "offset", ndim=4)
+    _chk(weight, "weight", ndim=4)
+    N, C, H, W = x.shape
+    F, Cw, kh, kw = weight.shape
+    if Cw != C:
+        raise ValueError("weight channels %d != data channels %d (num_group must be 1)" % (Cw, C))
+    Ho, Wo = _dcn_out_hw(H, W, kh, kw, pad, stride, dilate)
+    if tuple(offset.shape) != (N, num_deformable_group * 2 * kh * kw, Ho, Wo):
+        raise ValueError("offset shape %s != %s" % (tuple(offset.shape),
+                                                     (N, num_deformable_group * 2 * kh * kw, Ho, Wo)))
+    y = torch.empty((N, F, Ho, Wo), device=x.device, dtype=torch.float32)
+    ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
+    lib().call("sd_deform_conv_fwd", _p(x), _p(offset), _p(weight), _p(y), N, C, H, W, F, kh, kw,
+               pad, stride, dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
+    return y
+
+
+def deform_conv_backward(out_grad, x, offset, weight, pad=1, stride=1, dilate=1,
+                         num_deformable_group=1, req=("write", "write", "write"), grads=None):
+    """-> (d_data, d_offset, d_weight)."""
+    _chk(out_grad, "out_grad", ndim=4)
+    N, C, H, W = x.shape
+    F, _, kh, kw = weight.shape
+    r = [REQ[v] if isinstance(v, str) else int(v) for v in req]
+    if grads is None:
+        grads = (torch.empty_like(x), torch.empty_like(offset), torch.empty_like(weight))
+    ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
+    lib().call("sd_deform_conv_bwd", _p(out_grad), _p(x), _p(offset), _p(weight), _p(grads[0]),
+               _p(grads[1]), _p(grads[2]), r[0], r[1], r[2], N, C, H, W, F, kh, kw, pad, stride,
+               dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
+    return grads

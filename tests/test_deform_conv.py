@@ -1,0 +1,176 @@
+"""DeformableConvolution v1: oracle self-consistency (CPU) and HIP parity (GPU).
+
+PARITY UNPINNED: the reference delegates this op to upstream MXNet 1.6.0, which is
+not vendored; the oracle restates the published algorithm.  The CPU tests therefore pin the oracle
+with properties that do not depend on the restatement: zero offsets == ordinary convolution,
+integer offsets == a shifted tap, col2im is the adjoint of im2col, the offset gradient matches
+finite differences.  Float bar: 1e-4 (north_star) -- the GEMM summation order differs.
+"""
+import numpy as np
+import pytest
+
+
+def _case(seed, N=2, C=8, H=9, W=11, F=6, k=3, pad=1, stride=1, dil=1, dg=4, off_scale=1.5):
+    rs = np.random.RandomState(seed)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    off = (rs.standard_normal((N, dg * 2 * k * k, Ho, Wo)) * off_scale).astype(np.float32)
+    w = (rs.standard_normal((F, C, k, k)) * 0.2).astype(np.float32)
+    return x, off, w, dict(pad=pad, stride=stride, dil=dil, dgroup=dg)
+
+
+def _conv_ref(x, w, pad, stride, dil):
+    N, C, H, W = x.shape
+    F, _, kh, kw = w.shape
+    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    xp = np.zeros((N, C, H + 2 * pad, W + 2 * pad), np.float64)
+    xp[:, :, pad:pad + H, pad:pad + W] = x
+    y = np.zeros((N, F, Ho, Wo), np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            patch = xp[:, :, i * dil:i * dil + stride * Ho:stride, j * dil:j * dil + stride * Wo:stride]
+            y += np.einsum("nchw,fc->nfhw", patch, w[:, :, i, j].astype(np.float64))
+    return y
+
+
+# ------------------------------------------------------------------------------------------ CPU --
+@pytest.mark.parametrize("cfg", [dict(), dict(stride=2), dict(pad=2, dil=2), dict(pad=0)])
+def test_oracle_zero_offset_is_ordinary_convolution(oracle, cfg):
+    x, off, w, kw = _case(0, off_scale=0.0, **cfg)
+    y = oracle.deform_conv_fwd(x, off, w, **kw)
+    np.testing.assert_allclose(y, _conv_ref(x, w, kw["pad"], kw["stride"], kw["dil"]), rtol=1e-4,
+                               atol=1e-4)
+
+
+def test_oracle_integer_offsets_shift_the_tap(oracle):
+    x, off, w, kw = _case(1, N=1, C=4, dg=1, off_scale=0.0)
+    off[:, 0::2] = 1.0   # every tap samples one row further down
+    off[:, 1::2] = -2.0  # and two columns to the left
+    col = oracle.deform_im2col(x[0], off[0], dgroup=1)
+    C, H, W = x[0].shape
+    want = np.zeros_like(col).reshape(C, 3, 3, H, W)
+    for i in range(3):
+        for j in range(3):
+            for h in range(H):
+                for w_ in range(W):
+                    hh, ww = h - 1 + i + 1, w_ - 1 + j - 2  # pad 1, offsets (+1, -2)
+                    if 0 <= hh < H and 0 <= ww < W:
+                        want[:, i, j, h, w_] = x[0][:, hh, ww]
+    np.testing.assert_array_equal(col, want.reshape(col.shape))
+
+
+def test_oracle_col2im_is_adjoint_of_im2col(oracle):
+    x, off, w, kw = _case(2, N=1)
+    rs = np.random.RandomState(3)
+    col = oracle.deform_im2col(x[0], off[0], dgroup=kw["dgroup"])
+    g = rs.standard_normal(col.shape).astype(np.float32)
+    dx = oracle.deform_col2im(g, off[0], x[0].shape, dgroup=kw["dgroup"])
+    # <im2col(x), g> == <x, col2im(g)>  (im2col is linear in x)
+    np.testing.assert_allclose((col.astype(np.float64) * g).sum(),
+                               (x[0].astype(np.float64) * dx).sum(), rtol=1e-4)
+
+
+def test_oracle_offset_gradient_matches_finite_differences(oracle):
+    x, off, w, kw = _case(4, N=1, C=4, H=7, W=8, dg=2)
+    rs = np.random.RandomState(5)
+    # keep sample points away from integer coordinates (the bilinear kinks)
+    frac = off - np.floor(off)
+    off = (np.floor(off) + np.clip(frac, 0.2, 0.8)).astype(np.float32)
+    col = oracle.deform_im2col(x[0], off[0], dgroup=2)
+    g = rs.standard_normal(col.shape).astype(np.float32)
+    doff = oracle.deform_col2im_coord(g, x[0], off[0], dgroup=2)
+    eps = 1e-2
+    for idx in [(0, 2, 3), (5, 0, 0), (17, 6, 7), (35, 3, 4), (20, 1, 6)]:
+        o1, o2 = off[0].copy(), off[0].copy()
+        o1[idx] += eps
+        o2[idx] -= eps
+        f1 = (oracle.deform_im2col(x[0], o1, dgroup=2).astype(np.float64) * g).sum()
+        f2 = (oracle.deform_im2col(x[0], o2, dgroup=2).astype(np.float64) * g).sum()
+        assert abs((f1 - f2) / (2 * eps) - doff[idx]) < 2e-2 * max(1.0, abs(doff[idx])), idx
+
+
+# ------------------------------------------------------------------------------------------ GPU --
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(), dict(stride=2), dict(pad=2, dil=2), dict(dg=1, C=6),
+                                 dict(H=25, W=42, C=16, F=20, off_scale=3.0)])
+def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
+    x, off, w, kw = _case(7, **cfg)
+    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
+    col = ops.deform_im2col(_t(x), _t(off), **a).cpu().numpy()
+    want = np.stack([oracle.deform_im2col(x[n], off[n], **{k: v for k, v in kw.items()})
+                     for n in range(x.shape[0])])
+    np.testing.assert_array_equal(col, want)  # same float ops in the same order: bit exact
+    g = np.random.RandomState(8).standard_normal(col.shape).astype(np.float32)
+    dx = ops.deform_col2im(_t(g), _t(off), x.shape, **a).cpu().numpy()
+    wdx = np.stack([oracle.deform_col2im(g[n], off[n], x[n].shape, **kw) for n in range(x.shape[0])])
+    np.testing.assert_allclose(dx, wdx, rtol=1e-4, atol=1e-4)
+    do = ops.deform_col2im_coord(_t(g), _t(x), _t(off), **a).cpu().numpy()
+    wdo = np.stack([oracle.deform_col2im_coord(g[n], x[n], off[n], **kw) for n in range(x.shape[0])])
+    np.testing.assert_allclose(do, wdo, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 128, 128, 16), (2, 256, 300, 72), (3, 70, 4200, 33),
+                                   (1, 1, 1, 1), (2, 129, 257, 17)])
+def test_mfma_gemm_all_layouts(ops, shape):
+    import torch
+    Bt, M, N, K = shape
+    rs = np.random.RandomState(0)
+    A = rs.standard_normal((Bt, M, K)).astype(np.float32)
+    B = rs.standard_normal((Bt, K, N)).astype(np.float32)
+    want = np.einsum("bmk,bkn->bmn", A.astype(np.float64), B.astype(np.float64))
+    tol = 1e-4 * np.sqrt(K) * 4
+    for ta in (False, True):
+        for tb in (False, True):
+            a = _t(A.transpose(0, 2, 1).copy() if ta else A)
+            b = _t(B.transpose(0, 2, 1).copy() if tb else B)
+            got = ops.gemm_f32(a, b, ta, tb).cpu().numpy()
+            assert np.abs(got - want).max() <= tol, (ta, tb, np.abs(got - want).max())
+    # accumulate modes
+    c0 = rs.standard_normal((Bt, M, N)).astype(np.float32)
+    got = ops.gemm_f32(_t(A), _t(B), out=_t(c0), accumulate=1).cpu().numpy()
+    assert np.abs(got - (want + c0)).max() <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(), dict(stride=2, H=14, W=15), dict(pad=2, dil=2),
+                                 dict(N=2, C=32, H=25, W=42, F=24, dg=4)])
+def test_deform_conv_forward_backward(ops, oracle, cfg):
+    x, off, w, kw = _case(11, **cfg)
+    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
+    y = ops.deform_conv_forward(_t(x), _t(off), _t(w), **a).cpu().numpy()
+    want = oracle.deform_conv_fwd(x, off, w, **kw)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(y - want).max() <= 1e-4 * scale
+    # backward vs oracle pieces: dcol = W^T dy ; dx = col2im(dcol) ; doff = col2im_coord(dcol) ;
+    # dW = sum_n dy_n col_n^T
+    rs = np.random.RandomState(12)
+    dy = rs.standard_normal(want.shape).astype(np.float32)
+    dx, doff, dw = [t.cpu().numpy() for t in
+                    ops.deform_conv_backward(_t(dy), _t(x), _t(off), _t(w), **a)]
+    N, F = dy.shape[:2]
+    K = w[0].size
+    wdx, wdo = np.zeros_like(x), np.zeros_like(off)
+    wdw = np.zeros((F, K), np.float64)
+    for n in range(N):
+        dcol = (w.reshape(F, K).T.astype(np.float64) @ dy[n].reshape(F, -1)).astype(np.float32)
+        wdx[n] = oracle.deform_col2im(dcol, off[n], x[n].shape, **kw)
+        wdo[n] = oracle.deform_col2im_coord(dcol, x[n], off[n], **kw)
+        wdw += dy[n].reshape(F, -1).astype(np.float64) @ oracle.deform_im2col(x[n], off[n], **kw).T
+    for got, wnt in ((dx, wdx), (doff, wdo), (dw.reshape(F, K), wdw)):
+        s = max(1.0, float(np.abs(wnt).max()))
+        assert np.abs(got - wnt).max() <= 2e-4 * s
+    # req = add accumulates, req = null leaves the buffer untouched
+    import torch
+    g0 = (torch.ones_like(_t(x)), torch.ones_like(_t(off)), torch.full_like(_t(w), 7.0))
+    ops.deform_conv_backward(_t(dy), _t(x), _t(off), _t(w), req=("add", "add", "null"), grads=g0, **a)
+    assert np.abs(g0[0].cpu().numpy() - (wdx + 1)).max() <= 2e-4 * max(1.0, np.abs(wdx).max())
+    assert np.abs(g0[1].cpu().numpy() - (wdo + 1)).max() <= 2e-4 * max(1.0, np.abs(wdo).max())
+    assert float((g0[2] - 7.0).abs().max()) == 0
