@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--tuning", action="append", default=[], help="key=value kernel knob (A/B)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also run the known-size HBM stream copies (measured peak + PMC calibration)")
+    ap.add_argument("--no-ops", action="store_true",
+                    help="skip the per-operator secondary measurements (bench_ops.py)")
     ap.add_argument("--extra", action="store_true", help="also time the un-fused 4-op graph path")
     return ap.parse_args()
 
@@ -253,6 +255,17 @@ def main():
         }
         # the GPU result of the last step must still match the oracle (cheap sanity, not timed)
         extra["matches_oracle"] = bool(np.array_equal(state["out"].cpu().numpy(), o[0]))
+
+    if world == 1 and not args.no_ops:
+        import bench_ops
+        del feats, d_feats, dy
+        torch.cuda.empty_cache()
+        extra["ops"] = bench_ops.run(args.seed, cpu=not args.no_cpu_baseline)
+        if cpu_baseline is not None and "cpu_ms" in extra["ops"]["nms"]:
+            # north_star: GPU vs CPU throughput of RoIAlign fwd+bwd + NMS on the same inputs
+            gpu_ms = ms_per_step + extra["ops"]["nms"]["ms"]
+            cpu_ms = cpu_baseline["ms_per_step"] + extra["ops"]["nms"]["cpu_ms"]
+            extra["roialign_plus_nms_speedup_vs_cpu"] = cpu_ms / gpu_ms
 
     line = {
         "metric": "images/sec at 800x1333 FPN 512-RoI RoIAlign fwd+bwd",

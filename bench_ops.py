@@ -1,0 +1,134 @@
+"""Secondary measurements printed inside bench.py's JSON line under "ops" (rank 0, N=1 only):
+every other row of the hot-path table at its baseline shape, each with its own
+bounding figure (8(d)): HBM GB/s for the streaming ops, problems/s + pair-IoU/s for the NMS family
+(on-chip / latency bound), TFLOP/s against the fp32 MFMA peak for the DCN GEMM, and the CPU oracle
+timed on the same inputs next to it.  Inputs are resident in HBM before each timed region; timing is
+HIP events on the launch stream (torch's current stream is the stream handed to the C ABI).
+"""
+import time
+
+import numpy as np
+
+PEAK_HBM_GBS = 8000.0
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def _time_gpu(fn, iters=20, warm=3):
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _time_cpu(fn, min_s=0.5, max_iter=20):
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_s or n >= max_iter:
+            return dt * 1e3 / n
+
+
+def run(seed=0, cpu=True):
+    import torch
+    from simpledet_amd import ops, synth
+    res = {}
+    orc = None
+    if cpu:
+        from oracle import pyoracle as orc
+
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    # ---- GenAnchor: P2..P6, A = 3 (pure write: 16 B per anchor) ----
+    shapes = list(synth.FPN_SHAPES) + [(13, 21)]
+    strides = [4, 8, 16, 32, 64]
+    ms = _time_gpu(lambda: [ops.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
+    nbytes = sum(16 * h * w * 3 for h, w in shapes)
+    res["gen_anchor"] = {"ms": ms, "bytes": nbytes, "GBs": nbytes / ms / 1e6, "launches": 5}
+    if orc:
+        res["gen_anchor"]["cpu_ms"] = _time_cpu(
+            lambda: [orc.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
+
+    # ---- ProposalTarget: B=2, 2000 proposals, 100 gt slots, 512 rois, 81 classes ----
+    rois, gt = synth.proposal_target_inputs(seed, 2, 2000, 100)
+    tr, tg = T(rois), T(gt)
+    state = ops.glibc_rand_state(1)
+    ms = _time_gpu(lambda: ops.proposal_target(tr, tg, 81, 2, 512, rng_state=state))
+    res["proposal_target"] = {"ms": ms, "images_per_s": 2 / ms * 1e3}
+    if orc:
+        p = orc.make_pt_param(81, 2, 512)
+        rng = orc.GlibcRand(1)
+        res["proposal_target"]["cpu_ms"] = _time_cpu(lambda: orc.proposal_target(rois, gt, p, rng=rng))
+
+    # ---- _contrib_NMS: B=2 x 2000 boxes, thr 0.7, post 1000 (train proposals) ----
+    dets = np.stack([synth.nms_dets(seed + i, 2000) for i in range(2)])
+    td = T(dets)
+    ms = _time_gpu(lambda: ops.nms(td, 2000, 1000, 0.7))
+    res["nms"] = {"ms": ms, "images_per_s": 2 / ms * 1e3, "pair_iou_per_s": 2 * 2000 * 1999 / 2 / ms * 1e3,
+                  "config": "B=2, N=2000, post 1000, thr 0.7"}
+    if orc:
+        res["nms"]["cpu_ms"] = _time_cpu(lambda: orc.nms(dets, 2000, 1000, 0.7))
+
+    # ---- batched soft-NMS: 16 images x 80 classes x 1000 boxes (BASELINE configs[2]) ----
+    P, n = 16 * 80, 1000
+    base = np.stack([synth.nms_dets(seed + 100 + i, n) for i in range(16)])
+    sd = np.repeat(base, 80, axis=0)
+    sd[:, :, 4] *= np.linspace(0.5, 1.0, P, dtype=np.float32)[:, None]  # distinct problems
+    tsd = T(sd)
+    ms = _time_gpu(lambda: ops.soft_nms_batched(tsd, None, 0.5, 0.5, 0.001, 1), iters=5, warm=1)
+    res["soft_nms"] = {"ms": ms, "problems": P, "boxes": n, "problems_per_s": P / ms * 1e3,
+                       "config": "1280 problems x 1000 boxes, linear, Nt 0.5, thr 0.001"}
+    if orc:
+        t = _time_cpu(lambda: orc.soft_nms(sd[0], 0.5, 0.5, 0.001, 1), min_s=0.3)
+        res["soft_nms"]["cpu_ms_per_problem"] = t
+        res["soft_nms"]["cpu_problems_per_s_1core"] = 1e3 / t
+
+    # ---- ROIPooling_v1: C4 map (2,1024,50,84), 1024 rois, 7x7 ----
+    rs = np.random.RandomState(seed)
+    data = torch.randn((2, 1024, 50, 84), device="cuda")
+    r = synth.random_rois(seed, 1, 1024)[0]
+    prois = T(np.concatenate([rs.randint(0, 2, (1024, 1)).astype(np.float32), r], 1))
+    o, idx = ops.roi_pool_v1_forward(data, prois, (7, 7), 1 / 16.0)
+    dy = torch.randn_like(o)
+    dx = torch.empty_like(data)
+    ms_f = _time_gpu(lambda: ops.roi_pool_v1_forward(data, prois, (7, 7), 1 / 16.0))
+    ms_b = _time_gpu(lambda: ops.roi_pool_v1_backward(dy, prois, idx, data.shape, 1 / 16.0, d_data=dx))
+    alg = 4 * data.numel() + 20 * 1024 + 2 * 4 * o.numel()
+    res["roi_pool_v1"] = {"fwd_ms": ms_f, "bwd_ms": ms_b, "algorithmic_bytes": alg,
+                          "fwd_GBs": alg / ms_f / 1e6, "fwd_frac": alg / ms_f / 1e6 / PEAK_HBM_GBS}
+    del data, o, idx, dy, dx
+
+    # ---- DeformableConvolution: x (16,256,50,84), 3x3, dg 4, F 256 ----
+    N, C, H, W, F = 16, 256, 50, 84, 256
+    x = torch.randn((N, C, H, W), device="cuda")
+    off = torch.randn((N, 72, H, W), device="cuda") * 2
+    wt = torch.randn((F, C, 3, 3), device="cuda") * 0.05
+    ms_i = _time_gpu(lambda: ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
+    ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=5, warm=1)
+    y = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)
+    dyc = torch.randn_like(y)
+    grads = (torch.empty_like(x), torch.empty_like(off), torch.empty_like(wt))
+    ms_b = _time_gpu(lambda: ops.deform_conv_backward(dyc, x, off, wt, 1, 1, 1, 4, grads=grads),
+                     iters=3, warm=1)
+    P_ = H * W
+    im2col_bytes = N * (4 * (C + 72) * P_ + 4 * 9 * C * P_)
+    flops = 2.0 * N * F * 9 * C * P_
+    gemm_ms = max(ms_f - ms_i, 1e-6)
+    res["deform_conv"] = {
+        "im2col_ms": ms_i, "im2col_GBs": im2col_bytes / ms_i / 1e6,
+        "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
+        "fwd_ms": ms_f, "bwd_ms": ms_b, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
+        "gemm_frac_of_f32_mfma_peak": flops / gemm_ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
+        "config": "x (16,256,50,84), 3x3 pad 1, 4 deformable groups, 256 filters, fp32"}
+    return res

@@ -49,6 +49,11 @@ int sd_abi_version(void);
 int sd_set_tuning(const char* key, int value);
 int sd_get_tuning(const char* key, int* value);
 
+/* Block the calling host thread until `stream` has drained.  Only the MXNet CustomOp adapter
+ * uses it (a CustomOp's outputs must be complete when forward()/backward() returns); the compute
+ * entry points never synchronise. */
+int sd_stream_synchronize(void* stream);
+
 /* HBM streaming copy (measurement aid, no reference counterpart): dst[i] = src[i] with
  * width_bytes (4, 8 or 16) per lane.  bench.py uses it to report the achievable HBM rate next to
  * the 8 TB/s spec peak and to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count */

@@ -84,6 +84,11 @@ extern "C" int sd_hbm_stream_copy(const void* src, void* dst, size_t bytes, int 
   return SD_OK;
 }
 
+extern "C" int sd_stream_synchronize(void* stream) {
+  SD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return SD_OK;
+}
+
 extern "C" const char* sd_last_error(void) { return sd::err_buf(); }
 extern "C" int sd_abi_version(void) { return 1; }
 

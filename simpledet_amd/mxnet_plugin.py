@@ -1,0 +1,579 @@
+"""MXNet CustomOp adapter: the reference's operator names on top of the HIP C ABI.
+
+The reference (tusen-ai/simpledet) reaches its detection ops by NAME from the symbol graph
+(`mx.sym.contrib.ROIAlign_v2`, `mx.sym.ROIPooling_v1`, `mx.sym.ProposalTarget`,
+`mx.sym.contrib.GenAnchor`, `mx.sym.contrib.NMS`, `mx.sym.contrib.DeformableConvolution`, and the
+Python CustomOp `assign_layer_fpn`).  Its only run-time extension hook is `mx.operator.CustomOp`
+(canonical example operator_py/bbox_target.py:96-219), so this module
+
+  1. registers one CustomOp per operator under the name  sd_<reference op name>, with the
+     reference's argument names, output names, NUMBER OF VISIBLE OUTPUTS and parameter names
+     (roi_align_v2.cc:170-186, roi_pooling_v1-inl.h:144-237, proposal_target-inl.h:283-330,
+     generate_anchor-inl.h:70-118, nms-inl.h:124-160), and
+  2. `install()` aliases the reference names to `mx.sym.Custom(op_type=...)` so symbol/builder.py,
+     models/ and config/ run unchanged.
+
+`import mxnet` happens inside `register()`: importing this module never needs MXNet (it is absent
+in the build container; tests drive the adapter through a tiny stub of the mx.operator interface).
+
+Data path: NDArray -> raw device pointer through MXNet's C API (MXNDArrayGetData) -> C ABI on the
+NULL stream -> sd_stream_synchronize before forward()/backward() return, because MXNet treats a
+CustomOp's outputs as written when the callback returns (threading).
+"""
+import ctypes
+from ast import literal_eval
+
+from ._lib import lib
+
+REQ = {"null": 0, "write": 1, "inplace": 2, "add": 3}
+_PREFIX = "sd_"
+_state = {"mx": None, "registered": False, "rng": {}}
+
+
+# ------------------------------------------------------------------------------------ helpers ----
+def _ptr(nd):
+    """Raw device pointer of an mx.nd.NDArray (MXNDArrayGetData), or of any object that exposes
+    `data_ptr()` (the test stub wraps torch tensors)."""
+    if nd is None:
+        return None
+    if hasattr(nd, "data_ptr"):
+        return ctypes.c_void_p(nd.data_ptr())
+    mx = _state["mx"]
+    p = ctypes.c_void_p()
+    rc = mx.base._LIB.MXNDArrayGetData(nd.handle, ctypes.byref(p))
+    if rc != 0:
+        raise RuntimeError("MXNDArrayGetData failed")
+    return p
+
+
+def _wait(*arrs):
+    for a in arrs:
+        if a is not None and hasattr(a, "wait_to_read"):
+            a.wait_to_read()
+
+
+def _req(r):
+    return REQ[r] if isinstance(r, str) else int(r)
+
+
+def _sync():
+    lib().call("sd_stream_synchronize", None)
+
+
+def _tuple(v, n=None, typ=float):
+    t = literal_eval(v) if isinstance(v, str) else v
+    if not isinstance(t, (tuple, list)):
+        t = (t,) * (n or 1)
+    return tuple(typ(x) for x in t)
+
+
+def _bool(v):
+    if isinstance(v, str):
+        return v.strip().lower() in ("1", "true", "yes")
+    return bool(v)
+
+
+def _iarr(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _darr(vals):
+    return (ctypes.c_double * len(vals))(*[float(v) for v in vals])
+
+
+def _scratch(like, nbytes):
+    """Device scratch owned by MXNet (an NDArray on the same context)."""
+    mx = _state["mx"]
+    return mx.nd.empty(((int(nbytes) + 3) // 4,), ctx=like.context, dtype="float32")
+
+
+def _require_write(req, names):
+    for r, n in zip(req, names):
+        if _req(r) not in (REQ["write"], REQ["null"]):
+            raise RuntimeError("%s requires kWriteTo (got req=%s)" % (n, r))
+
+
+# ---------------------------------------------------------------------------------- operators ----
+def _build_ops(mx):
+    CustomOp, CustomOpProp = mx.operator.CustomOp, mx.operator.CustomOpProp
+    ops = {}
+
+    # ---- _contrib_ROIAlign_v2: 2 inputs, 3 outputs (1 visible) ----
+    class ROIAlignV2(CustomOp):
+        def __init__(self, pooled_size, spatial_scale):
+            super().__init__()
+            self.ph, self.pw = pooled_size
+            self.scale = spatial_scale
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            data, rois = in_data
+            _wait(data, rois)
+            B, C, H, W = data.shape
+            R = rois.shape[1]
+            lib().call("sd_roi_align_v2_fwd", _ptr(data), _ptr(rois), _ptr(out_data[0]),
+                       _ptr(out_data[1]), _ptr(out_data[2]), B, C, H, W, R, self.ph, self.pw,
+                       float(self.scale), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            data, rois = in_data
+            _wait(out_grad[0], rois, out_data[1], out_data[2])
+            B, C, H, W = data.shape
+            R = rois.shape[1]
+            lib().call("sd_roi_align_v2_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                       _ptr(out_data[2]), _ptr(in_grad[0]), _ptr(in_grad[1]), _req(req[0]),
+                       _req(req[1]), B, C, H, W, R, self.ph, self.pw, float(self.scale), None)
+            _sync()
+
+    class ROIAlignV2Prop(CustomOpProp):
+        def __init__(self, pooled_size, spatial_scale):
+            super().__init__(need_top_grad=True)
+            self.pooled_size = _tuple(pooled_size, 2, int)
+            self.spatial_scale = float(spatial_scale)
+            if self.pooled_size[0] <= 0 or self.pooled_size[1] <= 0:
+                raise ValueError("ROIAlignParam: pooled_size must be nonzero")
+            if not 0.0 <= self.spatial_scale <= 1.0:
+                raise ValueError("spatial_scale must be in [0, 1]")
+
+        def list_arguments(self):
+            return ["data", "rois"]
+
+        def list_outputs(self):
+            return ["output", "maxidx_x", "maxidx_y"]
+
+        num_visible_outputs = 1
+
+        def infer_shape(self, in_shape):
+            d, b = in_shape
+            if len(d) != 4:
+                raise ValueError("data should be a 4D tensor")
+            if len(b) != 3 or b[2] != 4:
+                raise ValueError("bbox should be a 3D tensor of shape [batch, rois, 4]")
+            o = (b[0], b[1], d[1], self.pooled_size[0], self.pooled_size[1])
+            return [d, b], [o, o, o]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return ROIAlignV2(self.pooled_size, self.spatial_scale)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            # ROIAlignGrad_v2 (roi_align_v2-inl.h:206-218): dY, rois, maxidx_x, maxidx_y
+            return [out_grad[0], in_data[1], out_data[1], out_data[2]]
+
+    ops["_contrib_ROIAlign_v2"] = (ROIAlignV2Prop, ("contrib", "ROIAlign_v2"))
+
+    # ---- ROIPooling_v1: 2 inputs, 2 outputs (1 visible) ----
+    class ROIPoolingV1(CustomOp):
+        def __init__(self, pooled_size, spatial_scale):
+            super().__init__()
+            self.ph, self.pw = pooled_size
+            self.scale = spatial_scale
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            data, rois = in_data
+            _wait(data, rois)
+            B, C, H, W = data.shape
+            lib().call("sd_roi_pool_v1_fwd", _ptr(data), _ptr(rois), _ptr(out_data[0]),
+                       _ptr(out_data[1]), B, C, H, W, rois.shape[0], self.ph, self.pw,
+                       float(self.scale), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            data, rois = in_data
+            _wait(out_grad[0], rois, out_data[1])
+            B, C, H, W = data.shape
+            lib().call("sd_roi_pool_v1_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                       _ptr(in_grad[0]), _ptr(in_grad[1]), _req(req[0]), _req(req[1]), B, C, H, W,
+                       rois.shape[0], self.ph, self.pw, float(self.scale), None)
+            _sync()
+
+    class ROIPoolingV1Prop(CustomOpProp):
+        def __init__(self, pooled_size, spatial_scale):
+            super().__init__(need_top_grad=True)
+            self.pooled_size = _tuple(pooled_size, 2, int)
+            self.spatial_scale = float(spatial_scale)
+
+        def list_arguments(self):
+            return ["data", "rois"]
+
+        def list_outputs(self):
+            return ["output", "maxidx"]
+
+        num_visible_outputs = 1
+
+        def infer_shape(self, in_shape):
+            d, b = in_shape
+            if len(d) != 4:
+                raise ValueError("data should be a 4D tensor")
+            if len(b) != 2 or b[1] != 5:
+                raise ValueError("bbox should be a 2D tensor of shape [batch, 5]")
+            o = (b[0], d[1], self.pooled_size[0], self.pooled_size[1])
+            return [d, b], [o, o]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return ROIPoolingV1(self.pooled_size, self.spatial_scale)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return [out_grad[0], in_data[1], out_data[1]]
+
+    ops["ROIPooling_v1"] = (ROIPoolingV1Prop, (None, "ROIPooling_v1"))
+
+    # ---- ProposalTarget: 2 inputs, 5 outputs (4 visible unless output_iou) ----
+    class ProposalTarget(CustomOp):
+        def __init__(self, p):
+            super().__init__()
+            self.p = p
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            from .ops import ProposalTargetParam
+            _require_write(req[:4], ["roi_output", "label", "bbox_target", "bbox_weight"])
+            rois, gt = in_data
+            _wait(rois, gt)
+            p = self.p
+            B = p["batch_images"]
+            N = int(_numel(rois.shape) // (B * 4))
+            M = int(_numel(gt.shape) // (B * 5))
+            cp = ProposalTargetParam()
+            cp.num_classes, cp.batch_images, cp.image_rois = p["num_classes"], B, p["image_rois"]
+            cp.fg_fraction, cp.fg_thresh = p["fg_fraction"], p["fg_thresh"]
+            cp.bg_thresh_hi, cp.bg_thresh_lo = p["bg_thresh_hi"], p["bg_thresh_lo"]
+            cp.proposal_without_gt, cp.class_agnostic = int(p["proposal_without_gt"]), int(p["class_agnostic"])
+            for i in range(4):
+                cp.bbox_mean[i], cp.bbox_std[i], cp.bbox_weight[i] = (p["bbox_mean"][i], p["bbox_std"][i],
+                                                                       p["bbox_weight"][i])
+            key = str(rois.context)
+            if key not in _state["rng"]:
+                # libc's global rand() state of a process that never called srand (seed 1): one
+                # stream per device, shared by every ProposalTarget node like the libc global is
+                host = (ctypes.c_int32 * 33)()
+                lib().call("sd_glibc_srand_host", ctypes.c_uint32(1), host)
+                _state["rng"][key] = _state["mx"].nd.array(list(host), ctx=rois.context, dtype="int32")
+            rng = _state["rng"][key]
+            wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
+            ws = _scratch(rois, wsb)
+            lib().call("sd_proposal_target", _ptr(rois), _ptr(gt), N, M, ctypes.byref(cp), _ptr(rng),
+                       _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
+                       _ptr(out_data[4]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            # proposal_target-inl.h:272-276: both input gradients are zero
+            self.assign(in_grad[0], req[0], 0)
+            self.assign(in_grad[1], req[1], 0)
+
+    def _numel(shape):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        return n
+
+    class ProposalTargetProp(CustomOpProp):
+        def __init__(self, num_classes, batch_images, image_rois, fg_thresh, bg_thresh_hi,
+                     bg_thresh_lo, fg_fraction="0.25", proposal_without_gt="False",
+                     class_agnostic="False", output_iou="False", bbox_mean="(0,0,0,0)",
+                     bbox_std="(0.1,0.1,0.2,0.2)", bbox_weight="(1,1,1,1)"):
+            super().__init__(need_top_grad=False)
+            self.p = dict(num_classes=int(num_classes), batch_images=int(batch_images),
+                          image_rois=int(image_rois), fg_thresh=float(fg_thresh),
+                          bg_thresh_hi=float(bg_thresh_hi), bg_thresh_lo=float(bg_thresh_lo),
+                          fg_fraction=float(fg_fraction),
+                          proposal_without_gt=_bool(proposal_without_gt),
+                          class_agnostic=_bool(class_agnostic), output_iou=_bool(output_iou),
+                          bbox_mean=_tuple(bbox_mean, 4), bbox_std=_tuple(bbox_std, 4),
+                          bbox_weight=_tuple(bbox_weight, 4))
+            self.num_visible_outputs = 5 if self.p["output_iou"] else 4
+
+        def list_arguments(self):
+            return ["rois", "gt_boxes"]
+
+        def list_outputs(self):
+            return ["roi_output", "label", "bbox_target", "bbox_weight", "match_gt_iou"]
+
+        def infer_shape(self, in_shape):
+            p = self.p
+            B, S, K = p["batch_images"], p["image_rois"], p["num_classes"]
+            return in_shape, [(B, S, 4), (B, S), (B, S, K * 4), (B, S, K * 4), (B, S)]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return ProposalTarget(self.p)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return []
+
+    ops["ProposalTarget"] = (ProposalTargetProp, (None, "ProposalTarget"))
+
+    # ---- _contrib_GenAnchor: 1 input (shape only), 1 output ----
+    class GenAnchor(CustomOp):
+        def __init__(self, scales, ratios, stride):
+            super().__init__()
+            self.scales, self.ratios, self.stride = scales, ratios, stride
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            _require_write(req[:1], ["output"])
+            H, W = in_data[0].shape[2], in_data[0].shape[3]
+            lib().call("sd_gen_anchor", _ptr(out_data[0]), H, W, self.stride, _darr(self.scales),
+                       len(self.scales), _darr(self.ratios), len(self.ratios), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            self.assign(in_grad[0], req[0], 0)
+
+    class GenAnchorProp(CustomOpProp):
+        def __init__(self, scales="(4,8,16,32)", ratios="(0.5,1,2)", feature_stride="16"):
+            super().__init__(need_top_grad=False)
+            self.scales, self.ratios = _tuple(scales), _tuple(ratios)
+            self.stride = int(feature_stride)
+
+        def list_arguments(self):
+            return ["cls_prob"]
+
+        def list_outputs(self):
+            return ["output"]
+
+        def infer_shape(self, in_shape):
+            d = in_shape[0]
+            if len(d) != 4:
+                raise ValueError("cls_prob should be a 4D tensor")
+            A = len(self.scales) * len(self.ratios)
+            return in_shape, [(d[2] * d[3] * A, 4)]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return GenAnchor(self.scales, self.ratios, self.stride)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return []
+
+    ops["_contrib_GenAnchor"] = (GenAnchorProp, ("contrib", "GenAnchor"))
+
+    # ---- _contrib_NMS: 1 input, 2 outputs (score visible only with output_score) ----
+    class NMS(CustomOp):
+        def __init__(self, pre, post, thr, already_sorted):
+            super().__init__()
+            self.pre, self.post, self.thr, self.sorted = pre, post, thr, already_sorted
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            rois = in_data[0]
+            _wait(rois)
+            B, N, _ = rois.shape
+            wsb = lib().cdll.sd_nms_workspace_bytes(B, N, self.pre)
+            ws = _scratch(rois, wsb)
+            lib().call("sd_nms", _ptr(rois), B, N, self.pre, self.post, float(self.thr), 0,
+                       int(self.sorted), _ptr(out_data[0]), _ptr(out_data[1]), None, _ptr(ws),
+                       ctypes.c_size_t(wsb), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            self.assign(in_grad[0], req[0], 0)  # nms.cu:379-381
+
+    class NMSProp(CustomOpProp):
+        def __init__(self, rpn_pre_nms_top_n="6000", rpn_post_nms_top_n="300", threshold="0.7",
+                     output_score="False", already_sorted="False", workspace="256"):
+            super().__init__(need_top_grad=False)
+            self.pre, self.post = int(rpn_pre_nms_top_n), int(rpn_post_nms_top_n)
+            self.thr = float(threshold)
+            self.sorted = _bool(already_sorted)
+            self.num_visible_outputs = 2 if _bool(output_score) else 1
+
+        def list_arguments(self):
+            return ["rois"]
+
+        def list_outputs(self):
+            return ["output", "score"]
+
+        def infer_shape(self, in_shape):
+            d = in_shape[0]
+            if len(d) != 3 or d[2] != 5:
+                raise ValueError("Input:[bbox] must be (batch, rois, 5)")
+            pre = self.pre if self.pre > 0 else d[1]
+            if self.post > min(pre, d[1]):
+                # the reference writes image i at offset i*4*min(post, pre) into a (B, post, 4)
+                # buffer (nms.cu:277,352-354): only post <= pre is a consistent layout
+                raise ValueError("rpn_post_nms_top_n must not exceed the boxes that enter NMS")
+            return in_shape, [(d[0], self.post, 4), (d[0], self.post, 1)]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return NMS(self.pre, self.post, self.thr, self.sorted)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return []
+
+    ops["_contrib_NMS"] = (NMSProp, ("contrib", "NMS"))
+
+    # ---- assign_layer_fpn (models/FPN/assign_layer_fpn.py): 1 input, len(rcnn_stride) outputs ----
+    class AssignLayerFPN(CustomOp):
+        def __init__(self, strides, scale0, lvl0):
+            super().__init__()
+            self.strides, self.scale0, self.lvl0 = strides, scale0, lvl0
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            rois = in_data[0]
+            _wait(rois)
+            n = 1
+            for s in rois.shape[:-1]:
+                n *= int(s)
+            mx_ = _state["mx"]
+            per = mx_.nd.empty((len(self.strides),) + tuple(rois.shape), ctx=rois.context)
+            lib().call("sd_fpn_roi_assign", _ptr(rois), n, _iarr(self.strides), len(self.strides),
+                       float(self.scale0), float(self.lvl0), _ptr(per), None, None)
+            _sync()
+            for i in range(len(self.strides)):
+                self.assign(out_data[i], req[i], per[i])
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            self.assign(in_grad[0], req[0], 0)
+
+    class AssignLayerFPNProp(CustomOpProp):
+        def __init__(self, rcnn_stride, roi_canonical_scale, roi_canonical_level):
+            super().__init__(need_top_grad=False)
+            self.rcnn_stride = _tuple(rcnn_stride, typ=int)
+            self.roi_canonical_scale = int(roi_canonical_scale)
+            self.roi_canonical_level = int(roi_canonical_level)
+
+        def list_arguments(self):
+            return ["rois"]
+
+        def list_outputs(self):
+            return ["rois_s{}".format(s) for s in self.rcnn_stride]
+
+        def infer_shape(self, in_shape):
+            return [in_shape[0]], [in_shape[0]] * len(self.rcnn_stride)
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return AssignLayerFPN(self.rcnn_stride, self.roi_canonical_scale,
+                                  self.roi_canonical_level)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return []
+
+    ops["assign_layer_fpn"] = (AssignLayerFPNProp, None)
+
+    # ---- _contrib_DeformableConvolution: data, offset, weight -> output (no_bias, num_group 1) ----
+    class DeformConv(CustomOp):
+        def __init__(self, g):
+            super().__init__()
+            self.g = g
+
+        def _ws(self, x):
+            g = self.g
+            N, C, H, W = x.shape
+            n = lib().cdll.sd_deform_conv_workspace_bytes(N, C, H, W, g["kh"], g["kw"], g["pad"],
+                                                          g["stride"], g["dil"])
+            return _scratch(x, n), n
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            x, off, w = in_data
+            _wait(x, off, w)
+            g = self.g
+            N, C, H, W = x.shape
+            ws, n = self._ws(x)
+            lib().call("sd_deform_conv_fwd", _ptr(x), _ptr(off), _ptr(w), _ptr(out_data[0]), N, C, H,
+                       W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"],
+                       _ptr(ws), ctypes.c_size_t(n), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            x, off, w = in_data
+            _wait(out_grad[0], x, off, w)
+            g = self.g
+            N, C, H, W = x.shape
+            ws, n = self._ws(x)
+            lib().call("sd_deform_conv_bwd", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w),
+                       _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]), _req(req[0]),
+                       _req(req[1]), _req(req[2]), N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"],
+                       g["stride"], g["dil"], g["dg"], _ptr(ws), ctypes.c_size_t(n), None)
+            _sync()
+
+    class DeformConvProp(CustomOpProp):
+        def __init__(self, kernel, num_filter, stride="(1,1)", dilate="(1,1)", pad="(0,0)",
+                     num_group="1", num_deformable_group="1", no_bias="False", workspace="1024",
+                     layout="None"):
+            super().__init__(need_top_grad=True)
+            k, s, d, p = (_tuple(kernel, 2, int), _tuple(stride, 2, int), _tuple(dilate, 2, int),
+                          _tuple(pad, 2, int))
+            if int(num_group) != 1:
+                raise ValueError("DeformableConvolution: only num_group=1 (the reference's setting)")
+            if not _bool(no_bias):
+                raise ValueError("DeformableConvolution: only no_bias=True (models/dcn/builder.py:17)")
+            if s[0] != s[1] or d[0] != d[1] or p[0] != p[1]:
+                raise ValueError("DeformableConvolution: square stride/dilate/pad only")
+            self.g = dict(kh=k[0], kw=k[1], stride=s[0], dil=d[0], pad=p[0], F=int(num_filter),
+                          dg=int(num_deformable_group))
+
+        def list_arguments(self):
+            return ["data", "offset", "weight"]
+
+        def list_outputs(self):
+            return ["output"]
+
+        def infer_shape(self, in_shape):
+            g = self.g
+            d = in_shape[0]
+            if len(d) != 4:
+                raise ValueError("Input data should be 4D in batch-num_filter-y-x")
+            Ho = (d[2] + 2 * g["pad"] - (g["dil"] * (g["kh"] - 1) + 1)) // g["stride"] + 1
+            Wo = (d[3] + 2 * g["pad"] - (g["dil"] * (g["kw"] - 1) + 1)) // g["stride"] + 1
+            off = (d[0], g["dg"] * 2 * g["kh"] * g["kw"], Ho, Wo)
+            w = (g["F"], d[1], g["kh"], g["kw"])
+            return [d, off, w], [(d[0], g["F"], Ho, Wo)]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return DeformConv(self.g)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return [out_grad[0], in_data[0], in_data[1], in_data[2]]
+
+    ops["_contrib_DeformableConvolution"] = (DeformConvProp, ("contrib", "DeformableConvolution"))
+    return ops
+
+
+# ------------------------------------------------------------------------------- registration ----
+def register(mx=None):
+    """Register every CustomOp (op_type = 'sd_' + reference op name).  Returns {name: PropClass}."""
+    if mx is None:
+        import mxnet as mx  # noqa: F811  (lazy: MXNet is only needed here)
+    lib()  # fail loudly now if the HIP library is missing
+    _state["mx"] = mx
+    table = _build_ops(mx)
+    out = {}
+    for name, (prop, _) in table.items():
+        out[name] = mx.operator.register(_PREFIX + name)(prop)
+    _state["registered"] = True
+    _state["table"] = table
+    return out
+
+
+def install(mx=None):
+    """register() + alias the reference's symbol constructors to mx.sym.Custom, e.g.
+    mx.sym.contrib.ROIAlign_v2(data=d, rois=r, pooled_size=(7,7), spatial_scale=0.25) builds
+    mx.sym.Custom(d, r, op_type='sd__contrib_ROIAlign_v2', pooled_size='(7, 7)', ...) and returns
+    only the visible outputs, so symbol/builder.py and the config/ graphs stay unchanged."""
+    props = register(mx)
+    mx = _state["mx"]
+
+    def make(name, prop):
+        def ctor(*args, **kwargs):
+            name_kw = kwargs.pop("name", None)
+            params = {k: (v if isinstance(v, str) else repr(v)) for k, v in kwargs.items()
+                      if not _is_symbol(mx, v)}
+            inputs = {k: v for k, v in kwargs.items() if _is_symbol(mx, v)}
+            sym = mx.sym.Custom(*args, op_type=_PREFIX + name, name=name_kw, **inputs, **params)
+            p = prop(**params)
+            nvis = getattr(p, "num_visible_outputs", len(p.list_outputs()))
+            nout = len(p.list_outputs())
+            if nvis == nout:
+                return sym
+            return sym[0] if nvis == 1 else mx.sym.Group([sym[i] for i in range(nvis)])
+        ctor.__name__ = name
+        return ctor
+
+    for name, (prop, where) in _state["table"].items():
+        if where is None:
+            continue
+        ns, attr = where
+        target = getattr(mx.sym, ns) if ns else mx.sym
+        setattr(target, attr, make(name, props[name]))
+    return props
+
+
+def _is_symbol(mx, v):
+    sym_t = getattr(getattr(mx, "sym", None), "Symbol", None)
+    return sym_t is not None and isinstance(v, sym_t)

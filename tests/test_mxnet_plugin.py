@@ -1,0 +1,142 @@
+"""MXNet CustomOp adapter (simpledet_amd/mxnet_plugin.py) driven through a stub of mx.operator:
+CPU tests cover registration, the reference's argument/output names, visible-output counts,
+parameter parsing and shape inference; the GPU test runs forward/backward through the adapter and
+compares with the oracle."""
+import numpy as np
+import pytest
+
+from . import mx_stub
+
+
+@pytest.fixture()
+def plugin():
+    from simpledet_amd import mxnet_plugin
+    mx = mx_stub.make_stub()
+    props = mxnet_plugin.install(mx)
+    return mx, props, mxnet_plugin
+
+
+def test_registers_reference_operator_names(plugin):
+    mx, props, _ = plugin
+    assert set(props) == {"_contrib_ROIAlign_v2", "ROIPooling_v1", "ProposalTarget",
+                          "_contrib_GenAnchor", "_contrib_NMS", "assign_layer_fpn",
+                          "_contrib_DeformableConvolution"}
+    for name in props:
+        assert "sd_" + name in mx.registry
+    # aliases on the symbol namespaces the reference graph uses
+    for attr in ("ROIAlign_v2", "GenAnchor", "NMS", "DeformableConvolution"):
+        assert callable(getattr(mx.sym.contrib, attr))
+    assert callable(mx.sym.ROIPooling_v1) and callable(mx.sym.ProposalTarget)
+
+
+def test_roi_align_prop_matches_reference_registration(plugin):
+    _, props, _ = plugin
+    p = props["_contrib_ROIAlign_v2"](pooled_size="(7, 7)", spatial_scale="0.0625")
+    assert p.list_arguments() == ["data", "rois"]                     # roi_align_v2.cc:179-182
+    assert p.list_outputs() == ["output", "maxidx_x", "maxidx_y"]     # :183-186
+    assert p.num_visible_outputs == 1                                 # :175-178
+    ins, outs = p.infer_shape([(2, 256, 50, 84), (2, 512, 4)])
+    assert outs == [(2, 512, 256, 7, 7)] * 3                          # :195-208
+    with pytest.raises(ValueError, match="3D tensor"):
+        p.infer_shape([(2, 256, 50, 84), (1024, 5)])
+    with pytest.raises(ValueError, match="pooled_size"):
+        props["_contrib_ROIAlign_v2"](pooled_size="(0, 7)", spatial_scale="0.5")
+    deps = p.declare_backward_dependency(["dy"], ["data", "rois"], ["out", "mx", "my"])
+    assert deps == ["dy", "rois", "mx", "my"]                         # roi_align_v2-inl.h:206-218
+
+
+def test_proposal_target_prop(plugin):
+    _, props, _ = plugin
+    kw = dict(num_classes="81", batch_images="2", image_rois="512", fg_thresh="0.5",
+              bg_thresh_hi="0.5", bg_thresh_lo="0.0", fg_fraction="0.25",
+              bbox_std="(0.1, 0.1, 0.2, 0.2)")
+    p = props["ProposalTarget"](**kw)
+    assert p.list_arguments() == ["rois", "gt_boxes"]
+    assert p.list_outputs() == ["roi_output", "label", "bbox_target", "bbox_weight", "match_gt_iou"]
+    assert p.num_visible_outputs == 4                                 # proposal_target-inl.h:297-303
+    assert props["ProposalTarget"](output_iou="True", **kw).num_visible_outputs == 5
+    _, outs = p.infer_shape([(2, 2000, 4), (2, 100, 5)])
+    assert outs == [(2, 512, 4), (2, 512), (2, 512, 324), (2, 512, 324), (2, 512)]
+    assert p.declare_backward_dependency([], [], []) == []
+
+
+def test_other_props_shapes(plugin):
+    _, props, _ = plugin
+    p = props["ROIPooling_v1"](pooled_size="(7,7)", spatial_scale="0.0625")
+    assert p.infer_shape([(2, 1024, 50, 84), (300, 5)])[1] == [(300, 1024, 7, 7)] * 2
+    p = props["_contrib_GenAnchor"](scales="(8,)", ratios="(0.5, 1, 2)", feature_stride="4")
+    assert p.infer_shape([(2, 6, 200, 334)])[1] == [(200 * 334 * 3, 4)]
+    p = props["_contrib_NMS"](rpn_pre_nms_top_n="2000", rpn_post_nms_top_n="1000", threshold="0.7")
+    assert p.list_outputs() == ["output", "score"] and p.num_visible_outputs == 1
+    assert p.infer_shape([(2, 2000, 5)])[1] == [(2, 1000, 4), (2, 1000, 1)]
+    with pytest.raises(ValueError):
+        p.infer_shape([(2, 500, 5)])
+    p = props["assign_layer_fpn"](rcnn_stride="(4, 8, 16, 32)", roi_canonical_scale="224",
+                                  roi_canonical_level="4")
+    assert p.list_outputs() == ["rois_s4", "rois_s8", "rois_s16", "rois_s32"]
+    p = props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="256", pad="(1,1)",
+                                                num_deformable_group="4", no_bias="True")
+    ins, outs = p.infer_shape([(2, 256, 50, 84), None, None])
+    assert ins[1] == (2, 72, 50, 84) and ins[2] == (256, 256, 3, 3) and outs == [(2, 256, 50, 84)]
+    with pytest.raises(ValueError, match="no_bias"):
+        props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="8")
+
+
+def test_symbol_alias_builds_custom_node_with_visible_outputs(plugin):
+    mx, _, _ = plugin
+    d, r = mx.sym.Variable("data"), mx.sym.Variable("rois")
+    s = mx.sym.contrib.ROIAlign_v2(data=d, rois=r, pooled_size=(7, 7), spatial_scale=0.25,
+                                   name="roi_align")
+    assert s[0] == "out" and s[1].op_type == "sd__contrib_ROIAlign_v2" and s[2] == 0
+    assert s[1].params == {"pooled_size": "(7, 7)", "spatial_scale": "0.25"}
+
+
+@pytest.mark.gpu
+def test_adapter_forward_backward_on_gpu(plugin, oracle):
+    import torch
+    from simpledet_amd import synth
+    mx, props, _ = plugin
+    w = mx_stub.wrap
+    rs = np.random.RandomState(0)
+    data = rs.standard_normal((2, 8, 25, 42)).astype(np.float32)
+    rois = synth.random_rois(0, 2, 32)
+    prop = props["_contrib_ROIAlign_v2"](pooled_size="(7,7)", spatial_scale=str(1 / 32.0))
+    _, oshape = prop.infer_shape([data.shape, rois.shape])
+    op = prop.create_operator(None, None, None)
+    tin = [w(torch.from_numpy(data).cuda()), w(torch.from_numpy(rois).cuda())]
+    tout = [w(torch.empty(s, device="cuda")) for s in oshape]
+    op.forward(True, ["write"] * 3, tin, tout, [])
+    want = oracle.roi_align_v2_fwd(data, rois, (7, 7), 1 / 32.0)
+    for g, x in zip(tout, want):
+        np.testing.assert_array_equal(g.t.cpu().numpy(), x)
+    dy = rs.standard_normal(oshape[0]).astype(np.float32)
+    grads = [w(torch.empty(data.shape, device="cuda")), w(torch.ones(rois.shape, device="cuda"))]
+    op.backward(["write", "write"], [w(torch.from_numpy(dy).cuda())], tin, tout, grads, [])
+    wdx = oracle.roi_align_v2_bwd(dy, want[1], want[2], data.shape)
+    np.testing.assert_allclose(grads[0].t.cpu().numpy(), wdx, rtol=1e-4, atol=1e-4)
+    assert float(grads[1].t.abs().max()) == 0
+    # ProposalTarget through the adapter == oracle with the never-seeded libc stream
+    prois, gt = synth.proposal_target_inputs(3, 2, 600, 40)
+    pp = props["ProposalTarget"](num_classes="81", batch_images="2", image_rois="128",
+                                 fg_thresh="0.5", bg_thresh_hi="0.5", bg_thresh_lo="0.0")
+    op = pp.create_operator(None, None, None)
+    _, oshape = pp.infer_shape([prois.shape, gt.shape])
+    tout = [w(torch.empty(s, device="cuda")) for s in oshape]
+    op.forward(True, ["write"] * 5, [w(torch.from_numpy(prois).cuda()), w(torch.from_numpy(gt).cuda())],
+               tout, [])
+    want = oracle.proposal_target(prois, gt, oracle.make_pt_param(81, 2, 128), rng=oracle.GlibcRand(1))
+    np.testing.assert_array_equal(tout[0].t.cpu().numpy(), want[0])
+    np.testing.assert_array_equal(tout[1].t.cpu().numpy(), want[1])
+    # GenAnchor + NMS + assign through the adapter
+    ga = props["_contrib_GenAnchor"](scales="(8,)", ratios="(0.5,1,2)", feature_stride="16")
+    op = ga.create_operator(None, None, None)
+    o = [w(torch.empty((50 * 84 * 3, 4), device="cuda"))]
+    op.forward(False, ["write"], [w(torch.empty((1, 6, 50, 84), device="cuda"))], o, [])
+    np.testing.assert_array_equal(o[0].t.cpu().numpy(), oracle.gen_anchor(50, 84, 16, [8], [0.5, 1, 2]))
+    dets = np.stack([synth.nms_dets(1, 500), synth.nms_dets(2, 500)])
+    nm = props["_contrib_NMS"](rpn_pre_nms_top_n="500", rpn_post_nms_top_n="100", threshold="0.7")
+    op = nm.create_operator(None, None, None)
+    o = [w(torch.empty((2, 100, 4), device="cuda")), w(torch.empty((2, 100, 1), device="cuda"))]
+    op.forward(False, ["write"] * 2, [w(torch.from_numpy(dets).cuda())], o, [])
+    wn = oracle.nms(dets, 500, 100, 0.7)
+    np.testing.assert_array_equal(o[0].t.cpu().numpy(), wn[0])

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --calibrate $*"
+CMD="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ops --calibrate $*"
 # 1. kernel trace + stats (average duration per kernel)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
 # 2. PMC passes, one counter group per run (never combined with tracing)
