@@ -522,6 +522,74 @@ def _build_ops(mx):
             return [out_grad[0], in_data[0], in_data[1], in_data[2]]
 
     ops["_contrib_DeformableConvolution"] = (DeformConvProp, ("contrib", "DeformableConvolution"))
+
+    # ---- fpn_roi_align: the whole FPNRoiAlign.get_roi_feature subgraph (models/FPN/builder.py:
+    #      567-610: assign -> per level ROIAlign_v2 -> add_n) as ONE op: feats..., rois -> output ----
+    class FPNRoIAlign(CustomOp):
+        def __init__(self, strides, pooled, scale0, lvl0):
+            super().__init__()
+            self.strides, self.pooled, self.scale0, self.lvl0 = strides, pooled, scale0, lvl0
+
+        def _levels(self, feats):
+            ptrs = (ctypes.c_void_p * len(feats))(*[_ptr(f).value for f in feats])
+            return ptrs, _iarr([f.shape[2] for f in feats]), _iarr([f.shape[3] for f in feats])
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            feats, rois = in_data[:-1], in_data[-1]
+            _wait(*in_data)
+            B, C = feats[0].shape[:2]
+            ptrs, Hs, Ws = self._levels(feats)
+            lib().call("sd_fpn_roi_align_fwd", ptrs, Hs, Ws, _iarr(self.strides), len(feats),
+                       _ptr(rois), _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), B, C,
+                       rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
+                       float(self.lvl0), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            feats, rois = in_data[:-1], in_data[-1]
+            _wait(out_grad[0], rois, out_data[1], out_data[2])
+            rq = {_req(r) for r in req[:-1]}
+            if len(rq) != 1:
+                raise RuntimeError("fpn_roi_align: all feature gradients must share one req")
+            B, C = feats[0].shape[:2]
+            ptrs, Hs, Ws = self._levels(in_grad[:-1])
+            lib().call("sd_fpn_roi_align_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                       _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B,
+                       C, rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
+                       float(self.lvl0), None)
+            _sync()
+            self.assign(in_grad[-1], req[-1], 0)
+
+    class FPNRoIAlignProp(CustomOpProp):
+        def __init__(self, rcnn_stride, pooled_size="(7, 7)", roi_canonical_scale="224",
+                     roi_canonical_level="4"):
+            super().__init__(need_top_grad=True)
+            self.rcnn_stride = _tuple(rcnn_stride, typ=int)
+            self.pooled_size = _tuple(pooled_size, 2, int)
+            self.scale0, self.lvl0 = float(roi_canonical_scale), float(roi_canonical_level)
+
+        def list_arguments(self):
+            return ["data_s{}".format(s) for s in self.rcnn_stride] + ["rois"]
+
+        def list_outputs(self):
+            return ["output", "maxidx_x", "maxidx_y"]
+
+        num_visible_outputs = 1
+
+        def infer_shape(self, in_shape):
+            feats, b = in_shape[:-1], in_shape[-1]
+            if len(b) != 3 or b[2] != 4:
+                raise ValueError("bbox should be a 3D tensor of shape [batch, rois, 4]")
+            o = (b[0], b[1], feats[0][1], self.pooled_size[0], self.pooled_size[1])
+            return in_shape, [o, o, o]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return FPNRoIAlign(self.rcnn_stride, self.pooled_size, self.scale0, self.lvl0)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return [out_grad[0], in_data[-1], out_data[1], out_data[2]]
+
+    ops["fpn_roi_align"] = (FPNRoIAlignProp, None)
     return ops
 
 

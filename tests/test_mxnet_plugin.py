@@ -20,7 +20,7 @@ def test_registers_reference_operator_names(plugin):
     mx, props, _ = plugin
     assert set(props) == {"_contrib_ROIAlign_v2", "ROIPooling_v1", "ProposalTarget",
                           "_contrib_GenAnchor", "_contrib_NMS", "assign_layer_fpn",
-                          "_contrib_DeformableConvolution"}
+                          "_contrib_DeformableConvolution", "fpn_roi_align"}
     for name in props:
         assert "sd_" + name in mx.registry
     # aliases on the symbol namespaces the reference graph uses
@@ -80,6 +80,15 @@ def test_other_props_shapes(plugin):
     assert ins[1] == (2, 72, 50, 84) and ins[2] == (256, 256, 3, 3) and outs == [(2, 256, 50, 84)]
     with pytest.raises(ValueError, match="no_bias"):
         props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="8")
+
+
+def test_fused_fpn_roi_align_prop(plugin):
+    _, props, _ = plugin
+    p = props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)")
+    assert p.list_arguments() == ["data_s4", "data_s8", "data_s16", "data_s32", "rois"]
+    assert p.num_visible_outputs == 1
+    shapes = [(2, 256, 200, 334), (2, 256, 100, 167), (2, 256, 50, 84), (2, 256, 25, 42), (2, 512, 4)]
+    assert p.infer_shape(shapes)[1] == [(2, 512, 256, 7, 7)] * 3
 
 
 def test_symbol_alias_builds_custom_node_with_visible_outputs(plugin):
