@@ -92,7 +92,10 @@ int sd_fpn_roi_align_fwd(const float* const* feats_host, const int* Hs_host, con
                          const int* strides_host, int nlvl, const float* rois, float* out,
                          float* maxidx_x, float* maxidx_y, int B, int C, int R, int pooled_h,
                          int pooled_w, float roi_canonical_scale, float roi_canonical_level,
-                         void* stream);
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* optional DEVICE scratch for the forward (a locality order of the RoIs: level-major, so the
+ * small P4/P5 slices stay in an XCD's L2); with workspace == NULL the RoIs run in input order */
+size_t sd_fpn_roi_align_workspace_bytes(int B, int R);
 int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois, const float* maxidx_x,
                          const float* maxidx_y, float* const* d_feats_host, const int* Hs_host,
                          const int* Ws_host, const int* strides_host, int nlvl, int req_data, int B,

@@ -23,6 +23,7 @@
 #include "../../include/simpledet_ops.h"
 #include <float.h>
 #include <math.h>
+#include <type_traits>
 
 namespace sd {
 
@@ -108,6 +109,11 @@ __device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ p
   return o;
 }
 
+// 8-byte load of two adjacent floats that is only 4-byte aligned
+struct __attribute__((packed, aligned(4))) F2u {
+  float x, y;
+};
+
 struct FwdArgs {
   RoiLevels L;
   const float* rois;
@@ -116,7 +122,8 @@ struct FwdArgs {
   float* ay;
   int B, C, R, PH, PW;
   int nslice;  // channel slices per RoI (one workgroup each)
-  int ablate;  // profiling only: 1 stop after tables, 2 no tile loads, 4 no stores
+  const int* order;  // optional locality order of the RoIs (a permutation of [0, B*R)), or null
+  int ablate;  // profiling only: 1 stop after the tables
 };
 
 __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
@@ -161,12 +168,12 @@ __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
 template <int PH, int PW, int NROI>
 struct FwdSmem {
   static constexpr int NR = 4 * PH, NC = 4 * PW, PP = PH * PW, NWAVE = 8;
-  // Tile layout T[k][dh][l][p][q][dw] (tap of sample (k,l) of bin (p,q), corner (dh,dw)): for a
-  // fixed sample the 8-byte (dw=0,1) pairs of consecutive bins are contiguous, so the compute
-  // phase's ds_read_b64 is bank-conflict free; LS (stride of one [p][q][dw] block) is 16 mod 32
-  // banks so the fill's writes of one tile row do not collide between l=0 and l=1.
-  static constexpr int LS = ((2 * PP + 15) / 32) * 32 + 16, CH = 8 * LS;
-  float tile[NWAVE * CH];
+  // Tile layout T[2k+l][p*PW+q][dh][dw] (tap of sample (k,l) of bin (p,q), corner (dh,dw)): the
+  // four taps of one sample are one 16-byte slot and consecutive bins are consecutive slots, so
+  // the compute phase is one conflict-free ds_read_b128 per sample.
+  // PPP: bins padded so that the stride between the four sample planes is 16 banks (mod 32)
+  static constexpr int PPP = ((PP + 3) / 8) * 8 + 4, CH = 16 * PPP;
+  __attribute__((aligned(16))) float tile[NWAVE * CH];
   struct Roi {
     float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab  (kl = 2k+l); x = NaN: none
     float2 coord[4 * PP];   // [kl][bin]: (w, h) of the sample
@@ -177,6 +184,7 @@ struct FwdSmem {
     int hcnt[PH], wcnt[PW];  // -1: empty axis bin (end <= start); else sample-loop iterations
     int binflag[PP];         // 1: the bin pools something (reference !is_empty)
     int lvl;                 // assigned level, -1 none, -2 RoI index past the end
+    int n;                   // RoI index (through the locality order when one is given)
     int fb_row, fb_col;      // a sample loop ran 3 times -> exact per-element fallback
     int any_valid;
     float box[4];
@@ -221,17 +229,18 @@ __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, fl
   return cnt;
 }
 
-template <int PH, int PW, int NROI>
+template <int PH, int PW, int NROI, int D>
 __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
   using S = FwdSmem<PH, PW, NROI>;
-  constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, LS = S::LS, CH = S::CH, NWAVE = S::NWAVE;
+  constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, PPP = S::PPP, CH = S::CH, NWAVE = S::NWAVE;
   constexpr int THREADS = NWAVE * kWave;
   static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
   constexpr int NPAIR = NC / 2;                 // (left,right) column pairs per tile row
   constexpr int RPW = kWave / NPAIR >= 1 ? kWave / NPAIR : 1;  // tile rows per wave instruction
   static_assert(NPAIR <= kWave, "one tile row must fit a wave");
   constexpr int ACT = RPW * NPAIR;              // active lanes in the fill
-  constexpr int ITER = (NR + RPW - 1) / RPW;    // fill instructions (8-byte loads) per channel
+  static_assert(NR % RPW == 0, "whole fill instructions");
+  constexpr int ITER = NR / RPW;                // fill instructions (8-byte loads) per channel
   constexpr int CHUNK = ITER < 8 ? ITER : 8;    // loads kept in flight per lane
   constexpr int NCHUNK = (ITER + CHUNK - 1) / CHUNK;
   constexpr int NI = (PP + kWave - 1) / kWave;  // bins per lane
@@ -252,10 +261,11 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
 
   // ---- per-RoI sample tables: wave 2i rows, wave 2i+1 columns of RoI i ----
   if (wave < 2 * NROI) {
-    const int i = wave >> 1, n = grp * NROI + i;
+    const int i = wave >> 1, slot = grp * NROI + i;
     typename S::Roi& t = s.roi[i];
-    int lvl = -2, cnt = 0;
-    if (n < nroi_total) {
+    int lvl = -2, cnt = 0, n = 0;
+    if (slot < nroi_total) {
+      n = a.order ? a.order[slot] : slot;
       const float* r = a.rois + (long)n * 4;
       const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
       lvl = 0;
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     const int fb = __any(cnt >= 3);
     if (lane == 0) {
       if (wave & 1) t.fb_col = fb;
-      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; }
+      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; t.n = n; }
     }
   }
   __syncthreads();
@@ -310,23 +320,30 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
 
   // ===== from here on every wave runs on its own: no workgroup barrier =====
   float* tile = s.tile + wave * CH;
-  // fill: lane -> (row r0 of the RPW rows of this instruction, column pair jp).  A pair is the
+  // fill: lane -> (row r0 of the RPW rows of one fill instruction, column pair jp).  A pair is the
   // (left,right) taps of one column sample; they are adjacent pixels, so one 8-byte load fetches
   // both.  When they coincide (integer coordinate / clamped border) the load starts at
   // min(left, W-2) and the register is patched (dup = 1: both .x, dup = 2: both .y).
+  // Tile row rr = it*RPW + r0 = 4p + 2k + dh; LDS slot of (p,q,k,l,dh) is T[2k+l][p*PW+q][dh][dw]:
+  // the lane part and the `it` part of that address are separable, so after unrolling every
+  // ds_write is  lane_base + immediate.
+  static_assert(RPW == 4 || RPW == 2 || RPW == 1, "fill geometry");
   const bool fill_lane = lane < ACT;
   const int jp = lane % NPAIR, r0 = lane / NPAIR;
-  const int colpart = (jp & 1) * LS + 2 * (jp >> 1);
-  // LDS offset of tile row rr: T[k][dh][.][p][..] with rr = 4p + 2k + dh
-  auto rowpart = [&](int rr) {
-    return ((rr >> 1) & 1) * (4 * LS) + (rr & 1) * (2 * LS) + (rr >> 2) * (2 * PW);
+  const int fq = jp >> 1, fl = jp & 1;
+  const int lane_k = RPW == 4 ? (r0 >> 1) : 0, lane_dh = RPW == 1 ? 0 : (r0 & 1);
+  const int fill_base = ((2 * lane_k + fl) * PPP + fq) * 4 + lane_dh * 2;  // floats
+  auto it_part = [](int it) {  // floats; compile-time after unrolling
+    const int rr = it * RPW;   // r0 = 0 part
+    const int p = rr >> 2, k = (rr >> 1) & 1, dh = rr & 1;
+    return ((2 * k) * PPP + p * PW) * 4 + dh * 2;
   };
 
   // rare RoIs first (assigned to no level, or a 3-iteration sample loop), exact and simple
 #pragma unroll 1
   for (int i = 0; i < NROI; ++i) {
     const typename S::Roi& t = s.roi[i];
-    const int n = grp * NROI + i;
+    const int n = t.n;
     const int lvl = t.lvl;
     if (lvl == -2) break;
     const long obase = ((long)n * a.C + cbeg) * PP;
@@ -356,127 +373,161 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
 #pragma unroll 1
   for (int i = 0; i < NROI; ++i) {
     const typename S::Roi& t = s.roi[i];
-    const int n = grp * NROI + i;
-    const int lvl = t.lvl;
+    // wave-uniform values are forced into SGPRs so that every global access below is
+    // "SGPR base + 32-bit lane offset" (no 64-bit vector address arithmetic in the loop)
+    const int n = __builtin_amdgcn_readfirstlane(t.n);
+    const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
     if (lvl == -2) break;
-    if (lvl < 0 || t.fb_row || t.fb_col) continue;
+    if (lvl < 0 || __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col)) continue;
     const long obase = ((long)n * a.C + cbeg) * PP;
     const int W = a.L.W[lvl];
     const long plane = (long)a.L.H[lvl] * W;
     const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
-    const int any_valid = t.any_valid;
+    const long pstep = (long)NWAVE * plane * 4;  // bytes between this wave's channels
 
-    // per-lane constants of this RoI (kept in registers across channels)
-    int co = -1, dup = 0;
+    if (!__builtin_amdgcn_readfirstlane(t.any_valid)) {  // nothing to pool anywhere in the RoI
+      for (int c = wave; c < nch; c += NWAVE) {
+        const long ob = obase + (long)c * PP;
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+          const int bin = lane + b * kWave;
+          if (bin < PP) {
+            a.out[ob + bin] = 0.f;
+            a.ax[ob + bin] = -1.f;
+            a.ay[ob + bin] = -1.f;
+          }
+        }
+      }
+      continue;
+    }
+
+    // ---- per-lane constants of this RoI ----
+    int dup = 0;
+    unsigned colbyte = 0;
+    bool colok = false;
     if (fill_lane) {
       const int cl = t.coloff[2 * jp], cr = t.coloff[2 * jp + 1];
       if (cl >= 0) {
-        co = cl == cr ? (cl < W - 1 ? cl : W - 2) : cl;
+        const int co = cl == cr ? (cl < W - 1 ? cl : W - 2) : cl;
         dup = cl == cr ? (co == cl ? 1 : 2) : 0;
+        colbyte = (unsigned)co * 4u;
+        colok = true;
       }
     }
     const bool any_dup = __any(dup != 0);
-    // global offset of this lane's pair of fill instruction `it` within one channel plane; unused
+    // byte offset of this lane's pair of fill instruction `it` within one channel plane; unused
     // slots read elements 0,1 of the plane (always in bounds, never consumed)
-    auto calc_goff = [&](int it) {
-      const int rr = it * RPW + r0;
-      const int ro = (fill_lane && rr < NR) ? t.rowoff[rr] : -1;
-      return (ro >= 0 && co >= 0) ? ro + co : 0;
+    auto calc_voff = [&](int it) -> unsigned {
+      const int ro = fill_lane ? t.rowoff[it * RPW + r0] : -1;
+      return (ro >= 0 && colok) ? (unsigned)ro * 4u + colbyte : 0u;
     };
-    int goff[CACHE_GOFF ? ITER : 1];
+    unsigned voff[CACHE_GOFF ? ITER : 1];
     if (CACHE_GOFF) {
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) goff[it] = calc_goff(it);
+      for (int it = 0; it < ITER; ++it) voff[it] = calc_voff(it);
     }
-    int bflag[NI];
+    float init[NI], cx[NI][2], cy[NI][2];
     float4 wreg[REGW ? 4 : 1];
 #pragma unroll
     for (int b = 0; b < NI; ++b) {
       const int bin = lane + b * kWave;
-      bflag[b] = bin < PP ? t.binflag[bin] : 0;
+      const int bb = bin < PP ? bin : 0, p = bb / PW, q = bb % PW;
+      init[b] = t.binflag[bb] ? -FLT_MAX : 0.f;
+      cx[b][0] = t.wval[2 * q]; cx[b][1] = t.wval[2 * q + 1];
+      cy[b][0] = t.hval[2 * p]; cy[b][1] = t.hval[2 * p + 1];
     }
-    if (REGW && lane < PP) {
+    if (REGW) {
+      const int bb = lane < PP ? lane : 0;
 #pragma unroll
-      for (int kl = 0; kl < 4; ++kl) wreg[kl] = t.wts[kl * PP + lane];
+      for (int kl = 0; kl < 4; ++kl) wreg[kl] = t.wts[kl * PP + bb];
     }
 
-    float2 nxt[CHUNK];
-    auto issue = [&](const float* pl, int chunk) {
+    // D channels of this wave are in flight at once (the kernel is latency bound: a tile is
+    // ~3 KB of taps behind ~1 us of loaded latency, and the arithmetic per tile is ~40 VALU).
+    // Loads of a batch are issued back to back, tiles are then consumed in issue order.
+    float2 nxt[D][CHUNK];
+    auto issue = [&](const char* pl, int d, int chunk) {
 #pragma unroll
       for (int u = 0; u < CHUNK; ++u) {
         const int it = chunk * CHUNK + u;
         if (it < ITER) {
-          const int g = CACHE_GOFF ? goff[it] : calc_goff(it);
-          if (a.ablate & 2) nxt[u] = make_float2(0.f, 0.f);
-          else {  // two dword loads the compiler merges into one global_load_dwordx2
-            nxt[u].x = pl[g];
-            nxt[u].y = pl[g + 1];
-          }
+          const F2u v = *reinterpret_cast<const F2u*>(pl + (CACHE_GOFF ? voff[it] : calc_voff(it)));
+          nxt[d][u] = make_float2(v.x, v.y);
         }
       }
     };
-    auto commit = [&](int chunk) {
+    auto commit = [&](int d, int chunk, auto dup_tag) {
+      constexpr bool kDup = decltype(dup_tag)::value;
+      if (fill_lane) {
 #pragma unroll
-      for (int u = 0; u < CHUNK; ++u) {
-        const int it = chunk * CHUNK + u;
-        const int rr = it * RPW + r0;
-        if (it < ITER && fill_lane && rr < NR) {
-          float2 v = nxt[u];
-          if (any_dup) {
-            if (dup == 1) v.y = v.x;
-            if (dup == 2) v.x = v.y;
+        for (int u = 0; u < CHUNK; ++u) {
+          const int it = chunk * CHUNK + u;
+          if (it < ITER) {
+            float2 v = nxt[d][u];
+            if (kDup) {
+              if (dup == 1) v.y = v.x;
+              if (dup == 2) v.x = v.y;
+            }
+            *reinterpret_cast<float2*>(tile + fill_base + it_part(it)) = v;
           }
-          *reinterpret_cast<float2*>(tile + rowpart(rr) + colpart) = v;
         }
       }
     };
 
-    // wave w handles channels w, w+NWAVE, ... of the slice
-    int c = wave;
-    if (any_valid && c < nch) issue(base + (long)c * plane, 0);
-    for (; c < nch; c += NWAVE) {
-      const float* pl = base + (long)c * plane;
-      if (any_valid) {
-        commit(0);
+    // wave w handles channels w, w+NWAVE, ... of the slice.  The loop is instantiated twice so
+    // that the (rare) coincident-column patch costs nothing on the common path.
+    auto channel_loop = [&](auto dup_tag) {
+      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
+      float* po = a.out + obase + (long)wave * PP;
+      float* px = a.ax + obase + (long)wave * PP;
+      float* py = a.ay + obase + (long)wave * PP;
+      for (int c0 = wave; c0 < nch; c0 += D * NWAVE) {
 #pragma unroll
-        for (int ch = 1; ch < NCHUNK; ++ch) {
-          issue(pl, ch);
-          commit(ch);
-        }
-        if (c + NWAVE < nch) issue(pl + (long)NWAVE * plane, 0);  // next channel, in flight below
-      }
-      const long ob = obase + (long)c * PP;
+        for (int d = 0; d < D; ++d)
+          if (c0 + d * NWAVE < nch) issue(pl + d * pstep, d, 0);
 #pragma unroll
-      for (int b = 0; b < NI; ++b) {
-        const int bin = lane + b * kWave;
-        if (bin < PP) {
-          float maxval = bflag[b] ? -FLT_MAX : 0.f;
-          int best = -1;
-          if (any_valid) {
-            const float* t0 = tile + 2 * bin;
+        for (int d = 0; d < D; ++d) {
+          if (c0 + d * NWAVE < nch) {
+            commit(d, 0, dup_tag);
 #pragma unroll
-            for (int kl = 0; kl < 4; ++kl) {
-              const float4 w = REGW ? wreg[kl] : t.wts[kl * PP + bin];
-              if (w.x == w.x) {
-                const float* tp = t0 + (kl >> 1) * (4 * LS) + (kl & 1) * LS;
-                const float2 top = *reinterpret_cast<const float2*>(tp);
-                const float2 bot = *reinterpret_cast<const float2*>(tp + 2 * LS);
-                const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
-                if (value > maxval) { maxval = value; best = kl; }
+            for (int ch = 1; ch < NCHUNK; ++ch) {
+              issue(pl + d * pstep, d, ch);
+              commit(d, ch, dup_tag);
+            }
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+              const int bin = lane + b * kWave;
+              if (bin < PP) {
+                float maxval = init[b], bx = -1.f, by = -1.f;
+                const float4* tp = reinterpret_cast<const float4*>(tile) + bin;
+#pragma unroll
+                for (int kl = 0; kl < 4; ++kl) {
+                  // an absent sample has w.x = NaN: its value is NaN and never wins the comparison
+                  const float4 w = REGW ? wreg[kl] : t.wts[kl * PP + bin];
+                  const float4 v = tp[kl * PPP];  // (TL, TR, BL, BR)
+                  const float value = w.x * v.x + w.y * v.z + w.z * v.y + w.w * v.w;
+                  if (value > maxval) {
+                    maxval = value;
+                    bx = cx[b][kl & 1];
+                    by = cy[b][kl >> 1];
+                  }
+                }
+                if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+                po[bin + d * NWAVE * PP] = maxval;
+                px[bin + d * NWAVE * PP] = bx;
+                py[bin + d * NWAVE * PP] = by;
               }
             }
           }
-          float2 xy = make_float2(-1.f, -1.f);
-          if (best >= 0) xy = t.coord[best * PP + bin];
-          if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-          if (!(a.ablate & 4)) {
-            a.out[ob + bin] = maxval;
-            a.ax[ob + bin] = xy.x;
-            a.ay[ob + bin] = xy.y;
-          }
         }
+        pl += D * pstep;
+        po += D * NWAVE * PP;
+        px += D * NWAVE * PP;
+        py += D * NWAVE * PP;
       }
-    }
+    };
+    if (any_dup) channel_loop(std::true_type{});
+    else channel_loop(std::false_type{});
   }
 }
 
@@ -740,6 +791,277 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused backward: every level of the pyramid in ONE launch
+// ------------------------------------------------------------------------------------------------
+// Workgroup = (level, image, row band, channel).  The band of the gradient plane lives in LDS as
+// fp32 (<= ~36 KB, so four workgroups share a CU), the RoI bins that touch it are scattered into it
+// with an LDS compare-and-swap add, and the band is written to HBM exactly once with 16-B stores:
+// no zero-fill pass, no global atomics, no per-level launch boundary / tail.  Measured against the
+// other accumulators (tools/ab.sh): float CAS planes beat 64-bit fixed-point planes (half the LDS
+// bytes to zero and to convert, no max|dY| pre-pass) and ds_add_f32 (0.33 lane-ops/clk/CU).
+struct BwdFusedArgs {
+  RoiLevels L;
+  const float* dy;
+  const float* ax;
+  const float* ay;
+  const float* rois;
+  float* dx[SD_MAX_FPN_LEVELS];
+  int band_rows[SD_MAX_FPN_LEVELS], nbands[SD_MAX_FPN_LEVELS];
+  int block_end[SD_MAX_FPN_LEVELS];  // exclusive prefix of workgroups per level (in launch order)
+  int order[SD_MAX_FPN_LEVELS];      // launch order of the levels (largest first)
+  int nlaunch;
+  int B, C, R, PP;
+  int filter;  // 1: fused FPN (a RoI contributes to its assigned level only), 0: single level
+  int req;
+  int ablate;
+};
+
+template <int PP, int THREADS>
+__global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int U = 4;  // items per lane per trip: 3*U independent global loads in flight
+  const int tid = threadIdx.x;
+  // ---- block -> (level, image, band, channel) ----
+  int li = 0;
+  while (li + 1 < a.nlaunch && (int)blockIdx.x >= a.block_end[li]) ++li;
+  const int lvl = a.order[li];
+  const int b0 = (int)blockIdx.x - (li ? a.block_end[li - 1] : 0);
+  const int H = a.L.H[lvl], W = a.L.W[lvl];
+  const float scale = a.L.scale[lvl];
+  const int nbands = a.nbands[lvl];
+  int u, c;
+  if (a.C % kNumXCD == 0) {  // an XCD keeps a contiguous channel range: dY/argmax lines stay in one L2
+    const int xcd = b0 % kNumXCD, j = b0 / kNumXCD, per = a.C / kNumXCD;
+    c = xcd * per + (j % per);
+    u = j / per;
+  } else {
+    c = b0 % a.C;
+    u = b0 / a.C;
+  }
+  const int img = u / nbands, band = u % nbands;
+  const int row0 = band * a.band_rows[lvl];
+  const int row1 = iminr(row0 + a.band_rows[lvl], H);
+  const int band_elems = (row1 - row0) * W;
+  const int plane_pad = (band_elems + 3) & ~3;
+  float* plane = smem;
+  int* list = reinterpret_cast<int*>(smem + plane_pad);
+  int* nlist = list + a.R;
+
+  {
+    float4* p4 = reinterpret_cast<float4*>(smem);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
+  }
+  if (tid == 0) *nlist = 0;
+  __syncthreads();
+  // ---- RoIs of this image that belong to this level and can touch this band ----
+  for (int r = tid; r < ((a.ablate & 4) ? 0 : a.R); r += THREADS) {
+    const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
+    bool take = true;
+    if (a.filter) take = fpn_level(rb.x, rb.y, rb.z, rb.w, a.L) == lvl;
+    if (take && nbands > 1) {
+      // conservative row range of every tap of this RoI (taps lie within the clipped bins +-1)
+      float s = fminr(fmaxr(rb.y * scale, 0.f), (float)(H - 1));
+      float e = fminr(fmaxr(rb.w * scale, 0.f), (float)(H - 1));
+      float lo = fminr(s, e) - 2.f, hi = fmaxr(s, e) + 2.f;
+      if (hi < (float)row0 || lo > (float)(row1 - 1)) take = false;
+    }
+    if (take) list[atomicAdd(nlist, 1)] = r;
+  }
+  __syncthreads();
+  int nitems = *nlist * PP;
+  if (a.ablate & 1) nitems = 0;
+  const long roi_stride = (long)a.C * PP;
+  const long img_base = (long)img * a.R * roi_stride + (long)c * PP;
+
+  for (int it0 = tid; it0 < nitems; it0 += U * THREADS) {
+    float vx[U], vy[U], vg[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int it = it0 + k * THREADS;
+      vx[k] = -1.f;
+      if (it < nitems) {
+        const long idx = img_base + (long)list[it / PP] * roi_stride + it % PP;
+        vx[k] = a.ax[idx];
+        vy[k] = a.ay[idx];
+        vg[k] = a.dy[idx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const float a_x = vx[k], a_y = vy[k];
+      if (a_x != -1.f && a_y != -1.f) {
+        const float g = vg[k];
+        int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+        int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+        int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+        int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+        float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
+        float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
+        const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
+        const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
+        const int o0 = (hlow - row0) * W, o1 = (hhigh - row0) * W;
+        if (hlow >= row0 && hlow < row1) {
+          lds_add_cas(plane + o0 + wleft, w00);
+          lds_add_cas(plane + o0 + wright, w01);
+        }
+        if (hhigh >= row0 && hhigh < row1) {
+          lds_add_cas(plane + o1 + wleft, w10);
+          lds_add_cas(plane + o1 + wright, w11);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.ablate & 2) return;
+  const long off = (((long)img * a.C + c) * H + row0) * W;
+  float* dst = a.dx[lvl] + off;
+  if (((off | band_elems) & 3) == 0) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i = tid; i < band_elems / 4; i += THREADS) {
+      float4 v = reinterpret_cast<const float4*>(plane)[i];
+      if (a.req == SD_REQ_ADD) {
+        const float4 o = d4[i];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      d4[i] = v;
+    }
+  } else {
+    for (int i = tid; i < band_elems; i += THREADS)
+      dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
+  }
+}
+
+// levels: dx[l] / H / W / scale from a.L; returns SD_ERR_UNSUPPORTED when a level does not fit
+static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
+  const long budget = (long)tuning("roi_align_bwd_lds_kb", 36) * 1024;
+  a.ablate = tuning("roi_align_bwd_ablate", 0);
+  size_t lds_max = 0;
+  long work[SD_MAX_FPN_LEVELS];
+  int nl = 0;
+  for (int l = 0; l < nlvl; ++l) {
+    if (!a.dx[l]) continue;
+    const long plane_bytes = (long)a.L.H[l] * a.L.W[l] * 4;
+    int nb = (int)((plane_bytes + budget - 1) / budget);
+    if (nb < 1) nb = 1;
+    int rows = (a.L.H[l] + nb - 1) / nb;
+    nb = (a.L.H[l] + rows - 1) / rows;
+    a.band_rows[l] = rows;
+    a.nbands[l] = nb;
+    const size_t lds = (size_t)((((long)rows * a.L.W[l] + 3) & ~3L) * 4) + (size_t)(a.R + 4) * 4;
+    if (lds > 150 * 1024) return SD_ERR_UNSUPPORTED;
+    if (lds > lds_max) lds_max = lds;
+    work[l] = (long)a.B * nb * a.C;
+    a.order[nl++] = l;
+  }
+  // largest level first so the long workgroups start early
+  for (int i = 0; i < nl; ++i)
+    for (int j = i + 1; j < nl; ++j)
+      if (work[a.order[j]] > work[a.order[i]]) {
+        const int t = a.order[i];
+        a.order[i] = a.order[j];
+        a.order[j] = t;
+      }
+  long total = 0;
+  for (int i = 0; i < nl; ++i) {
+    total += work[a.order[i]];
+    a.block_end[i] = (int)total;
+  }
+  a.nlaunch = nl;
+  if (total == 0) return SD_OK;
+  if (total >= (1L << 31)) return SD_ERR_UNSUPPORTED;
+  int threads = tuning("roi_align_bwd_threads", 0);
+  if (threads != 256 && threads != 512) threads = 512;
+#define SD_BWDF(PPv, T)                                                                          \
+  do {                                                                                           \
+    auto k = roi_align_bwd_fused<PPv, T>;                                                        \
+    if (lds_max > 64 * 1024)                                                                     \
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds_max));                                           \
+    hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(T), lds_max, st, a);                       \
+  } while (0)
+  if (a.PP == 49) {
+    if (threads == 256) SD_BWDF(49, 256); else SD_BWDF(49, 512);
+  } else {
+    if (threads == 256) SD_BWDF(196, 256); else SD_BWDF(196, 512);
+  }
+#undef SD_BWDF
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+// Locality order for the forward: RoIs grouped by (level, image, coarse cell) so that an XCD's L2
+// (4 MB) holds the feature slice the concurrently running workgroups read -- a whole P4/P5 slice
+// fits, so those levels are fetched from HBM once instead of once per RoI.  Counting sort in one
+// workgroup; the order inside a bucket is arbitrary (results are stored by RoI index).
+constexpr int kOrderCells = 8;  // cells per axis
+constexpr int kOrderMaxBuckets = 4096;
+__global__ __launch_bounds__(1024) void roi_order_kernel(const float* rois, int nroi, int R,
+                                                         RoiLevels L, int B, float img_w,
+                                                         float img_h, int* order) {
+  __shared__ int hist[kOrderMaxBuckets + 1];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x;
+  const int nlv = L.nlvl + 1;  // + "no level"
+  const int nbuckets = nlv * B * kOrderCells * kOrderCells;
+  for (int i = tid; i <= nbuckets; i += 1024) hist[i] = 0;
+  __syncthreads();
+  constexpr int PER = 16;  // RoIs per thread (nroi <= 16384)
+  int bucket[PER], slot[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid + k * 1024;
+    bucket[k] = -1;
+    if (i < nroi) {
+      const float4 r = *reinterpret_cast<const float4*>(rois + (long)i * 4);
+      int lvl = L.nlvl > 1 ? fpn_level(r.x, r.y, r.z, r.w, L) : 0;
+      // coarsest level first: its slice is the smallest and stays resident
+      const int lv = lvl < 0 ? nlv - 1 : (L.nlvl - 1 - lvl);
+      const float cx = 0.5f * (r.x + r.z), cy = 0.5f * (r.y + r.w);
+      int gx = (int)(cx / img_w * kOrderCells), gy = (int)(cy / img_h * kOrderCells);
+      gx = iminr(imaxr(gx, 0), kOrderCells - 1);
+      gy = iminr(imaxr(gy, 0), kOrderCells - 1);
+      if (gy & 1) gx = kOrderCells - 1 - gx;  // boustrophedon: consecutive cells are neighbours
+      bucket[k] = ((lv * B + i / R) * kOrderCells + gy) * kOrderCells + gx;
+      slot[k] = atomicAdd(&hist[bucket[k]], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive prefix sum over the buckets (block scan, 4 buckets per thread)
+  int v[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int bi = tid * 4 + k;
+    v[k] = bi < nbuckets ? hist[bi] : 0;
+    sum += v[k];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += t;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  int run = base + incl - sum;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int bi = tid * 4 + k;
+    if (bi < nbuckets) hist[bi] = run;
+    run += v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid + k * 1024;
+    if (i < nroi) order[hist[bucket[k]] + slot[k]] = i;
+  }
+}
+
 __global__ __launch_bounds__(256) void fpn_assign_kernel(const float* rois, int n_rois,
                                                          RoiLevels L, float* rois_per_level,
                                                          int32_t* level) {
@@ -782,12 +1104,27 @@ static int fill_levels(RoiLevels& L, const float* const* feats, const int* Hs, c
   return SD_OK;
 }
 
-static int launch_fwd(FwdArgs& a, hipStream_t st) {
+static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
+                      size_t workspace_bytes = 0) {
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
   const int variant = tuning("roi_align_fwd", 1);  // 0 naive, 1 tiled
   a.ablate = tuning("roi_align_fwd_ablate", 0);
   const int nroi = a.B * a.R;
+  a.order = nullptr;
+  const int nbuckets = (a.L.nlvl + 1) * a.B * kOrderCells * kOrderCells;
+  if (variant == 1 && workspace && workspace_bytes >= (size_t)nroi * sizeof(int) + 16 &&
+      nroi <= 16384 && nbuckets <= kOrderMaxBuckets && tuning("roi_align_fwd_order", 1)) {
+    int* order = reinterpret_cast<int*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    int l0 = 0;
+    for (int l = 1; l < a.L.nlvl; ++l)
+      if (a.L.stride[l] >= 0 && a.L.scale[l] > a.L.scale[l0]) l0 = l;
+    const float img_w = (float)a.L.W[l0] / a.L.scale[l0], img_h = (float)a.L.H[l0] / a.L.scale[l0];
+    hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, st, a.rois, nroi, a.R, a.L, a.B,
+                       img_w, img_h, order);
+    SD_LAUNCH_CHECK();
+    a.order = order;
+  }
   // channel slices (workgroups) per RoI: largest divisor of C not above the knob
   int want = tuning("roi_align_fwd_slices", 8);
   if (want < 1) want = 1;
@@ -799,17 +1136,22 @@ static int launch_fwd(FwdArgs& a, hipStream_t st) {
   for (int l = 0; l < a.L.nlvl; ++l)
     if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
   const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
+  const int depth = tuning("roi_align_fwd_depth", 1);  // channels in flight per wave
   if (variant == 1 && wide && a.PH == 7 && a.PW == 7) {
-    if (rpw >= 4)
-      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 4>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512),
-                         0, st, a);
-    else if (rpw >= 2)
-      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 2>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512),
-                         0, st, a);
-    else
-      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 1>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
+#define SD_FWD77(NROI, D)                                                                       \
+  hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, D>), dim3(cdiv(nroi, NROI) * a.nslice),   \
+                     dim3(512), 0, st, a)
+    if (rpw >= 4) {
+      if (depth >= 4) SD_FWD77(4, 4); else if (depth >= 2) SD_FWD77(4, 2); else SD_FWD77(4, 1);
+    } else if (rpw >= 2) {
+      if (depth >= 4) SD_FWD77(2, 4); else if (depth >= 2) SD_FWD77(2, 2); else SD_FWD77(2, 1);
+    } else {
+      if (depth >= 4) SD_FWD77(1, 4); else if (depth >= 2) SD_FWD77(1, 2); else SD_FWD77(1, 1);
+    }
+#undef SD_FWD77
   } else if (variant == 1 && wide && a.PH == 14 && a.PW == 14) {
-    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1>), dim3(nroi * a.nslice), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1, 1>), dim3(nroi * a.nslice), dim3(512), 0, st,
+                       a);
   } else {
     const int grid = (int)((count + 255) / 256 < 65536 * 16 ? (count + 255) / 256 : 65536 * 16);
     hipLaunchKernelGGL(roi_align_fwd_naive, dim3(grid), dim3(256), 0, st, a);
@@ -885,7 +1227,7 @@ static int launch_bwd(BwdArgs& a, hipStream_t st) {
   const int variant = tuning("roi_align_bwd", 1);  // 0 global atomics, 1 LDS planes
   a.ablate = tuning("roi_align_bwd_ablate", 0);
   const size_t list_bytes = (size_t)(a.R + 8) * 4;
-  if (variant == 1 && (a.PP == 49 || a.PP == 196) && list_bytes < 20 * 1024 && count > 0) {
+  if (variant >= 1 && (a.PP == 49 || a.PP == 196) && list_bytes < 20 * 1024 && count > 0) {
     return a.PP == 49 ? launch_bwd_plane<49>(a, st) : launch_bwd_plane<196>(a, st);
   }
   if (a.req == SD_REQ_WRITE) SD_HIP_CHECK(hipMemsetAsync(a.dx, 0, dx_bytes, st));
@@ -950,7 +1292,23 @@ extern "C" int sd_roi_align_v2_bwd(const float* out_grad, const float* rois, con
     a.scale = spatial_scale;
     a.filter_lvl = -1;
     a.req = req_data;
-    if (int e = launch_bwd(a, st)) return e;
+    bool done = false;
+    if (tuning("roi_align_bwd", 2) == 2 && (a.PP == 49 || a.PP == 196) && (long)B * R * C > 0 &&
+        R <= 8192) {
+      BwdFusedArgs f{};
+      f.L = a.L;
+      f.L.nlvl = 1; f.L.H[0] = H; f.L.W[0] = W; f.L.scale[0] = spatial_scale;
+      f.dy = out_grad; f.ax = maxidx_x; f.ay = maxidx_y; f.rois = rois;
+      f.dx[0] = d_data;
+      f.B = B; f.C = C; f.R = R; f.PP = a.PP; f.filter = 0; f.req = req_data;
+      const int e = launch_bwd_fused(f, 1, st);
+      if (e != SD_ERR_UNSUPPORTED) {
+        if (e) return e;
+        done = true;
+      }
+    }
+    if (!done)
+      if (int e = launch_bwd(a, st)) return e;
   }
   if (req_rois == SD_REQ_WRITE && (long)B * R > 0) {  // roi_align_v2.cu:139-141
     SD_REQUIRE(d_rois, "d_rois is null but req_rois == write");
@@ -964,7 +1322,8 @@ extern "C" int sd_fpn_roi_align_fwd(const float* const* feats_host, const int* H
                                     const float* rois, float* out, float* maxidx_x,
                                     float* maxidx_y, int B, int C, int R, int pooled_h,
                                     int pooled_w, float roi_canonical_scale,
-                                    float roi_canonical_level, void* stream) {
+                                    float roi_canonical_level, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
   SD_REQUIRE(feats_host && Hs_host && Ws_host && strides_host, "null level description");
   FwdArgs a{};
@@ -975,7 +1334,11 @@ extern "C" int sd_fpn_roi_align_fwd(const float* const* feats_host, const int* H
   if (nlvl == 1) a.L.nlvl = 2, a.L.stride[1] = -1;  // keep the assignment filter on (1-level FPN)
   a.rois = rois; a.out = out; a.ax = maxidx_x; a.ay = maxidx_y;
   a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
-  return launch_fwd(a, (hipStream_t)stream);
+  return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+extern "C" size_t sd_fpn_roi_align_workspace_bytes(int B, int R) {
+  return (size_t)(B > 0 ? B : 0) * (size_t)(R > 0 ? R : 0) * sizeof(int) + 64;
 }
 
 extern "C" int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois,
@@ -998,8 +1361,23 @@ extern "C" int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois,
   a.dy = out_grad; a.ax = maxidx_x; a.ay = maxidx_y; a.rois = rois;
   a.B = B; a.C = C; a.R = R; a.PP = pooled_h * pooled_w;
   a.req = req_data;
-  for (int l = 0; l < nlvl; ++l) {
+  for (int l = 0; l < nlvl; ++l)
     SD_REQUIRE(d_feats_host[l] || (long)B * C == 0, "d_feats[%d] null", l);
+  const long count = (long)B * R * C * a.PP;
+  if (tuning("roi_align_bwd", 2) == 2 && (a.PP == 49 || a.PP == 196) && count > 0 && R <= 8192) {
+    BwdFusedArgs f{};
+    f.L = a.L;
+    f.dy = out_grad; f.ax = maxidx_x; f.ay = maxidx_y; f.rois = rois;
+    for (int l = 0; l < nlvl; ++l) {
+      f.L.H[l] = Hs_host[l];
+      f.L.W[l] = Ws_host[l];
+      f.dx[l] = d_feats_host[l];
+    }
+    f.B = B; f.C = C; f.R = R; f.PP = a.PP; f.filter = 1; f.req = req_data;
+    const int e = launch_bwd_fused(f, nlvl, (hipStream_t)stream);
+    if (e != SD_ERR_UNSUPPORTED) return e;
+  }
+  for (int l = 0; l < nlvl; ++l) {
     a.dx = d_feats_host[l];
     a.H = Hs_host[l];
     a.W = Ws_host[l];

@@ -29,9 +29,11 @@ struct Knob {
 Knob g_knobs[] = {
     {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default)
     {"roi_align_fwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
-    {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 4)
+    {"roi_align_fwd_order", 0, false},   // 1 (default) locality order when a workspace is given
+    {"roi_align_fwd_depth", 0, false},   // channels in flight per wave (1, 2 or 4; default 1: more in flight was measured slower)
+    {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)
     {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
-    {"roi_align_bwd", 0, false},         // 0 global atomics, 1 LDS planes (default)
+    {"roi_align_bwd", 0, false},         // 0 global atomics, 1 per-level LDS planes, 2 fused (default)
     {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 72
     {"roi_align_bwd_accum", 0, false},   // 1 int64 fixed-point LDS planes (default), 0 float CAS
     {"roi_align_bwd_ablate", 0, false},  // profiling only (results are wrong when != 0)

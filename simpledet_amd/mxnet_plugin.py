@@ -539,10 +539,12 @@ def _build_ops(mx):
             _wait(*in_data)
             B, C = feats[0].shape[:2]
             ptrs, Hs, Ws = self._levels(feats)
+            wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, rois.shape[1])
+            ws = _scratch(rois, wsb)
             lib().call("sd_fpn_roi_align_fwd", ptrs, Hs, Ws, _iarr(self.strides), len(feats),
                        _ptr(rois), _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), B, C,
                        rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
-                       float(self.lvl0), None)
+                       float(self.lvl0), _ptr(ws), ctypes.c_size_t(wsb), None)
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):

@@ -147,10 +147,12 @@ def fpn_roi_align_forward(feats, rois, rcnn_stride, pooled_size, roi_canonical_s
     out = torch.empty(shape, device=rois.device, dtype=torch.float32)
     mx = torch.empty(shape, device=rois.device, dtype=torch.float32)
     my = torch.empty(shape, device=rois.device, dtype=torch.float32)
+    wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, R)
+    ws = torch.empty(wsb, device=rois.device, dtype=torch.uint8)
     lib().call("sd_fpn_roi_align_fwd", _parr(feats), _iarr([f.shape[2] for f in feats]),
                _iarr([f.shape[3] for f in feats]), _iarr(rcnn_stride), len(feats), _p(rois),
                _p(out), _p(mx), _p(my), B, C, R, ph, pw, float(roi_canonical_scale),
-               float(roi_canonical_level), _stream())
+               float(roi_canonical_level), _p(ws), ctypes.c_size_t(wsb), _stream())
     return out, mx, my
 
 

@@ -165,7 +165,7 @@ def test_single_level_forward_bit_exact(ops, oracle, case, variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [2, 1, 0])
 @pytest.mark.parametrize("case", ["small", "p2_bands", "c4", "mask14", "odd_pool"])
 def test_single_level_backward(ops, oracle, case, variant):
     from simpledet_amd._lib import lib
@@ -205,7 +205,7 @@ def test_single_level_backward(ops, oracle, case, variant):
         torch.cuda.synchronize()
         _assert_bwd_close(acc.cpu().numpy(), want + base)
     finally:
-        lib().set_tuning("roi_align_bwd", 1)
+        lib().set_tuning("roi_align_bwd", 2)
 
 
 @pytest.mark.gpu
@@ -289,6 +289,12 @@ def test_fpn_full_size_baseline_config(ops, oracle):
                                          [f.shape for f in feats], STRIDES)
         for g, w in zip(gd0, wd):
             _assert_bwd_close(g.cpu().numpy(), w)
+        # ... and so do the per-level LDS-plane kernels (fixed-point accumulators)
+        lib().set_tuning("roi_align_bwd", 1)
+        gd1 = ops.fpn_roi_align_backward(_t(dy), _t(rois), got[1], got[2],
+                                         [f.shape for f in feats], STRIDES)
+        for g, w in zip(gd1, wd):
+            _assert_bwd_close(g.cpu().numpy(), w)
     finally:
         lib().set_tuning("roi_align_fwd", 1)
-        lib().set_tuning("roi_align_bwd", 1)
+        lib().set_tuning("roi_align_bwd", 2)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of kernel variants on one GPU box (scratch helper)
-run() { echo "== $*"; python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+# A/B of kernel variants on one GPU box (scratch helper): each argument is a bench.py flag string
+run() { echo "== $*"; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops $* 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
