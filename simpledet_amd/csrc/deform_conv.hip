@@ -123,52 +123,63 @@ __device__ __forceinline__ float get_gradient_weight(float argmax_h, float argma
   return weight;
 }
 
-// grid as im2col; dx must be zeroed (write) or hold the value to add to
+// Data gradient.  The reference scatters every col element with up to four global atomicAdds
+// (620 M atomics for the (16,256,50,84) layer).  Here one workgroup owns a row band of ONE
+// (image, channel) plane in LDS, accumulates the 9 taps x Ho*Wo col elements of that channel into
+// it with LDS compare-and-swap adds and writes the band to HBM once: no global atomics, no
+// zero-fill pass.  grid: x = channel, y = band, z = image.
+__device__ __forceinline__ void lds_add_cas_f32(float* p, float v) {
+  int* ip = reinterpret_cast<int*>(p);
+  int old = *ip;
+  while (true) {
+    const int assumed = old;
+    old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + v));
+    if (old == assumed) break;
+  }
+}
+
 __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restrict__ col,
                                                             const float* __restrict__ offset,
-                                                            float* __restrict__ dx, DcnGeom g) {
-  const int P = g.Ho * g.Wo;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const int K2 = g.kh * g.kw;
-  const int grp = blockIdx.y / K2, tap = blockIdx.y % K2;
-  const int i = tap / g.kw, j = tap % g.kw;
-  const int n = blockIdx.z;
-  const int cpg = g.C / g.dgroup;
-  const int h_out = p / g.Wo, w_out = p % g.Wo;
-  const int h_in = h_out * g.stride_h - g.pad_h, w_in = w_out * g.stride_w - g.pad_w;
+                                                            float* __restrict__ dx, DcnGeom g,
+                                                            int band_rows, int req_add) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];
+  const int P = g.Ho * g.Wo, K2 = g.kh * g.kw;
+  const int c = blockIdx.x, n = blockIdx.z;
+  const int row0 = blockIdx.y * band_rows, row1 = iminr(row0 + band_rows, g.H);
+  const int band_elems = (row1 - row0) * g.W;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < band_elems; i += 256) plane[i] = 0.f;
+  __syncthreads();
+  const int cpg = g.C / g.dgroup, grp = c / cpg;
   const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P;
-  const float offset_h = off[(long)(2 * tap) * P + p];
-  const float offset_w = off[(long)(2 * tap + 1) * P + p];
-  const float cur_inv_h_data = h_in + i * g.dil_h + offset_h;
-  const float cur_inv_w_data = w_in + j * g.dil_w + offset_w;
-  const int cur_h = (int)cur_inv_h_data, cur_w = (int)cur_inv_w_data;
-  // the (at most four) pixels that pass the reference's 5x5 neighbourhood test, with weights
-  int pos[4];
-  float wt[4];
-  int cnt = 0;
-  for (int dy = -2; dy <= 2; dy++)
-    for (int dxx = -2; dxx <= 2; dxx++) {
-      if (cur_h + dy >= 0 && cur_h + dy < g.H && cur_w + dxx >= 0 && cur_w + dxx < g.W &&
-          fabsf(cur_inv_h_data - (cur_h + dy)) < 1 && fabsf(cur_inv_w_data - (cur_w + dxx)) < 1) {
-        const float w = get_gradient_weight(cur_inv_h_data, cur_inv_w_data, cur_h + dy,
-                                            cur_w + dxx, g.H, g.W);
-        if (cnt < 4) {
-          pos[cnt] = (cur_h + dy) * g.W + cur_w + dxx;
-          wt[cnt] = w;
-          ++cnt;
+  const float* cp = col + ((long)n * g.C + c) * K2 * P;
+  for (int idx = tid; idx < K2 * P; idx += 256) {
+    const int tap = idx / P, p = idx - tap * P;
+    const int i = tap / g.kw, j = tap % g.kw;
+    const int h_out = p / g.Wo, w_out = p % g.Wo;
+    const int h_in = h_out * g.stride_h - g.pad_h, w_in = w_out * g.stride_w - g.pad_w;
+    const float offset_h = off[(long)(2 * tap) * P + p];
+    const float offset_w = off[(long)(2 * tap + 1) * P + p];
+    const float cur_inv_h_data = h_in + i * g.dil_h + offset_h;
+    const float cur_inv_w_data = w_in + j * g.dil_w + offset_w;
+    const int cur_h = (int)cur_inv_h_data, cur_w = (int)cur_inv_w_data;
+    // quick reject: every touched row lies in [cur_h - 1, cur_h + 1]
+    if (cur_h + 1 < row0 || cur_h - 1 >= row1) continue;
+    const float cur_top_grad = cp[idx];
+    for (int dy = -2; dy <= 2; dy++)
+      for (int dxx = -2; dxx <= 2; dxx++) {
+        const int hh = cur_h + dy, ww = cur_w + dxx;
+        if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W && fabsf(cur_inv_h_data - hh) < 1 &&
+            fabsf(cur_inv_w_data - ww) < 1) {
+          const float w = get_gradient_weight(cur_inv_h_data, cur_inv_w_data, hh, ww, g.H, g.W);
+          if (hh >= row0 && hh < row1 && w != 0.f)
+            lds_add_cas_f32(plane + (hh - row0) * g.W + ww, w * cur_top_grad);
         }
       }
-    }
-  const long plane = (long)g.H * g.W;
-  float* d = dx + ((long)n * g.C + (long)grp * cpg) * plane;
-  const float* cp = col + (((long)n * g.C + (long)grp * cpg) * K2 + tap) * P + p;
-  for (int c = 0; c < cpg; ++c) {
-    const float cur_top_grad = *cp;
-    for (int k = 0; k < cnt; ++k) atomicAdd(d + pos[k], wt[k] * cur_top_grad);
-    d += plane;
-    cp += (long)K2 * P;
   }
+  __syncthreads();
+  float* d = dx + (((long)n * g.C + c) * g.H + row0) * g.W;
+  for (int i = tid; i < band_elems; i += 256) d[i] = req_add ? d[i] + plane[i] : plane[i];
 }
 
 // grid: x = pixel tiles, y = offset channel (group, tap, dir), z = image
@@ -448,10 +459,20 @@ extern "C" int sd_deform_col2im(const float* col, const float* offset, float* dx
   if (N == 0 || req == SD_REQ_NULL) return SD_OK;
   SD_REQUIRE(col && offset && dx, "null tensor pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (req == SD_REQ_WRITE) SD_HIP_CHECK(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * C * H * W, st));
-  const int P = g.Ho * g.Wo;
-  hipLaunchKernelGGL(deform_col2im_kernel, dim3(cdiv(P, 256), dgroup * kh * kw, N), dim3(256), 0, st,
-                     col, offset, dx, g);
+  // row bands of at most 36 KB so that four workgroups share a CU
+  const long budget = 36 * 1024;
+  int nb = (int)(((long)H * W * 4 + budget - 1) / budget);
+  if (nb < 1) nb = 1;
+  int rows = (H + nb - 1) / nb;
+  nb = (H + rows - 1) / rows;
+  const size_t lds = (size_t)rows * W * sizeof(float);
+  SD_REQUIRE(lds <= 150 * 1024, "DeformableConvolution: feature row of %d floats too wide", W);
+  SD_REQUIRE(nb <= 65535, "too many row bands");
+  if (lds > 64 * 1024)
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(deform_col2im_kernel, dim3(C, nb, N), dim3(256), lds, st, col, offset, dx, g,
+                     rows, req == SD_REQ_ADD ? 1 : 0);
   SD_LAUNCH_CHECK();
   return SD_OK;
 }
