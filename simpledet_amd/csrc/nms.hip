@@ -8,13 +8,14 @@
 //                         == a stable descending sort) bitonic-sorted in LDS (up to 16384 keys =
 //                         128 KB of the CU's 160 KB), top `pre` boxes gathered into a float4 array.
 //   2. nms_mask_kernel    one wave per 64x64 tile of the UPPER triangle only (the scan never
-//                         reads the lower one): lane = column box in registers, the 64 row boxes
-//                         are broadcast through SGPRs (v_readlane) and each row's 64-bit mask word
-//                         is exactly the wave's v_cmp result (ballot) -- no shifts, no LDS.
-//   3. nms_scan_kernel    one workgroup per image replaces the reference's host loop: per 64-row
-//                         block the diagonal word is resolved with scalar ops in one wave, then
-//                         the kept rows' mask words are OR-ed into the later column words by all
-//                         lanes with independent coalesced loads (throughput, not latency bound).
+//                         reads the lower one), stored TRANSPOSED (per column box: which earlier
+//                         boxes suppress it): lane = row box in registers, the 64 column boxes
+//                         are broadcast through SGPRs (v_readlane) and a column's 64-bit word is
+//                         exactly the wave's v_cmp result (ballot) -- no shifts, no LDS.
+//   3. nms_scan_kernel    one wave per image replaces the reference's host loop, with no barrier:
+//                         lane = box of the current 64-box block, "already suppressed" is an OR of
+//                         (T word & keep word) along the box's own row of T (independent loads),
+//                         the diagonal word is resolved with scalar ops, one ballot per kept box.
 //                         Kept boxes are written straight to out/score; the tail is zero padded.
 // No host round trip, no device synchronisation, one stream.
 #include "common.h"
@@ -98,6 +99,11 @@ __device__ __forceinline__ float dev_iou(float a0, float a1, float a2, float a3,
   return interS / (Sa + Sb - interS);
 }
 
+// Transposed suppression matrix: T[col][rb] = bit r set  <=>  box (rb*64 + r) suppresses box col
+// (IoU over the threshold, r ranked before col).  Lanes hold the 64 row boxes of block rb, the 64
+// column boxes of block cb are broadcast through SGPRs; the word of one column IS the wave's
+// v_cmp result (ballot).  devIoU is symmetric in its arguments bit for bit (max/min and the float
+// additions commute), so this is the reference's mask read column-wise.
 __global__ __launch_bounds__(256) void nms_mask_kernel(MaskArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int pair = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
@@ -117,22 +123,22 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(MaskArgs a) {
   if (col < a.pre) cbx = boxes[col];
   const float Sr = (rbx.z - rbx.x + 1.f) * (rbx.w - rbx.y + 1.f);
   const float Sc = (cbx.z - cbx.x + 1.f) * (cbx.w - cbx.y + 1.f);
-  const unsigned long long colvalid = __ballot(col < a.pre);
+  const unsigned long long rowvalid = __ballot(row < a.pre);
   unsigned long long word = 0;
 #pragma unroll 8
-  for (int r = 0; r < kWave; ++r) {
-    // row box r broadcast through SGPRs
-    const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbx.x), r));
-    const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbx.y), r));
-    const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbx.z), r));
-    const float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbx.w), r));
-    const float Sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sr), r));
-    const float iou = dev_iou(a0, a1, a2, a3, Sa, cbx.x, cbx.y, cbx.z, cbx.w, Sc);
-    unsigned long long m = __ballot(a.ge ? iou >= a.thr : iou > a.thr) & colvalid;
-    if (rb == cb) m &= (r == 63) ? 0ull : (~0ull << (r + 1));  // start = threadIdx.x + 1
-    if (lane == r) word = m;
+  for (int c = 0; c < kWave; ++c) {
+    const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbx.x), c));
+    const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbx.y), c));
+    const float b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbx.z), c));
+    const float b3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbx.w), c));
+    const float Sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sc), c));
+    // nms.cu:92-100 with a = the row ("cur") box, b = the column box
+    const float iou = dev_iou(rbx.x, rbx.y, rbx.z, rbx.w, Sr, b0, b1, b2, b3, Sb);
+    unsigned long long m = __ballot(a.ge ? iou >= a.thr : iou > a.thr) & rowvalid;
+    if (rb == cb) m &= (1ull << c) - 1;  // only rows ranked before the column (start = tid + 1)
+    if (lane == c) word = m;
   }
-  if (row < a.pre) a.ws.mask[((long)img * a.pre + row) * a.nb + cb] = word;
+  if (col < a.pre) a.ws.mask[((long)img * a.pre + col) * a.nb + rb] = word;
 }
 
 struct ScanArgs {
@@ -143,69 +149,59 @@ struct ScanArgs {
   int pre, post, nb;
 };
 
-__global__ __launch_bounds__(256) void nms_scan_kernel(ScanArgs a) {
-  __shared__ unsigned long long remv[kMaxSortKeys / 64];
-  __shared__ unsigned long long keepmask_s;
-  const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-  const int lane = tid & (kWave - 1), wave = tid / kWave;
-  const unsigned long long* mask = a.ws.mask + (long)img * a.pre * a.nb;
+// Greedy scan, one wave per image, no barrier and no host: lane = box of the current 64-box
+// block.  suppressed(box) = OR over earlier blocks w of (T[box][w] & keep[w]) -- independent
+// 8-byte loads along the box's own row of T -- then the block's diagonal word is resolved with
+// scalar ops: every kept k knocks out the boxes whose diagonal word has bit k (one ballot).
+__global__ __launch_bounds__(64) void nms_scan_kernel(ScanArgs a) {
+  __shared__ unsigned long long kw[kMaxSortKeys / 64];
+  const int img = blockIdx.x, lane = threadIdx.x;
+  const unsigned long long* T = a.ws.mask + (long)img * a.pre * a.nb;
   const float4* boxes = a.ws.boxes + (long)img * a.pre;
   const float* sscore = a.ws.score + (long)img * a.pre;
   const int* order = a.ws.order + (long)img * a.pre;
   float* out = a.out + (long)img * a.post * 4;
   float* score = a.score + (long)img * a.post;
   int* keep_index = a.keep_index ? a.keep_index + (long)img * a.post : nullptr;
-  for (int j = tid; j < a.nb; j += T) remv[j] = 0;
-  __syncthreads();
-  int nkeep = 0;  // kept so far: every thread tracks it identically from keepmask_s
+  int nkeep = 0;
   for (int rb = 0; rb < a.nb; ++rb) {
     if (nkeep >= a.post) break;  // only the first `post` kept boxes are ever output
-    if (wave == 0) {
-      const int row = rb * kWave + lane;
-      unsigned long long diag = 0;
-      if (row < a.pre) diag = mask[(long)row * a.nb + rb];
-      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-      const unsigned long long valid = __ballot(row < a.pre);
-      unsigned long long cur = remv[rb];
-      cur = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)cur);
-      unsigned long long keepmask = 0;
-      for (int k = 0; k < kWave; ++k) {  // wave-uniform (scalar) greedy resolve of the diagonal
-        const unsigned long long bit = 1ull << k;
-        if (!(cur & bit) && (valid & bit)) {
-          keepmask |= bit;
-          cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, k) << 32) |
-                 (unsigned)__builtin_amdgcn_readlane((int)dlo, k);
-        }
-      }
-      // PrepareOutput (nms.cu:207-233) for the rows kept in this block
-      if (keepmask & (1ull << lane)) {
-        const int rank = nkeep + __popcll(keepmask & ((1ull << lane) - 1));
-        if (rank < a.post) {
-          reinterpret_cast<float4*>(out)[rank] = boxes[row];
-          score[rank] = sscore[row];
-          if (keep_index) keep_index[rank] = order[row];
-        }
-      }
-      if (lane == 0) keepmask_s = keepmask;
+    const int c = rb * kWave + lane;
+    const bool valid = c < a.pre;
+    const unsigned long long* Tc = T + (long)(valid ? c : 0) * a.nb;
+    unsigned long long acc = 0;
+    for (int w0 = 0; w0 < rb; w0 += 16) {
+      unsigned long long t[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) t[e] = (w0 + e < rb) ? Tc[w0 + e] : 0ull;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (w0 + e < rb) acc |= t[e] & kw[w0 + e];
     }
-    __syncthreads();
-    const unsigned long long keepmask = keepmask_s;
+    const unsigned long long diag = valid ? Tc[rb] : 0ull;
+    unsigned long long cur = __ballot(acc != 0 || !valid);
+    unsigned long long keepmask = 0;
+    unsigned long long cand = ~cur;
+    while (cand) {  // wave-uniform: one trip per kept box of this block
+      const int k = __ffsll((long long)cand) - 1;
+      keepmask |= 1ull << k;
+      cur |= __ballot((diag >> k) & 1ull) | (1ull << k);
+      cand = ~cur;
+    }
+    if (lane == 0) kw[rb] = keepmask;
+    // PrepareOutput (nms.cu:207-233) for the boxes kept in this block
+    if (keepmask & (1ull << lane)) {
+      const int rank = nkeep + __popcll(keepmask & ((1ull << lane) - 1));
+      if (rank < a.post) {
+        reinterpret_cast<float4*>(out)[rank] = boxes[c];
+        score[rank] = sscore[c];
+        if (keep_index) keep_index[rank] = order[c];
+      }
+    }
     nkeep += __popcll(keepmask);
-    for (int j = rb + 1 + tid; j < a.nb; j += T) {
-      unsigned long long acc = remv[j];
-      unsigned long long km = keepmask;
-      while (km) {
-        const int k = __ffsll((long long)km) - 1;
-        km &= km - 1;
-        acc |= mask[(long)(rb * kWave + k) * a.nb + j];
-      }
-      remv[j] = acc;
-    }
-    __syncthreads();
   }
   if (nkeep > a.post) nkeep = a.post;
-  for (int i = nkeep + tid; i < a.post; i += T) {
+  for (int i = nkeep + lane; i < a.post; i += kWave) {
     reinterpret_cast<float4*>(out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     score[i] = 0.f;
     if (keep_index) keep_index[i] = -1;
@@ -291,7 +287,7 @@ extern "C" int sd_nms(const float* dets, int B, int N, int pre_nms_top_n, int po
   SD_LAUNCH_CHECK();
 
   ScanArgs ca{ws, out, score, keep_index, pre, post, nb};
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, st, ca);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, ca);
   SD_LAUNCH_CHECK();
   return SD_OK;
 }

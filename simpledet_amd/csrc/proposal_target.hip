@@ -10,9 +10,10 @@
 //                         against the gt boxes held in LDS, first-maximum arg-max, then the fg / neg
 //                         / bg index lists in candidate order (block-wide prefix scans).
 //   2. pt_sample_kernel   ONE workgroup, images in order: replays the reference's random_shuffle
-//                         calls bit for bit.  rand() draws are generated by one lane from the glibc
-//                         state kept in device memory (the draw count is data dependent, so the
-//                         state has to live where the data is); the Fisher-Yates swaps run in LDS.
+//                         calls bit for bit from the glibc state kept in device memory (the draw
+//                         count is data dependent, so the state has to live where the data is):
+//                         draws from a register-resident ring, j_i = draw % (i+1) in parallel,
+//                         and the kept prefix by walking the swaps backwards, one thread per row.
 //   3. pt_encode_kernel   one workgroup per output row: gather roi / label / IoU, encode the box
 //                         deltas, write the 4-of-4K expanded target and weight rows (zero fill +
 //                         slot) with coalesced stores.
@@ -181,20 +182,57 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
   }
 }
 
-// glibc rand(): r[f] += r[b]; result = r[f] >> 1; both indices advance modulo 31
-struct GlibcRand {
+// ---- std::random_shuffle replay, parallel where the algorithm allows it -------------------------
+// random_shuffle(first, last):  for i in [1, n): swap(a[i], a[rand() % (i + 1)]).
+// (1) the n-1 draws do not depend on the data: one lane generates them with the 31-word ring held
+//     in registers.  In coordinates rotated so that the front index is 0 the rear index is always
+//     28 (TYPE_3 keeps front = rear + 3), so the unrolled recurrence reg[s] += reg[(s+28) % 31]
+//     has static register indices: ~3 instructions per draw instead of a chain of LDS round trips;
+// (2) j_i = draw_i % (i+1) for all i in parallel;
+// (3) only the first `take` shuffled entries are ever used, and the origin of output position p
+//     follows from walking the swaps backwards (i = n-1 .. 1: at i == cur the content came from
+//     j_i; at j_i == cur it came from i, which no earlier swap can touch): one thread per output.
+// The rare multi-round negative padding (proposal_target.cc:116-122 with fewer negatives than
+// missing rows) needs the whole permuted list between rounds and replays the swaps in order.
+struct RingRegs {
   unsigned r[31];
-  int f, b;
-  __device__ __forceinline__ int next() {
-    const unsigned v = (r[f] += r[b]);
-    if (++f >= 31) f = 0;
-    if (++b >= 31) b = 0;
-    return (int)(v >> 1);
-  }
 };
 
-// std::random_shuffle(first, last): for i in [1, n): swap(a[i], a[rand() % (i + 1)])
-// (lane 0 of the workgroup only; list in global memory, draws and swaps strictly in order)
+template <int THREADS>
+__device__ void draw_many(unsigned* ring, int* fb, int* draws, int n) {
+  // every lane of wave 0 runs the same recurrence on the same values; the stores of a draw all
+  // carry the same value to the same LDS word (no exec-mask juggling per draw)
+  if (threadIdx.x < kWave) {
+    const int f = fb[0];
+    RingRegs g;
+#pragma unroll
+    for (int k = 0; k < 31; ++k) g.r[k] = ring[(f + k) % 31];
+    int base = 0;
+    for (; base + 31 <= n; base += 31) {
+#pragma unroll
+      for (int s = 0; s < 31; ++s) {
+        g.r[s] += g.r[(s + 28) % 31];
+        draws[base + s] = (int)(g.r[s] >> 1);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 31; ++s) {
+      if (base + s < n) {
+        g.r[s] += g.r[(s + 28) % 31];
+        draws[base + s] = (int)(g.r[s] >> 1);
+      }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 31; ++k) ring[(f + k) % 31] = g.r[k];
+      fb[0] = (f + n) % 31;
+      fb[1] = (fb[1] + n) % 31;
+    }
+  }
+  __syncthreads();
+}
+
+// in-order replay (multi-round padding only): lane 0, list in LDS
 __device__ void shuffle_list(int* list, int n, unsigned* ring, int& f, int& b) {
   for (int i = 1; i < n; ++i) {
     const unsigned v = (ring[f] += ring[b]);
@@ -211,10 +249,12 @@ __device__ void shuffle_list(int* list, int n, unsigned* ring, int& f, int& b) {
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pt_sample_kernel(PtArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int lists[];  // one list of up to Ncand ints
+  extern __shared__ __attribute__((aligned(16))) int lds[];  // [list: Ncand][draws / j: Ncand]
   __shared__ unsigned ring[31];
   __shared__ int fb[2];
   const int tid = threadIdx.x;
+  int* lists = lds;
+  int* draws = lds + a.Ncand;
   if (tid < 31) ring[tid] = (unsigned)a.rng[tid];
   if (tid == 0) {
     fb[0] = a.rng[31];
@@ -222,6 +262,34 @@ __global__ __launch_bounds__(THREADS) void pt_sample_kernel(PtArgs a) {
   }
   __syncthreads();
   const int S = a.S;
+  // out[0..take) = first `take` entries of random_shuffle(list[0..n)); consumes n-1 draws
+  auto shuffled_prefix = [&](const int* list, int n, int take, int* out) {
+    draw_many<THREADS>(ring, fb, draws, n - 1);
+    for (int i = 1 + tid; i < n; i += THREADS) draws[i - 1] = draws[i - 1] % (i + 1);  // j_i
+    __syncthreads();
+    for (int p = tid; p < take; p += THREADS) {
+      int cur = p;
+      // j_i are read eight at a time (independent LDS loads); once cur has moved up to some i no
+      // later (smaller) i can match it, so the walk simply runs to the end without a branch
+      int i = n - 1;
+      for (; i >= 8; i -= 8) {
+        int j[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) j[e] = draws[i - 1 - e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ii = i - e;
+          cur = (cur == ii) ? j[e] : ((cur == j[e]) ? ii : cur);
+        }
+      }
+      for (; i >= 1; --i) {
+        const int j = draws[i - 1];
+        cur = (cur == i) ? j : ((cur == j) ? i : cur);
+      }
+      out[p] = list[cur];
+    }
+    __syncthreads();
+  };
   for (int img = 0; img < a.B; ++img) {
     PtWs ws = a.ws;
     int* c = ws.counts + img * 8;
@@ -233,52 +301,42 @@ __global__ __launch_bounds__(THREADS) void pt_sample_kernel(PtArgs a) {
     const int fg_this = a.fg_per_image < n_fg ? a.fg_per_image : n_fg;       // :81
     const int want_bg = S - fg_this;
     const int bg_this = want_bg < n_bg ? want_bg : n_bg;                      // :100
-    // each shuffle: stage the list in LDS, lane 0 replays the swaps, everyone copies what is kept
-    auto staged_shuffle = [&](int* list, int n) {
-      for (int i = tid; i < n; i += THREADS) lists[i] = list[i];
-      __syncthreads();
-      if (tid == 0) {
-        int f = fb[0], b = fb[1];
-        shuffle_list(lists, n, ring, f, b);
-        fb[0] = f;
-        fb[1] = b;
-      }
-      __syncthreads();
-    };
     int nkept = 0;
     if (n_fg > fg_this) {                                                     // :82-85
-      staged_shuffle(fg, n_fg);
-      for (int i = tid; i < fg_this; i += THREADS) kept[i] = lists[i];
+      shuffled_prefix(fg, n_fg, fg_this, kept);
     } else {
       for (int i = tid; i < fg_this; i += THREADS) kept[i] = fg[i];
     }
     nkept = fg_this;
-    __syncthreads();
     if (n_bg > bg_this) {                                                     // :101-104
-      staged_shuffle(bg, n_bg);
-      for (int i = tid; i < bg_this; i += THREADS) kept[nkept + i] = lists[i];
+      shuffled_prefix(bg, n_bg, bg_this, kept + nkept);
     } else {
       for (int i = tid; i < bg_this; i += THREADS) kept[nkept + i] = bg[i];
     }
     nkept += bg_this;
-    __syncthreads();
-    // pad with shuffled negatives (:116-122); neg keeps its shuffled order between rounds
+    // pad with shuffled negatives (:116-122)
     if (nkept < S && n_neg > 0) {
-      for (int i = tid; i < n_neg; i += THREADS) lists[i] = neg[i];
-      __syncthreads();
-      while (nkept < S) {
-        const int gap = S - nkept;
-        if (tid == 0) {
-          int f = fb[0], b = fb[1];
-          shuffle_list(lists, n_neg, ring, f, b);
-          fb[0] = f;
-          fb[1] = b;
+      const int gap = S - nkept;
+      if (n_neg >= gap) {  // one round: only its first `gap` entries matter
+        shuffled_prefix(neg, n_neg, gap, kept + nkept);
+        nkept += gap;
+      } else {             // several rounds over the same, progressively re-shuffled list
+        for (int i = tid; i < n_neg; i += THREADS) lists[i] = neg[i];
+        __syncthreads();
+        while (nkept < S) {
+          const int g2 = S - nkept;
+          if (tid == 0) {
+            int f = fb[0], b = fb[1];
+            shuffle_list(lists, n_neg, ring, f, b);
+            fb[0] = f;
+            fb[1] = b;
+          }
+          __syncthreads();
+          const int take = g2 < n_neg ? g2 : n_neg;
+          for (int i = tid; i < take; i += THREADS) kept[nkept + i] = lists[i];
+          nkept += take;
+          __syncthreads();
         }
-        __syncthreads();
-        const int take = gap < n_neg ? gap : n_neg;
-        for (int i = tid; i < take; i += THREADS) kept[nkept + i] = lists[i];
-        nkept += take;
-        __syncthreads();
       }
     }
     for (int i = nkept + tid; i < S; i += THREADS) kept[i] = -1;
@@ -462,12 +520,12 @@ extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int 
   SD_REQUIRE(lds1 <= 64 * 1024, "too many gt boxes per image (M=%d)", M);
   hipLaunchKernelGGL((pt_assign_kernel<1024>), dim3(B), dim3(1024), lds1, st, a);
   SD_LAUNCH_CHECK();
-  const size_t lds2 = (size_t)(a.Ncand > 0 ? a.Ncand : 1) * sizeof(int);
+  const size_t lds2 = (size_t)(a.Ncand > 0 ? a.Ncand : 1) * 2 * sizeof(int);
   SD_REQUIRE(lds2 <= 150 * 1024, "too many candidate rois per image (%d)", a.Ncand);
   if (lds2 > 64 * 1024)
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)pt_sample_kernel<256>,
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)pt_sample_kernel<512>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-  hipLaunchKernelGGL((pt_sample_kernel<256>), dim3(1), dim3(256), lds2, st, a);
+  hipLaunchKernelGGL((pt_sample_kernel<512>), dim3(1), dim3(512), lds2, st, a);
   SD_LAUNCH_CHECK();
   hipLaunchKernelGGL(pt_encode_kernel, dim3(B * S), dim3(128), 0, st, a);
   SD_LAUNCH_CHECK();
