@@ -15,7 +15,7 @@ gradient buffer with every step (the reference's only inter-GPU exchange, detect
 
 roofline: ALGORITHMIC bytes of one forward launch (N*S_F + 16*N*R + 3*N*S_O
 = 335.9 MB at N=2) / the forward kernel's average duration measured with HIP events on the launch
-stream inside the timed region; peak = 8 TB/s HBM3E.  The backward (4 launches, one per level,
+stream inside the timed region; peak = 8 TB/s HBM3E.  The backward (one fused launch for all levels,
 same algorithmic bytes) is reported next to it.
 cpu_baseline: the CPU oracle (oracle/, a port of operator_cxx's arithmetic) timed on the host
 cores on the same workload, rank 0, N=1 only.  It is a reported baseline, not the product.
@@ -212,7 +212,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "kernel": "sd::roi_align_fwd_tiled<7,7,4> (fused FPN forward, 1 launch/step)",
+        "kernel": "sd::roi_align_fwd_tiled<7,7,4,1> (fused FPN forward, 1 launch/step)",
         "bound": "hbm",
         "achieved": alg / (fwd_ms * 1e-3) / 1e9,
         "peak": PEAK_HBM_GBS,
@@ -222,7 +222,7 @@ def main():
         "algorithmic_bytes": alg,
         "avg_launch_ms": fwd_ms,
         "backward": {
-            "kernel": "roi_align_bwd_plane (4 launches/step, one per FPN level)",
+            "kernel": "sd::roi_align_bwd_fused<49,512> (all FPN levels, 1 launch/step)",
             "achieved": alg / (bwd_ms * 1e-3) / 1e9,
             "frac": alg / (bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "avg_ms": bwd_ms,

@@ -1114,7 +1114,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   a.order = nullptr;
   const int nbuckets = (a.L.nlvl + 1) * a.B * kOrderCells * kOrderCells;
   if (variant == 1 && workspace && workspace_bytes >= (size_t)nroi * sizeof(int) + 16 &&
-      nroi <= 16384 && nbuckets <= kOrderMaxBuckets && tuning("roi_align_fwd_order", 1)) {
+      nroi <= 16384 && nbuckets <= kOrderMaxBuckets && tuning("roi_align_fwd_order", 0)) {
     int* order = reinterpret_cast<int*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
     int l0 = 0;
     for (int l = 1; l < a.L.nlvl; ++l)
