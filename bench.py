@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--grad-allreduce", type=float, default=0.0,
                     help="MB of fp32 gradients all-reduced (RCCL) per step, overlapped; 0 = off")
     ap.add_argument("--tuning", action="append", default=[], help="key=value kernel knob (A/B)")
+    ap.add_argument("--float-argmax", action="store_true",
+                    help="keep the arg-max between forward and backward as two fp32 planes (the "
+                         "reference op's outputs) instead of one byte per output")
     ap.add_argument("--calibrate", action="store_true",
                     help="also run the known-size HBM stream copies (measured peak + PMC calibration)")
     ap.add_argument("--no-ops", action="store_true",
@@ -109,10 +112,16 @@ def main():
                 dist.all_reduce(grad_buf)
         if ev:
             ev[0].record()
-        out, ax, ay = ops.fpn_roi_align_forward(feats, rois, strides, (7, 7))
+        if args.float_argmax:
+            out, ax, ay = ops.fpn_roi_align_forward(feats, rois, strides, (7, 7))
+        else:
+            out, am = ops.fpn_roi_align_forward_packed(feats, rois, strides, (7, 7))
         if ev:
             ev[1].record()
-        ops.fpn_roi_align_backward(dy, rois, ax, ay, None, strides, d_feats=d_feats)
+        if args.float_argmax:
+            ops.fpn_roi_align_backward(dy, rois, ax, ay, None, strides, d_feats=d_feats)
+        else:
+            ops.fpn_roi_align_backward_packed(dy, rois, am, None, strides, d_feats=d_feats)
         if ev:
             ev[2].record()
         if grad_buf is not None:
@@ -285,6 +294,7 @@ def main():
                         "7x7x4 samples (BASELINE configs[1])" % (args.channels, args.images, args.rois),
             "images_per_gpu": args.images,
             "rois_per_image": args.rois,
+            "argmax_state": "fp32 x,y planes" if args.float_argmax else "packed u8 (decoded in backward)",
             "sharding": "images across ranks, no data-path collective"
                         + (", +%.0f MB grad all-reduce/step" % args.grad_allreduce
                            if grad_buf is not None else ""),

@@ -101,6 +101,24 @@ int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois, const float* 
                          const int* Ws_host, const int* strides_host, int nlvl, int req_data, int B,
                          int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
                          float roi_canonical_level, void* stream);
+/* The same fused op with the arg-max kept as ONE byte per output (row sample * 3 + column sample,
+ * 255 = nothing pooled) plus a small per-RoI table of the sample coordinates
+ * (coords: B*R x 2 x 3*pooled floats, 172 KB at the baseline) instead of two fp32 planes: the
+ * arg-max is state between this op's own forward and backward, not part of the reference's graph
+ * interface.  The backward looks the float coordinate up in the table, i.e. gets exactly the value
+ * the float planes would have held.  Cuts the forward's writes from 3 to 1.25 planes and the
+ * backward's reads likewise (7x7 and 14x14 pooling). */
+int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_host,
+                                const int* Ws_host, const int* strides_host, int nlvl,
+                                const float* rois, float* out, uint8_t* argmax, float* coords, int B,
+                                int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
+                                float roi_canonical_level, void* workspace, size_t workspace_bytes,
+                                void* stream);
+int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const uint8_t* argmax,
+                                const float* coords, float* const* d_feats_host, const int* Hs_host, const int* Ws_host,
+                                const int* strides_host, int nlvl, int req_data, int B, int C, int R,
+                                int pooled_h, int pooled_w, float roi_canonical_scale,
+                                float roi_canonical_level, void* stream);
 /* assign_layer_fpn CustomOp (models/FPN/assign_layer_fpn.py:10-73): rois (n_rois,4) ->
  * rois_per_level (nlvl, n_rois, 4) zero-masked, and optionally level (n_rois) int32 (-1 = none) */
 int sd_fpn_roi_assign(const float* rois, int n_rois, const int* strides_host, int nlvl,

@@ -20,6 +20,7 @@ _SCALARS = {
     "size_t": ctypes.c_size_t,
     "int32_t": ctypes.c_int32,
     "uint32_t": ctypes.c_uint32,
+    "uint8_t": ctypes.c_uint8,
     "int64_t": ctypes.c_int64,
     "uint64_t": ctypes.c_uint64,
     "unsigned": ctypes.c_uint,

@@ -41,17 +41,30 @@ def roi_align(data, rois, out_size, stride):
 class _FPNRoIAlign(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, rcnn_stride, pooled_size, scale0, lvl0, *feats):
-        out, mx, my = ops.fpn_roi_align_forward(list(feats), rois, rcnn_stride, pooled_size, scale0,
-                                                lvl0)
-        ctx.save_for_backward(rois, mx, my)
+        ph, pw = (pooled_size, pooled_size) if isinstance(pooled_size, int) else tuple(pooled_size)
+        ctx.packed = (ph, pw) in ((7, 7), (14, 14)) and rois.shape[1] <= 8192
+        if ctx.packed:  # one-byte arg-max between forward and backward
+            out, am = ops.fpn_roi_align_forward_packed(list(feats), rois, rcnn_stride, (ph, pw),
+                                                       scale0, lvl0)
+            ctx.save_for_backward(rois, am[0], am[1])
+        else:
+            out, mx, my = ops.fpn_roi_align_forward(list(feats), rois, rcnn_stride, (ph, pw), scale0,
+                                                    lvl0)
+            ctx.save_for_backward(rois, mx, my)
         ctx.meta = ([tuple(f.shape) for f in feats], list(rcnn_stride), scale0, lvl0)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        rois, mx, my = ctx.saved_tensors
         shapes, strides, scale0, lvl0 = ctx.meta
-        d = ops.fpn_roi_align_backward(dy.contiguous(), rois, mx, my, shapes, strides, scale0, lvl0)
+        if ctx.packed:
+            rois, am, co = ctx.saved_tensors
+            d = ops.fpn_roi_align_backward_packed(dy.contiguous(), rois, (am, co), shapes, strides,
+                                                  scale0, lvl0)
+        else:
+            rois, mx, my = ctx.saved_tensors
+            d = ops.fpn_roi_align_backward(dy.contiguous(), rois, mx, my, shapes, strides, scale0,
+                                           lvl0)
         return (None, None, None, None, None) + tuple(d)
 
 

@@ -55,6 +55,7 @@ __device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2,
 // ------------------------------------------------------------------------------------------------
 struct FwdOut {
   float val, ax, ay;
+  int code;  // packed arg-max: row sample * 3 + column sample, 255 = none
 };
 
 __device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ plane, int height,
@@ -78,7 +79,7 @@ __device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ p
   wstart = fminr(fmaxr(wstart + roi_start_w, 0.f), (float)(width - 1));
   wend = fminr(fmaxr(wend + roi_start_w, 0.f), (float)(width - 1));
   bool is_empty = (hend <= hstart) || (wend <= wstart);
-  FwdOut o{0.f, -1.f, -1.f};
+  FwdOut o{0.f, -1.f, -1.f, 255};
   if (!is_empty) {
     o.val = -FLT_MAX;
     float h_stride = (float)((double)(hend - hstart) / 3.0);
@@ -86,11 +87,13 @@ __device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ p
     double hlim = (double)(hend - h_stride) + 0.01;
     double wlim = (double)(wend - w_stride) + 0.01;
     float hstep = fmaxr(h_stride, 0.01f), wstep = fmaxr(w_stride, 0.01f);
-    for (float h = hstart + h_stride; (double)h <= hlim; h += hstep) {
+    int ik = 0;
+    for (float h = hstart + h_stride; (double)h <= hlim; h += hstep, ++ik) {
       int hlow = iminr(imaxr((int)floorf(h), 0), height - 1);
       int hhigh = iminr(imaxr((int)ceilf(h), 0), height - 1);
       float alpha = (hlow == hhigh) ? 0.5f : (h - (float)hlow) / (float)(hhigh - hlow);
-      for (float w = wstart + w_stride; (double)w <= wlim; w += wstep) {
+      int il = 0;
+      for (float w = wstart + w_stride; (double)w <= wlim; w += wstep, ++il) {
         int wleft = iminr(imaxr((int)floorf(w), 0), width - 1);
         int wright = iminr(imaxr((int)ceilf(w), 0), width - 1);
         float beta = (wleft == wright) ? 0.5f : (w - (float)wleft) / (float)(wright - wleft);
@@ -102,6 +105,7 @@ __device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ p
           o.val = value;
           o.ax = w;
           o.ay = h;
+          o.code = ik * 3 + il;
         }
       }
     }
@@ -121,6 +125,8 @@ struct FwdArgs {
   float* ax;
   float* ay;
   int B, C, R, PH, PW;
+  unsigned char* amax8;  // packed arg-max output (fused op); when set, ax / ay are not written
+  float* coords;         // with amax8: (B*R, 2, 3*P) sample-coordinate table the backward decodes with
   int nslice;  // channel slices per RoI (one workgroup each)
   const int* order;  // optional locality order of the RoIs (a permutation of [0, B*R)), or null
   int ablate;  // profiling only: 1 stop after the tables
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
     float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
     int lvl = 0;
     if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
-    FwdOut o{0.f, -1.f, -1.f};
+    FwdOut o{0.f, -1.f, -1.f, 255};
     if (lvl >= 0) {
       int H = a.L.H[lvl], W = a.L.W[lvl];
       const float* plane = a.L.data[lvl] + ((long)(n / a.R) * a.C + c) * H * W;
@@ -147,8 +153,12 @@ __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
     }
     if (a.L.nlvl > 1) o.val = o.val + 0.0f;  // add_n with the other levels' zeros
     a.out[index] = o.val;
-    a.ax[index] = o.ax;
-    a.ay[index] = o.ay;
+    if (a.amax8) {
+      a.amax8[index] = (unsigned char)o.code;
+    } else {
+      a.ax[index] = o.ax;
+      a.ay[index] = o.ay;
+    }
   }
 }
 
@@ -229,8 +239,45 @@ __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, fl
   return cnt;
 }
 
-template <int PH, int PW, int NROI, int D>
+// coordinate of sample k of axis bin p: the same float expressions as axis_samples / the
+// reference loop (start + stride, then += max(stride, 0.01f) per further sample), so a packed
+// arg-max (k, l) decodes to exactly the float the forward would have stored
+__device__ __forceinline__ float sample_coord(int p, int pooled, float start_c, float end_c,
+                                              float scale, int size, int k) {
+  const float roi_start = start_c * scale;
+  const float roi_end = end_c * scale;
+  const float roi_len = roi_end - roi_start;
+  const float bin = roi_len / (float)pooled;
+  float lo = (float)p * bin;
+  float hi = (float)(p + 1) * bin;
+  lo = fminr(fmaxr(lo + roi_start, 0.f), (float)(size - 1));
+  hi = fminr(fmaxr(hi + roi_start, 0.f), (float)(size - 1));
+  const float stride = (hi - lo) / 3.0f;
+  const float step = fmaxr(stride, 0.01f);
+  float v = lo + stride;
+  for (int i = 0; i < k; ++i) v += step;
+  return v;
+}
+
+// sample-coordinate table of the packed arg-max: coords[roi][0][p*3 + k] = row coordinate of sample
+// k of bin row p, coords[roi][1][q*3 + l] = column coordinate (2 * 3 * P floats per RoI)
+__global__ __launch_bounds__(64) void roi_coords_kernel(const float* rois, int nroi, RoiLevels L,
+                                                        int PH, int PW, float* coords) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const float* r = rois + (long)n * 4;
+  int lvl = 0;
+  if (L.nlvl > 1) lvl = fpn_level(r[0], r[1], r[2], r[3], L);
+  if (lvl < 0) return;
+  float* c = coords + (long)n * 3 * (PH + PW);
+  for (int e = lane; e < 3 * PH; e += 64)
+    c[e] = sample_coord(e / 3, PH, r[1], r[3], L.scale[lvl], L.H[lvl], e % 3);
+  for (int e = lane; e < 3 * PW; e += 64)
+    c[3 * PH + e] = sample_coord(e / 3, PW, r[0], r[2], L.scale[lvl], L.W[lvl], e % 3);
+}
+
+template <int PH, int PW, int NROI, bool PK>
 __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
+  constexpr int D = 1;  // channels in flight per wave (deeper batches measured slower)
   using S = FwdSmem<PH, PW, NROI>;
   constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, PPP = S::PPP, CH = S::CH, NWAVE = S::NWAVE;
   constexpr int THREADS = NWAVE * kWave;
@@ -317,6 +364,24 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
   }
   __syncthreads();
   if (a.ablate & 1) return;
+  if (PK && slice == 0) {  // the sample coordinates the packed arg-max indexes, once per RoI
+    for (int e = tid; e < NROI * 3 * (PH + PW); e += THREADS) {
+      const int i = e / (3 * (PH + PW)), j = e % (3 * (PH + PW));
+      const typename S::Roi& t = s.roi[i];
+      if (t.lvl < 0) continue;
+      const bool row = j < 3 * PH;
+      const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
+      float v;
+      if (k < 2 && !(t.fb_row | t.fb_col)) {
+        v = row ? t.hval[2 * p + k] : t.wval[2 * p + k];
+      } else {
+        const int lv = t.lvl;
+        v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
+                : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
+      }
+      a.coords[(long)t.n * 3 * (PH + PW) + j] = v;
+    }
+  }
 
   // ===== from here on every wave runs on its own: no workgroup barrier =====
   float* tile = s.tile + wave * CH;
@@ -350,8 +415,12 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     if (lvl < 0) {  // every per-level op sees a zero box
       for (int e = tid; e < nch * PP; e += THREADS) {
         a.out[obase + e] = 0.f;
-        a.ax[obase + e] = -1.f;
-        a.ay[obase + e] = -1.f;
+        if (PK) {
+          a.amax8[obase + e] = 255;
+        } else {
+          a.ax[obase + e] = -1.f;
+          a.ay[obase + e] = -1.f;
+        }
       }
     } else if (t.fb_row || t.fb_col) {
       const int H = a.L.H[lvl], W = a.L.W[lvl];
@@ -364,8 +433,12 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
                                       t.box[3], scale, bin / PW, bin % PW, PH, PW);
         if (a.L.nlvl > 1) o.val = o.val + 0.0f;
         a.out[obase + e] = o.val;
-        a.ax[obase + e] = o.ax;
-        a.ay[obase + e] = o.ay;
+        if (PK) {
+          a.amax8[obase + e] = (unsigned char)o.code;
+        } else {
+          a.ax[obase + e] = o.ax;
+          a.ay[obase + e] = o.ay;
+        }
       }
     }
   }
@@ -393,8 +466,12 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
           const int bin = lane + b * kWave;
           if (bin < PP) {
             a.out[ob + bin] = 0.f;
-            a.ax[ob + bin] = -1.f;
-            a.ay[ob + bin] = -1.f;
+            if (PK) {
+              a.amax8[ob + bin] = 255;
+            } else {
+              a.ax[ob + bin] = -1.f;
+              a.ay[ob + bin] = -1.f;
+            }
           }
         }
       }
@@ -479,8 +556,9 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     auto channel_loop = [&](auto dup_tag) {
       const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
       float* po = a.out + obase + (long)wave * PP;
-      float* px = a.ax + obase + (long)wave * PP;
-      float* py = a.ay + obase + (long)wave * PP;
+      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
+      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
+      unsigned char* pk = PK ? a.amax8 + obase + (long)wave * PP : nullptr;
       for (int c0 = wave; c0 < nch; c0 += D * NWAVE) {
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -499,6 +577,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
               const int bin = lane + b * kWave;
               if (bin < PP) {
                 float maxval = init[b], bx = -1.f, by = -1.f;
+                int bk = -1;
                 const float4* tp = reinterpret_cast<const float4*>(tile) + bin;
 #pragma unroll
                 for (int kl = 0; kl < 4; ++kl) {
@@ -508,22 +587,34 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
                   const float value = w.x * v.x + w.y * v.z + w.z * v.y + w.w * v.w;
                   if (value > maxval) {
                     maxval = value;
-                    bx = cx[b][kl & 1];
-                    by = cy[b][kl >> 1];
+                    if (PK) {
+                      bk = (kl >> 1) * 3 + (kl & 1);
+                    } else {
+                      bx = cx[b][kl & 1];
+                      by = cy[b][kl >> 1];
+                    }
                   }
                 }
                 if (a.L.nlvl > 1) maxval = maxval + 0.0f;
                 po[bin + d * NWAVE * PP] = maxval;
-                px[bin + d * NWAVE * PP] = bx;
-                py[bin + d * NWAVE * PP] = by;
+                if (PK) {
+                  pk[bin + d * NWAVE * PP] = (unsigned char)(bk < 0 ? 255 : bk);
+                } else {
+                  px[bin + d * NWAVE * PP] = bx;
+                  py[bin + d * NWAVE * PP] = by;
+                }
               }
             }
           }
         }
         pl += D * pstep;
         po += D * NWAVE * PP;
-        px += D * NWAVE * PP;
-        py += D * NWAVE * PP;
+        if (PK) {
+          pk += D * NWAVE * PP;
+        } else {
+          px += D * NWAVE * PP;
+          py += D * NWAVE * PP;
+        }
       }
     };
     if (any_dup) channel_loop(std::true_type{});
@@ -805,6 +896,8 @@ struct BwdFusedArgs {
   const float* dy;
   const float* ax;
   const float* ay;
+  const unsigned char* amax8;  // packed arg-max (k*3 + l, 255 none) instead of ax / ay
+  const float* coords;         // with amax8: the forward's sample-coordinate table
   const float* rois;
   float* dx[SD_MAX_FPN_LEVELS];
   int band_rows[SD_MAX_FPN_LEVELS], nbands[SD_MAX_FPN_LEVELS];
@@ -817,8 +910,9 @@ struct BwdFusedArgs {
   int ablate;
 };
 
-template <int PP, int THREADS>
+template <int PP, int THREADS, bool PK>
 __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
+  constexpr int PW = PP == 49 ? 7 : 14, PH = PW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int U = 4;  // items per lane per trip: 3*U independent global loads in flight
   const int tid = threadIdx.x;
@@ -881,10 +975,21 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
     for (int k = 0; k < U; ++k) {
       const int it = it0 + k * THREADS;
       vx[k] = -1.f;
+      vy[k] = -1.f;
       if (it < nitems) {
-        const long idx = img_base + (long)list[it / PP] * roi_stride + it % PP;
-        vx[k] = a.ax[idx];
-        vy[k] = a.ay[idx];
+        const int r = list[it / PP], bin = it % PP;
+        const long idx = img_base + (long)r * roi_stride + bin;
+        if (PK) {
+          const int code = a.amax8[idx];
+          if (code != 255) {
+            const float* ct = a.coords + ((long)img * a.R + r) * (3 * (PH + PW));
+            vy[k] = ct[(bin / PW) * 3 + code / 3];
+            vx[k] = ct[3 * PH + (bin % PW) * 3 + code % 3];
+          }
+        } else {
+          vx[k] = a.ax[idx];
+          vy[k] = a.ay[idx];
+        }
         vg[k] = a.dy[idx];
       }
     }
@@ -973,13 +1078,18 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
   if (total >= (1L << 31)) return SD_ERR_UNSUPPORTED;
   int threads = tuning("roi_align_bwd_threads", 0);
   if (threads != 256 && threads != 512) threads = 512;
-#define SD_BWDF(PPv, T)                                                                          \
+#define SD_BWDF2(PPv, T, PKv)                                                                    \
   do {                                                                                           \
-    auto k = roi_align_bwd_fused<PPv, T>;                                                        \
+    auto k = roi_align_bwd_fused<PPv, T, PKv>;                                                   \
     if (lds_max > 64 * 1024)                                                                     \
       SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)lds_max));                                           \
     hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(T), lds_max, st, a);                       \
+  } while (0)
+#define SD_BWDF(PPv, T)                                 \
+  do {                                                  \
+    if (a.amax8) SD_BWDF2(PPv, T, true);                \
+    else SD_BWDF2(PPv, T, false);                       \
   } while (0)
   if (a.PP == 49) {
     if (threads == 256) SD_BWDF(49, 256); else SD_BWDF(49, 512);
@@ -987,6 +1097,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
     if (threads == 256) SD_BWDF(196, 256); else SD_BWDF(196, 512);
   }
 #undef SD_BWDF
+#undef SD_BWDF2
   SD_LAUNCH_CHECK();
   return SD_OK;
 }
@@ -1136,25 +1247,31 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   for (int l = 0; l < a.L.nlvl; ++l)
     if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
   const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
-  const int depth = tuning("roi_align_fwd_depth", 1);  // channels in flight per wave
   if (variant == 1 && wide && a.PH == 7 && a.PW == 7) {
-#define SD_FWD77(NROI, D)                                                                       \
-  hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, D>), dim3(cdiv(nroi, NROI) * a.nslice),   \
-                     dim3(512), 0, st, a)
-    if (rpw >= 4) {
-      if (depth >= 4) SD_FWD77(4, 4); else if (depth >= 2) SD_FWD77(4, 2); else SD_FWD77(4, 1);
-    } else if (rpw >= 2) {
-      if (depth >= 4) SD_FWD77(2, 4); else if (depth >= 2) SD_FWD77(2, 2); else SD_FWD77(2, 1);
-    } else {
-      if (depth >= 4) SD_FWD77(1, 4); else if (depth >= 2) SD_FWD77(1, 2); else SD_FWD77(1, 1);
-    }
+#define SD_FWD77(NROI)                                                                           \
+  do {                                                                                           \
+    if (a.amax8)                                                                                 \
+      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, true>),                                \
+                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), 0, st, a);                \
+    else                                                                                         \
+      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, false>),                               \
+                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), 0, st, a);                \
+  } while (0)
+    if (rpw >= 4) SD_FWD77(4); else if (rpw >= 2) SD_FWD77(2); else SD_FWD77(1);
 #undef SD_FWD77
   } else if (variant == 1 && wide && a.PH == 14 && a.PW == 14) {
-    hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1, 1>), dim3(nroi * a.nslice), dim3(512), 0, st,
-                       a);
+    if (a.amax8)
+      hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1, true>), dim3(nroi * a.nslice), dim3(512), 0,
+                         st, a);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1, false>), dim3(nroi * a.nslice), dim3(512),
+                         0, st, a);
   } else {
     const int grid = (int)((count + 255) / 256 < 65536 * 16 ? (count + 255) / 256 : 65536 * 16);
     hipLaunchKernelGGL(roi_align_fwd_naive, dim3(grid), dim3(256), 0, st, a);
+    if (a.amax8)  // the tiled kernels write the coordinate table themselves
+      hipLaunchKernelGGL(roi_coords_kernel, dim3(nroi), dim3(64), 0, st, a.rois, nroi, a.L, a.PH,
+                         a.PW, a.coords);
   }
   SD_LAUNCH_CHECK();
   return SD_OK;
@@ -1335,6 +1452,69 @@ extern "C" int sd_fpn_roi_align_fwd(const float* const* feats_host, const int* H
   a.rois = rois; a.out = out; a.ax = maxidx_x; a.ay = maxidx_y;
   a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
   return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_host,
+                                           const int* Ws_host, const int* strides_host, int nlvl,
+                                           const float* rois, float* out, uint8_t* argmax,
+                                           float* coords, int B, int C, int R, int pooled_h,
+                                           int pooled_w,
+                                           float roi_canonical_scale, float roi_canonical_level,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
+  SD_REQUIRE(feats_host && Hs_host && Ws_host && strides_host, "null level description");
+  SD_REQUIRE((argmax && coords) || (long)B * R * C == 0, "argmax / coords is null");
+  FwdArgs a{};
+  if (int e = fill_levels(a.L, feats_host, Hs_host, Ws_host, strides_host, nlvl,
+                          roi_canonical_scale, roi_canonical_level))
+    return e;
+  for (int l = 0; l < nlvl; ++l) SD_REQUIRE(feats_host[l] || (long)B * C == 0, "feats[%d] null", l);
+  if (nlvl == 1) a.L.nlvl = 2, a.L.stride[1] = -1;
+  a.rois = rois; a.out = out; a.amax8 = argmax; a.coords = coords;
+  a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
+  return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois,
+                                           const uint8_t* argmax, const float* coords,
+                                           float* const* d_feats_host,
+                                           const int* Hs_host, const int* Ws_host,
+                                           const int* strides_host, int nlvl, int req_data, int B,
+                                           int C, int R, int pooled_h, int pooled_w,
+                                           float roi_canonical_scale, float roi_canonical_level,
+                                           void* stream) {
+  if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
+  SD_REQUIRE(d_feats_host && Hs_host && Ws_host && strides_host, "null level description");
+  SD_REQUIRE(req_data == SD_REQ_NULL || req_data == SD_REQ_WRITE || req_data == SD_REQ_ADD,
+             "ROIAlign: Backward doesn't support req_data=%d (kWriteInplace)", req_data);
+  if (req_data == SD_REQ_NULL) return SD_OK;
+  const int PPv = pooled_h * pooled_w;
+  SD_REQUIRE((pooled_h == 7 && pooled_w == 7) || (pooled_h == 14 && pooled_w == 14),
+             "packed arg-max backward supports 7x7 and 14x14 pooling only");
+  SD_REQUIRE(R <= 8192, "packed arg-max backward: R=%d > 8192", R);
+  BwdFusedArgs f{};
+  if (int e = fill_levels(f.L, nullptr, Hs_host, Ws_host, strides_host, nlvl, roi_canonical_scale,
+                          roi_canonical_level))
+    return e;
+  if (nlvl == 1) f.L.nlvl = 2, f.L.stride[1] = -1;
+  f.dy = out_grad; f.amax8 = argmax; f.coords = coords; f.rois = rois;
+  for (int l = 0; l < nlvl; ++l) {
+    SD_REQUIRE(d_feats_host[l] || (long)B * C == 0, "d_feats[%d] null", l);
+    f.dx[l] = d_feats_host[l];
+  }
+  f.B = B; f.C = C; f.R = R; f.PP = PPv; f.filter = 1; f.req = req_data;
+  if ((long)B * R * C == 0) {
+    for (int l = 0; l < nlvl; ++l)
+      if (req_data == SD_REQ_WRITE && d_feats_host[l])
+        SD_HIP_CHECK(hipMemsetAsync(d_feats_host[l], 0,
+                                    sizeof(float) * (size_t)B * C * Hs_host[l] * Ws_host[l],
+                                    (hipStream_t)stream));
+    return SD_OK;
+  }
+  SD_REQUIRE(out_grad && rois && argmax && coords, "null tensor pointer");
+  const int e = launch_bwd_fused(f, nlvl, (hipStream_t)stream);
+  if (e == SD_ERR_UNSUPPORTED) return fail(e, "packed arg-max backward: a level does not fit LDS");
+  return e;
 }
 
 extern "C" size_t sd_fpn_roi_align_workspace_bytes(int B, int R) {

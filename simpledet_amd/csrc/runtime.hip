@@ -30,7 +30,6 @@ Knob g_knobs[] = {
     {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default)
     {"roi_align_fwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
     {"roi_align_fwd_order", 0, false},   // 1: locality order of the RoIs (-25% L2-miss reads, same time; default 0)
-    {"roi_align_fwd_depth", 0, false},   // channels in flight per wave (1, 2 or 4; default 1: more in flight was measured slower)
     {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)
     {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
     {"roi_align_bwd", 0, false},         // 0 global atomics, 1 per-level LDS planes, 2 fused (default)

@@ -156,6 +156,62 @@ def fpn_roi_align_forward(feats, rois, rcnn_stride, pooled_size, roi_canonical_s
     return out, mx, my
 
 
+def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_canonical_scale=224,
+                                 roi_canonical_level=4):
+    """The fused extractor with a one-byte arg-max: -> out (B,R,C,ph,pw) fp32, argmax (B,R,C,ph,pw)
+    uint8 (row sample * 3 + column sample, 255 = nothing pooled), coords (B,R,2,3*ph... ) fp32
+    sample-coordinate table.  (argmax, coords) are state between this op's forward and backward
+    only; fpn_roi_align_backward_packed decodes them."""
+    _chk(rois, "rois", ndim=3)
+    if len(feats) != len(rcnn_stride):
+        raise ValueError("one feature map per stride expected")
+    B, C = feats[0].shape[:2]
+    for i, f in enumerate(feats):
+        _chk(f, "feats[%d]" % i, ndim=4)
+        if tuple(f.shape[:2]) != (B, C):
+            raise ValueError("all levels must share (B,C)")
+    if rois.shape[0] != B:
+        raise ValueError("rois batch mismatch")
+    ph, pw = _pair(pooled_size)
+    R = rois.shape[1]
+    shape = (B, R, C, ph, pw)
+    out = torch.empty(shape, device=rois.device, dtype=torch.float32)
+    amax = torch.empty(shape, device=rois.device, dtype=torch.uint8)
+    coords = torch.empty((B, R, 3 * (ph + pw)), device=rois.device, dtype=torch.float32)
+    wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, R)
+    ws = torch.empty(wsb, device=rois.device, dtype=torch.uint8)
+    lib().call("sd_fpn_roi_align_fwd_packed", _parr(feats), _iarr([f.shape[2] for f in feats]),
+               _iarr([f.shape[3] for f in feats]), _iarr(rcnn_stride), len(feats), _p(rois),
+               _p(out), _p(amax), _p(coords), B, C, R, ph, pw, float(roi_canonical_scale),
+               float(roi_canonical_level), _p(ws), ctypes.c_size_t(wsb), _stream())
+    return out, (amax, coords)
+
+
+def fpn_roi_align_backward_packed(out_grad, rois, argmax, feat_shapes, rcnn_stride,
+                                  roi_canonical_scale=224, roi_canonical_level=4, req_data="write",
+                                  d_feats=None):
+    _chk(out_grad, "out_grad", ndim=5)
+    _chk(rois, "rois", ndim=3)
+    argmax, coords = argmax
+    _chk(argmax, "argmax", dtype=torch.uint8, ndim=5)
+    _chk(coords, "coords", ndim=3)
+    B, R, C, ph, pw = out_grad.shape
+    rd = REQ[req_data] if isinstance(req_data, str) else int(req_data)
+    if d_feats is None:
+        if rd == REQ["add"]:
+            raise ValueError("req_data='add' needs d_feats")
+        d_feats = [torch.empty(tuple(s), device=out_grad.device, dtype=torch.float32)
+                   for s in feat_shapes]
+    for i, f in enumerate(d_feats):
+        _chk(f, "d_feats[%d]" % i, ndim=4)
+    lib().call("sd_fpn_roi_align_bwd_packed", _p(out_grad), _p(rois), _p(argmax), _p(coords),
+               _parr(d_feats),
+               _iarr([f.shape[2] for f in d_feats]), _iarr([f.shape[3] for f in d_feats]),
+               _iarr(rcnn_stride), len(d_feats), rd, B, C, R, ph, pw, float(roi_canonical_scale),
+               float(roi_canonical_level), _stream())
+    return d_feats
+
+
 def fpn_roi_align_backward(out_grad, rois, maxidx_x, maxidx_y, feat_shapes, rcnn_stride,
                            roi_canonical_scale=224, roi_canonical_level=4, req_data="write",
                            d_feats=None):

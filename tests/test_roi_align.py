@@ -298,3 +298,121 @@ def test_fpn_full_size_baseline_config(ops, oracle):
     finally:
         lib().set_tuning("roi_align_fwd", 1)
         lib().set_tuning("roi_align_bwd", 2)
+
+
+# ------------------------------------------------------------------- packed (one-byte) arg-max --
+def _decode_packed(am, rois, feats_shapes, strides, level):
+    """numpy float32 restatement of the device decode (sample_coord): (ax, ay) from (k, l)."""
+    f = np.float32
+    B, R, C, PH, PW = am.shape
+    ax = -np.ones(am.shape, f)
+    ay = -np.ones(am.shape, f)
+    for b in range(B):
+        for r in range(R):
+            lv = level[b, r]
+            if lv < 0:
+                continue
+            H, W = feats_shapes[lv][2], feats_shapes[lv][3]
+            scale = f(1.0) / f(strides[lv])
+            x1, y1, x2, y2 = [f(v) for v in rois[b, r]]
+
+            def coord(p, pooled, s, e, size, k):
+                rs, re = f(s * scale), f(e * scale)
+                bn = f(f(re - rs) / f(pooled))
+                lo = f(min(max(f(f(p) * bn) + rs, f(0)), f(size - 1)))
+                hi = f(min(max(f(f(p + 1) * bn) + rs, f(0)), f(size - 1)))
+                st = f(f(hi - lo) / f(3.0))
+                step = f(max(st, f(0.01)))
+                v = f(lo + st)
+                for _ in range(k):
+                    v = f(v + step)
+                return v
+            code = am[b, r]
+            for p in range(PH):
+                for q in range(PW):
+                    cc = code[:, p, q]
+                    for cv in np.unique(cc):
+                        if cv == 255:
+                            continue
+                        m = cc == cv
+                        ay[b, r, m, p, q] = coord(p, PH, y1, y2, H, int(cv) // 3)
+                        ax[b, r, m, p, q] = coord(q, PW, x1, x2, W, int(cv) % 3)
+    return ax, ay
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 0])
+def test_fpn_packed_argmax_forward_backward(ops, oracle, variant):
+    import torch
+    from simpledet_amd._lib import lib
+    feats = synth.feature_maps(5, batch=2, channels=16)
+    rois = synth.random_rois(5, 2, 96)
+    want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (7, 7))
+    _, level = oracle.fpn_roi_assign(rois, STRIDES)
+    tf = [_t(f) for f in feats]
+    lib().set_tuning("roi_align_fwd", variant)
+    try:
+        out, am = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, (7, 7))
+    finally:
+        lib().set_tuning("roi_align_fwd", 1)
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+    amn, con = am[0].cpu().numpy(), am[1].cpu().numpy()
+    np.testing.assert_array_equal(amn == 255, want[1] == -1)
+    dax, day = _decode_packed(amn, rois, [f.shape for f in feats], STRIDES, level)
+    np.testing.assert_array_equal(dax, want[1])  # decoded coordinates are the forward's floats
+    np.testing.assert_array_equal(day, want[2])
+    # ... and so is the device's coordinate table, entry by entry where a code points into it
+    B, R = rois.shape[:2]
+    pp, qq = np.meshgrid(np.arange(7), np.arange(7), indexing="ij")
+    code = amn.astype(np.int64)
+    ok = code != 255
+    ty = np.take_along_axis(con[:, :, None, None, None, :21].repeat(16, 2).repeat(7, 3).repeat(7, 4),
+                            np.where(ok, pp[None, None, None] * 3 + code // 3, 0)[..., None], -1)[..., 0]
+    tx = np.take_along_axis(con[:, :, None, None, None, 21:].repeat(16, 2).repeat(7, 3).repeat(7, 4),
+                            np.where(ok, qq[None, None, None] * 3 + code % 3, 0)[..., None], -1)[..., 0]
+    np.testing.assert_array_equal(np.where(ok, ty, -1), want[2])
+    np.testing.assert_array_equal(np.where(ok, tx, -1), want[1])
+    dy = np.random.RandomState(6).standard_normal(want[0].shape).astype(np.float32)
+    wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], [f.shape for f in feats], STRIDES)
+    gd = ops.fpn_roi_align_backward_packed(_t(dy), _t(rois), am, [f.shape for f in feats], STRIDES)
+    for g, w in zip(gd, wd):
+        _assert_bwd_close(g.cpu().numpy(), w)
+    # kAddTo
+    acc = [torch.ones_like(g) for g in gd]
+    ops.fpn_roi_align_backward_packed(_t(dy), _t(rois), am, [f.shape for f in feats], STRIDES,
+                                      req_data="add", d_feats=acc)
+    for g, w in zip(acc, wd):
+        _assert_bwd_close(g.cpu().numpy(), w + 1)
+
+
+@pytest.mark.gpu
+def test_fpn_packed_equals_float_argmax_path_full_size(ops):
+    """Baseline shapes: the packed path and the float arg-max path give the same output and the
+    same gradients (size-independent cross-check, no oracle needed)."""
+    import torch
+    feats = [_t(f) for f in synth.feature_maps(1, batch=2, channels=64)]
+    rois = _t(synth.random_rois(1, 2, 512))
+    o1, mx, my = ops.fpn_roi_align_forward(feats, rois, STRIDES, (7, 7))
+    o2, am = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, (7, 7))
+    assert torch.equal(o1, o2)
+    assert torch.equal(am[0] == 255, mx == -1)
+    dy = torch.randn_like(o1)
+    shapes = [f.shape for f in feats]
+    g1 = ops.fpn_roi_align_backward(dy, rois, mx, my, shapes, STRIDES)
+    g2 = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
+    for a, b in zip(g1, g2):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.gpu
+def test_contrib_fpn_roi_align_autograd(ops):
+    import torch
+    from simpledet_amd import contrib
+    feats = [_t(f).requires_grad_(True) for f in synth.feature_maps(2, batch=1, channels=8)]
+    rois = _t(synth.random_rois(2, 1, 64))
+    out = contrib.fpn_roi_align(feats, rois, STRIDES, (7, 7))
+    out.sum().backward()
+    o2, mx, my = ops.fpn_roi_align_forward([f.detach() for f in feats], rois, STRIDES, (7, 7))
+    g = ops.fpn_roi_align_backward(torch.ones_like(o2), rois, mx, my, [f.shape for f in feats], STRIDES)
+    for f, w in zip(feats, g):
+        assert float((f.grad - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max()))
