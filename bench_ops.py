@@ -80,6 +80,25 @@ def run(seed=0, cpu=True):
     if orc:
         res["nms"]["cpu_ms"] = _time_cpu(lambda: orc.nms(dets, 2000, 1000, 0.7))
 
+    # ---- Proposal_v3 over the five FPN levels + get_top_proposal ----
+    lv = [synth.rpn_outputs(seed + i, 2, 3, h, w, st) for i, ((h, w), st) in
+          enumerate(zip(list(synth.FPN_SHAPES) + [(13, 21)], [4, 8, 16, 32, 64]))]
+    tl = [(T(c), T(b), T(i)) for c, b, i in lv]
+
+    def rpn_proposals():
+        outs = [ops.proposal_v3(c, b, i, 2000, 2000, 0.7, 0, (8,), (0.5, 1, 2), st)
+                for (c, b, i), st in zip(tl, [4, 8, 16, 32, 64])]
+        return ops.get_top_proposal(torch.cat([o[0] for o in outs], 1),
+                                    torch.cat([o[1] for o in outs], 1), 2000)
+    ms = _time_gpu(rpn_proposals, iters=10, warm=2)
+    res["proposal_v3_fpn"] = {"ms": ms, "images_per_s": 2 / ms * 1e3,
+                              "config": "B=2, P2-P6, 267k anchors/img, pre/post 2000 per level + top 2000"}
+    if orc:
+        c, b, i = lv[2]
+        t = _time_cpu(lambda: orc.proposal_v3(c, b, i, 2000, 2000, 0.7, 0, (8,), (0.5, 1, 2), 16),
+                      min_s=0.3, max_iter=5)
+        res["proposal_v3_fpn"]["cpu_ms_p4_level_only"] = t
+
     # ---- batched soft-NMS: 16 images x 80 classes x 1000 boxes (BASELINE configs[2]) ----
     P, n = 16 * 80, 1000
     base = np.stack([synth.nms_dets(seed + 100 + i, n) for i in range(16)])

@@ -252,6 +252,28 @@ int sd_deform_conv_bwd(const float* out_grad, const float* x, const float* offse
                        int F, int kh, int kw, int pad, int stride, int dil, int dgroup,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * _contrib_Proposal_v3  (mx.sym.contrib.Proposal_v3, models/FPN/builder.py:275-287) -- SURVEY 8(f)
+ *   replaces ProposalGPUOp_v3::Forward  operator_cxx/contrib/proposal_v3.cu:428-638 (anchor grid
+ *   :64-85, box decode :92-155, top-k by thrust sort, min-size filter :211-235, NMS with >= and its
+ *   host scan :271-381, PrepareOutput :386-416; three D2H/H2D copies per image)
+ *   cls_prob (B,2A,H,W) (foreground = second half)  bbox_pred (B,4A,H,W)  im_info (B,3) DEVICE
+ *   out (B,post,4)  score (B,post): post = is_train ? min(post_nms_top_n, pre) : post_nms_top_n;
+ *   padding past the kept boxes: zeros (test) or the kept boxes repeated cyclically (is_train).
+ *   iou_loss=true is not supported (no reference config uses it).
+ * ---------------------------------------------------------------------------------------------- */
+size_t sd_proposal_v3_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n);
+int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info, float* out,
+                   float* score, int B, int A, int H, int W, int rpn_pre_nms_top_n,
+                   int rpn_post_nms_top_n, float threshold, int rpn_min_size,
+                   const float* scales_host, int n_scales, const float* ratios_host, int n_ratios,
+                   int feature_stride, int is_train, void* workspace, size_t workspace_bytes,
+                   void* stream);
+/* get_top_proposal CustomOp (models/FPN/get_top_proposal.py:15-39): the top_n rows of bbox (B,N,4)
+ * by score (B,N) descending (ties: lower row first), zero padded when N < top_n */
+int sd_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,
+                        float* out_bbox, float* out_score, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

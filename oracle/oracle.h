@@ -92,6 +92,18 @@ void orc_nms(const float* dets, int B, int N, int pre_nms_top_n, int post_nms_to
              float threshold, int already_sorted, float* out, float* score,
              int* keep_out /* B*post, original indices, -1 pad; may be NULL */);
 
+/* ---- _contrib_Proposal_v3 (GPU path): contrib/proposal_v3.cu:64-235,271-416,428-638 ---- */
+void orc_proposal_v3_anchors(int feature_stride, const float* scales, int ns, const float* ratios,
+                             int nr, float* anchors);
+int orc_proposal_v3_post(int count, int pre_nms_top_n, int post_nms_top_n, int is_train);
+void orc_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info, int B,
+                     int A, int H, int W, int pre_nms_top_n, int post_nms_top_n, float threshold,
+                     int min_size, const float* scales, int ns, const float* ratios, int nr,
+                     int feature_stride, int is_train, float* out, float* score_out);
+/* models/FPN/get_top_proposal.py:15-39 */
+void orc_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,
+                          float* out_bbox, float* out_score);
+
 /* ---- soft_nms : operator_py/cython/cpu_nms.pyx:98-203 ---- */
 /* boxes (n,5) is updated in place (as the Cython copy is); returns new N; inds (n) out. */
 int orc_soft_nms(float* boxes, int64_t* inds, int n, float sigma, float Nt, float threshold,

@@ -358,3 +358,44 @@ def deform_conv_fwd(x, offset, weight, pad=1, stride=1, dil=1, dgroup=1):
     y = np.empty((N, F, Ho, Wo), np.float32)
     cdll().orc_deform_conv_fwd(px, po, pw, y.ctypes, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup)
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# _contrib_Proposal_v3 (GPU path) and get_top_proposal
+# ------------------------------------------------------------------------------------------------
+def _fa(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def proposal_v3_anchors(stride, scales, ratios):
+    out = np.empty((len(scales) * len(ratios), 4), np.float32)
+    cdll().orc_proposal_v3_anchors(int(stride), _fa(scales), len(scales), _fa(ratios), len(ratios),
+                                   out.ctypes)
+    return out
+
+
+def proposal_v3(cls_prob, bbox_pred, im_info, pre, post, threshold, min_size, scales, ratios,
+                stride, is_train=False):
+    cls_prob, pc = _f(cls_prob)
+    bbox_pred, pb = _f(bbox_pred)
+    im_info, pi = _f(im_info)
+    B, A2, H, W = cls_prob.shape
+    A = A2 // 2
+    cdll().orc_proposal_v3_post.restype = ctypes.c_int
+    peff = cdll().orc_proposal_v3_post(A * H * W, int(pre), int(post), int(is_train))
+    out = np.empty((B, peff, 4), np.float32)
+    score = np.empty((B, peff, 1), np.float32)
+    cdll().orc_proposal_v3(pc, pb, pi, B, A, H, W, int(pre), int(post), ctypes.c_float(threshold),
+                           int(min_size), _fa(scales), len(scales), _fa(ratios), len(ratios),
+                           int(stride), int(is_train), out.ctypes, score.ctypes)
+    return out, score
+
+
+def get_top_proposal(bbox, score, top_n):
+    bbox, pb = _f(bbox)
+    score, ps = _f(score)
+    B, N = bbox.shape[:2]
+    ob = np.empty((B, top_n, 4), np.float32)
+    os_ = np.empty((B, top_n, 1), np.float32)
+    cdll().orc_get_top_proposal(pb, ps, B, N, int(top_n), ob.ctypes, os_.ctypes)
+    return ob, os_

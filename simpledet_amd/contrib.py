@@ -156,3 +156,22 @@ def NMS(rois, rpn_pre_nms_top_n=6000, rpn_post_nms_top_n=300, threshold=0.7, out
     with torch.no_grad():
         out, score = ops.nms(rois, rpn_pre_nms_top_n, rpn_post_nms_top_n, threshold, already_sorted)
     return (out, score) if output_score else out
+
+
+def Proposal_v3(cls_prob, bbox_pred, im_info, rpn_pre_nms_top_n=6000, rpn_post_nms_top_n=300,
+                threshold=0.7, rpn_min_size=16, scales=(4., 8., 16., 32.), ratios=(0.5, 1., 2.),
+                feature_stride=16, output_score=False, iou_loss=False, is_train=False):
+    """mx.sym.contrib.Proposal_v3 as models/FPN/builder.py:275-287 calls it."""
+    if iou_loss:
+        raise ValueError("Proposal_v3: iou_loss=True is not supported")
+    with torch.no_grad():
+        out, score = ops.proposal_v3(cls_prob, bbox_pred, im_info, rpn_pre_nms_top_n,
+                                     rpn_post_nms_top_n, threshold, rpn_min_size, scales, ratios,
+                                     feature_stride, is_train)
+    return (out, score) if output_score else out
+
+
+def get_top_proposal(bbox, score, top_n):
+    """mxnext.tvm.get_top_proposal / models/FPN/get_top_proposal.py."""
+    with torch.no_grad():
+        return ops.get_top_proposal(bbox, score, top_n)

@@ -20,6 +20,7 @@
 // No host round trip, no device synchronisation, one stream.
 #include "common.h"
 #include "../../include/simpledet_ops.h"
+#include <math.h>
 
 namespace sd {
 
@@ -29,6 +30,26 @@ __device__ __forceinline__ unsigned ordered_desc_bits(float f) {
   unsigned u = __float_as_uint(f);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-order-preserving map
   return ~u;                                        // descending
+}
+
+// ascending bitonic sort of P2 (power of two) 64-bit keys in LDS by the whole workgroup
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int P2, int tid, int T) {
+  for (int k = 2; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < P2 / 2; t += T) {
+        // pair (lo, lo + j) of the bitonic network; direction from bit k of lo
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo + j;
+        const unsigned long long x = keys[lo], y = keys[hi];
+        const bool up = (lo & k) == 0;
+        if ((x > y) == up) {
+          keys[lo] = y;
+          keys[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
 }
 
 struct NmsWs {
@@ -55,22 +76,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(SortArgs a) {
       keys[i] = k;
     }
     __syncthreads();
-    for (int k = 2; k <= a.P2; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < a.P2 / 2; t += T) {
-          // pair (lo, lo + j) of the bitonic network; direction from bit k of lo
-          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int hi = lo + j;
-          const unsigned long long x = keys[lo], y = keys[hi];
-          const bool up = (lo & k) == 0;
-          if ((x > y) == up) {
-            keys[lo] = y;
-            keys[hi] = x;
-          }
-        }
-        __syncthreads();
-      }
-    }
+    bitonic_sort_lds(keys, a.P2, tid, T);
   }
   for (int i = tid; i < a.pre; i += T) {
     const int src = a.already_sorted ? i : (int)(unsigned)(keys[i] & 0xffffffffu);
@@ -147,6 +153,8 @@ struct ScanArgs {
   float* score;
   int* keep_index;
   int pre, post, nb;
+  int pad_cyclic;  // 0: zero padding (nms.cu:224-230); 1: repeat the kept boxes (proposal_v3.cu
+                   // PrepareOutput with is_train)
 };
 
 // Greedy scan, one wave per image, no barrier and no host: lane = box of the current 64-box
@@ -201,10 +209,178 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(ScanArgs a) {
     nkeep += __popcll(keepmask);
   }
   if (nkeep > a.post) nkeep = a.post;
+  __threadfence_block();  // the kept rows written above are read back below (same wave)
   for (int i = nkeep + lane; i < a.post; i += kWave) {
-    reinterpret_cast<float4*>(out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    score[i] = 0.f;
-    if (keep_index) keep_index[i] = -1;
+    if (a.pad_cyclic && nkeep > 0) {
+      const int src = i % nkeep;
+      reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(out)[src];
+      score[i] = score[src];
+      if (keep_index) keep_index[i] = keep_index[src];
+    } else {
+      reinterpret_cast<float4*>(out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      score[i] = 0.f;
+      if (keep_index) keep_index[i] = -1;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// _contrib_Proposal_v3: anchors -> decode -> top-k -> min-size filter -> NMS (>=) -> padded output
+//   reference: operator_cxx/contrib/proposal_v3.cu:64-235 (grid, decode, filter kernels), :428-638
+//   (Forward: per image thrust sort of ALL anchors, 3 D2H/H2D copies and a host NMS scan).
+// Here: one decode launch for the batch, one workgroup per image that SELECTS the top
+// pre_nms_top_n scores with an 8-bit radix select over the score keys (4 passes over L2-resident
+// keys, no full sort of the 10^5 anchors), bitonic-sorts only the selected <= 16384 keys in LDS,
+// applies the min-size filter, then the NMS mask / scan kernels above.  im_info stays on the device.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxAnchors = 64;
+
+struct PropArgs {
+  const float* cls_prob;   // (B, 2A, H, W)
+  const float* bbox_pred;  // (B, 4A, H, W)
+  const float* im_info;    // (B, 3)
+  float4* boxes_all;       // (B, count)
+  float* score_all;        // (B, count)
+  NmsWs ws;
+  float anchors[kMaxAnchors * 4];
+  int A, H, W, stride, count, pre, P2;
+  float min_size;
+};
+
+__global__ __launch_bounds__(256) void proposal_decode_kernel(PropArgs a) {
+  const int img = blockIdx.y;
+  const int index = blockIdx.x * blockDim.x + threadIdx.x;
+  if (index >= a.count) return;
+  const int an = index % a.A, w = (index / a.A) % a.W, h = index / a.A / a.W;
+  const float im_height = a.im_info[img * 3 + 0], im_width = a.im_info[img * 3 + 1];
+  const long plane = (long)a.H * a.W;
+  const float* fg = a.cls_prob + ((long)img * 2 * a.A + a.A) * plane;
+  const float* deltas = a.bbox_pred + (long)img * 4 * a.A * plane;
+  const long hw = (long)h * a.W + w;
+  // ProposalGridKernel (proposal_v3.cu:64-85)
+  const float x1 = a.anchors[an * 4 + 0] + (float)(w * a.stride);
+  const float y1 = a.anchors[an * 4 + 1] + (float)(h * a.stride);
+  const float x2 = a.anchors[an * 4 + 2] + (float)(w * a.stride);
+  const float y2 = a.anchors[an * 4 + 3] + (float)(h * a.stride);
+  // BBoxPredKernel (:92-155)
+  const float width = x2 - x1 + 1.0f, height = y2 - y1 + 1.0f;
+  const float ctr_x = x1 + 0.5f * width, ctr_y = y1 + 0.5f * height;
+  const float dx = deltas[(long)(an * 4) * plane + hw];
+  const float dy = deltas[(long)(an * 4 + 1) * plane + hw];
+  float dw = deltas[(long)(an * 4 + 2) * plane + hw];
+  float dh = deltas[(long)(an * 4 + 3) * plane + hw];
+  dw = (float)((double)dw < 4.135166556742356 ? (double)dw : 4.135166556742356);
+  dh = (float)((double)dh < 4.135166556742356 ? (double)dh : 4.135166556742356);
+  const float pred_ctr_x = dx * width + ctr_x, pred_ctr_y = dy * height + ctr_y;
+  const float pred_w = (float)exp((double)dw) * width, pred_h = (float)exp((double)dh) * height;
+  float4 o;
+  o.x = fmaxr(fminr(pred_ctr_x - 0.5f * pred_w, im_width - 1.0f), 0.0f);
+  o.y = fmaxr(fminr(pred_ctr_y - 0.5f * pred_h, im_height - 1.0f), 0.0f);
+  o.z = fmaxr(fminr(pred_ctr_x + 0.5f * pred_w - 1.0f, im_width - 1.0f), 0.0f);
+  o.w = fmaxr(fminr(pred_ctr_y + 0.5f * pred_h - 1.0f, im_height - 1.0f), 0.0f);
+  a.boxes_all[(long)img * a.count + index] = o;
+  a.score_all[(long)img * a.count + index] = fg[(long)an * plane + hw];
+}
+
+// one 8-bit digit of a radix select among the elements whose key matches `prefix` under `mask`:
+// returns the digit where the running count reaches `want` (1-based rank inside the matching set)
+// and updates below (elements before that digit) -- all threads get the same values
+template <typename KeyFn>
+__device__ __forceinline__ int radix_digit(int count, int shift, unsigned mask, unsigned prefix,
+                                           int want, int* hist, int* below, KeyFn key_of) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  for (int i = tid; i < 256; i += T) hist[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < count; i += T) {
+    const unsigned k = key_of(i);
+    if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+  }
+  __syncthreads();
+  int run = 0, digit = 255, lower = 0;
+  for (int d = 0; d < 256; ++d) {  // every thread scans the same 256 counters (LDS broadcast)
+    const int c = hist[d];
+    if (run + c >= want) {
+      digit = d;
+      lower = run;
+      break;
+    }
+    run += c;
+  }
+  *below = lower;
+  __syncthreads();
+  return digit;
+}
+
+__global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // P2 composite keys
+  __shared__ int hist[256];
+  __shared__ int ncand;
+  const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const float* sc = a.score_all + (long)img * a.count;
+  const float4* bx = a.boxes_all + (long)img * a.count;
+  auto skey = [&](int i) { return ordered_desc_bits(sc[i]); };  // ascending key = best score first
+  // ---- the pre-th smallest score key ----
+  unsigned prefix = 0, mask = 0;
+  int want = a.pre;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    int below;
+    const int d = radix_digit(a.count, shift, mask, prefix, want, hist, &below, skey);
+    want -= below;
+    prefix |= (unsigned)d << shift;
+    mask |= 255u << shift;
+  }
+  const unsigned Tkey = prefix;  // `want` of the elements with this key are still needed
+  // ---- ties on the score: the lowest rows win (stable sort); select the want-th smallest row ----
+  unsigned ipre = 0, imask = 0;
+  int iwant = want;
+  auto ikey = [&](int i) { return skey(i) == Tkey ? (unsigned)i : 0xffffffffu; };
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    int below;
+    // rows that do not carry Tkey map to 0xffffffff and never match a prefix below 2^24 rows ...
+    const int d = radix_digit(a.count, shift, imask, ipre, iwant, hist, &below, ikey);
+    iwant -= below;
+    ipre |= (unsigned)d << shift;
+    imask |= 255u << shift;
+  }
+  const unsigned Irow = ipre;  // ties with row <= Irow are taken
+  // ---- unordered compaction of the selected rows into composite keys, then sort ----
+  if (tid == 0) ncand = 0;
+  for (int i = tid; i < a.P2; i += T) keys[i] = ~0ull;
+  __syncthreads();
+  for (int i = tid; i < a.count; i += T) {
+    const unsigned k = skey(i);
+    if (k < Tkey || (k == Tkey && (unsigned)i <= Irow)) {
+      const int pos = atomicAdd(&ncand, 1);
+      if (pos < a.P2) keys[pos] = ((unsigned long long)k << 32) | (unsigned)i;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_lds(keys, a.P2, tid, T);
+  // ---- gather + FilterBoxKernel (proposal_v3.cu:211-235) ----
+  const float im_h = a.im_info[img * 3 + 0], im_w = a.im_info[img * 3 + 1];
+  const float scale = a.im_info[img * 3 + 2];
+  for (int i = tid; i < a.pre; i += T) {
+    const int src = (int)(unsigned)(keys[i] & 0xffffffffu);
+    float4 d = bx[src];
+    float s = sc[src];
+    const float ws_orig_scale = (d.z - d.x) / scale + 1.0f;
+    const float hs_orig_scale = (d.w - d.y) / scale + 1.0f;
+    const float min_size_max = fmaxr(a.min_size, 1.0f);
+    const float ws = d.z - d.x + 1.0f, hs = d.w - d.y + 1.0f;
+    const float x_ctr = d.x + ws / 2.0f, y_ctr = d.y + hs / 2.0f;
+    if (ws_orig_scale < min_size_max || hs_orig_scale < min_size_max || x_ctr >= im_w ||
+        y_ctr >= im_h) {
+      d.x -= min_size_max / 2;
+      d.y -= min_size_max / 2;
+      d.z += min_size_max / 2;
+      d.w += min_size_max / 2;
+      s = -1.0f;
+    }
+    const long o = (long)img * a.pre + i;
+    a.ws.order[o] = src;
+    a.ws.boxes[o] = d;
+    a.ws.score[o] = s;
   }
 }
 
@@ -286,8 +462,156 @@ extern "C" int sd_nms(const float* dets, int B, int N, int pre_nms_top_n, int po
   hipLaunchKernelGGL(nms_mask_kernel, dim3((ma.npairs + 3) / 4, B), dim3(256), 0, st, ma);
   SD_LAUNCH_CHECK();
 
-  ScanArgs ca{ws, out, score, keep_index, pre, post, nb};
+  ScanArgs ca{ws, out, score, keep_index, pre, post, nb, 0};
   hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, ca);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+// proposal_v3-inl.h:279-318 (float math, floor(size / ratio))
+static void proposal_v3_anchors(int feature_stride, const float* scales, int ns, const float* ratios,
+                                int nr, float* anchors) {
+  const float base[4] = {0.0f, 0.0f, (float)(feature_stride - 1.0), (float)(feature_stride - 1.0)};
+  int n = 0;
+  for (int j = 0; j < nr; ++j)
+    for (int k = 0; k < ns; ++k) {
+      const float scale = scales[k], ratio = ratios[j];
+      const float w = base[2] - base[0] + 1.0f, h = base[3] - base[1] + 1.0f;
+      const float x_ctr = (float)(base[0] + 0.5 * (w - 1.0f));
+      const float y_ctr = (float)(base[1] + 0.5 * (h - 1.0f));
+      const float size_ratios = floorf((w * h) / ratio);
+      const float new_w = rintf(sqrtf(size_ratios)) * scale;
+      const float new_h = rintf((new_w / scale * ratio)) * scale;
+      anchors[n * 4 + 0] = x_ctr - 0.5f * (new_w - 1.0f);
+      anchors[n * 4 + 1] = y_ctr - 0.5f * (new_h - 1.0f);
+      anchors[n * 4 + 2] = x_ctr + 0.5f * (new_w - 1.0f);
+      anchors[n * 4 + 3] = y_ctr + 0.5f * (new_h - 1.0f);
+      ++n;
+    }
+}
+
+static void proposal_dims(int count, int pre_in, int post_in, int is_train, int* pre, int* post) {
+  int p = pre_in > 0 ? pre_in : count;  // proposal_v3.cu:467-473
+  if (p > count) p = count;
+  *pre = p;
+  *post = post_in < p ? post_in : p;
+  if (!is_train) *post = post_in;
+}
+
+extern "C" size_t sd_proposal_v3_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n) {
+  if (B <= 0 || A <= 0 || H <= 0 || W <= 0) return 256;
+  const long count = (long)A * H * W;
+  int pre, post;
+  proposal_dims((int)count, pre_nms_top_n, 1, 1, &pre, &post);
+  const int nb = (pre + 63) / 64;
+  return nms_layout(B, pre, nb, nullptr, nullptr) + align_up((size_t)B * count * 16, 256) +
+         align_up((size_t)B * count * 4, 256) + 512;
+}
+
+extern "C" int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                              float* out, float* score, int B, int A, int H, int W,
+                              int rpn_pre_nms_top_n, int rpn_post_nms_top_n, float threshold,
+                              int rpn_min_size, const float* scales_host, int n_scales,
+                              const float* ratios_host, int n_ratios, int feature_stride,
+                              int is_train, void* workspace, size_t workspace_bytes, void* stream) {
+  SD_REQUIRE(B >= 0 && A > 0 && H > 0 && W > 0, "bad dimensions");
+  SD_REQUIRE(scales_host && ratios_host && n_scales * n_ratios == A,
+             "num_anchors (%d) != ratios (%d) x scales (%d)", A, n_ratios, n_scales);
+  SD_REQUIRE(A <= kMaxAnchors, "more than %d anchors per location", kMaxAnchors);
+  SD_REQUIRE(feature_stride > 0 && rpn_post_nms_top_n >= 0, "bad stride / post_nms_top_n");
+  const long count_l = (long)A * H * W;
+  SD_REQUIRE(count_l < (1L << 24), "too many anchors per image (%ld)", count_l);
+  const int count = (int)count_l;
+  int pre, post;
+  proposal_dims(count, rpn_pre_nms_top_n, rpn_post_nms_top_n, is_train, &pre, &post);
+  if (B == 0 || post == 0) return SD_OK;
+  SD_REQUIRE(cls_prob && bbox_pred && im_info && out && score, "null tensor pointer");
+  SD_REQUIRE(pre <= kMaxSortKeys, "Proposal: rpn_pre_nms_top_n=%d exceeds %d", pre, kMaxSortKeys);
+  SD_REQUIRE(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
+  const int nb = (pre + 63) / 64;
+  PropArgs a{};
+  char* base = reinterpret_cast<char*>(align_up((size_t)(uintptr_t)workspace, 256));
+  size_t off = nms_layout(B, pre, nb, &a.ws, base);
+  a.boxes_all = reinterpret_cast<float4*>(base + off);
+  off += align_up((size_t)B * count * 16, 256);
+  a.score_all = reinterpret_cast<float*>(base + off);
+  off += align_up((size_t)B * count * 4, 256);
+  const size_t need = off + (size_t)(base - (char*)workspace);
+  if (!workspace || workspace_bytes < need)
+    return fail(SD_ERR_WORKSPACE, "Proposal workspace too small: %zu < %zu bytes", workspace_bytes,
+                need);
+  proposal_v3_anchors(feature_stride, scales_host, n_scales, ratios_host, n_ratios, a.anchors);
+  a.cls_prob = cls_prob; a.bbox_pred = bbox_pred; a.im_info = im_info;
+  a.A = A; a.H = H; a.W = W; a.stride = feature_stride; a.count = count; a.pre = pre;
+  a.min_size = (float)rpn_min_size;
+  int P2 = 64;
+  while (P2 < pre) P2 <<= 1;
+  a.P2 = P2;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(proposal_decode_kernel, dim3((count + 255) / 256, B), dim3(256), 0, st, a);
+  SD_LAUNCH_CHECK();
+  const size_t lds = (size_t)P2 * sizeof(unsigned long long);
+  if (lds > 64 * 1024)
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)proposal_topk_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(proposal_topk_kernel, dim3(B), dim3(1024), lds, st, a);
+  SD_LAUNCH_CHECK();
+  MaskArgs ma{a.ws, pre, nb, nb * (nb + 1) / 2, threshold, 1};  // IoU >= threshold (:319)
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((ma.npairs + 3) / 4, B), dim3(256), 0, st, ma);
+  SD_LAUNCH_CHECK();
+  ScanArgs ca{a.ws, out, score, nullptr, pre, post, nb, is_train ? 1 : 0};
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, ca);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+// get_top_proposal (models/FPN/get_top_proposal.py:15-39): bbox (B,N,4), score (B,N) -> the top_n
+// rows by score (descending, ties keep the lower row), zero padded when N < top_n
+struct TopArgs {
+  const float4* bbox;
+  const float* score;
+  float4* out_bbox;
+  float* out_score;
+  int N, top_n, P2;
+};
+
+__global__ __launch_bounds__(1024) void top_proposal_kernel(TopArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const float* sc = a.score + (long)img * a.N;
+  for (int i = tid; i < a.P2; i += T)
+    keys[i] = i < a.N ? (((unsigned long long)ordered_desc_bits(sc[i]) << 32) | (unsigned)i) : ~0ull;
+  __syncthreads();
+  bitonic_sort_lds(keys, a.P2, tid, T);
+  for (int i = tid; i < a.top_n; i += T) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
+    if (i < a.N) {
+      const int src = (int)(unsigned)(keys[i] & 0xffffffffu);
+      b = a.bbox[(long)img * a.N + src];
+      s = sc[src];
+    }
+    a.out_bbox[(long)img * a.top_n + i] = b;
+    a.out_score[(long)img * a.top_n + i] = s;
+  }
+}
+
+extern "C" int sd_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,
+                                   float* out_bbox, float* out_score, void* stream) {
+  SD_REQUIRE(B >= 0 && N >= 0 && top_n >= 0, "negative dimension");
+  if (B == 0 || top_n == 0) return SD_OK;
+  SD_REQUIRE(out_bbox && out_score && ((bbox && score) || N == 0), "null tensor pointer");
+  SD_REQUIRE((((uintptr_t)bbox | (uintptr_t)out_bbox) & 15) == 0, "bbox must be 16-byte aligned");
+  int P2 = 64;
+  while (P2 < N) P2 <<= 1;
+  SD_REQUIRE(P2 <= kMaxSortKeys, "get_top_proposal: N=%d exceeds %d", N, kMaxSortKeys);
+  TopArgs a{reinterpret_cast<const float4*>(bbox), score, reinterpret_cast<float4*>(out_bbox),
+            out_score, N, top_n, P2};
+  const size_t lds = (size_t)P2 * sizeof(unsigned long long);
+  if (lds > 64 * 1024)
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)top_proposal_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(top_proposal_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, a);
   SD_LAUNCH_CHECK();
   return SD_OK;
 }

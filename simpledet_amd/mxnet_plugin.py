@@ -592,6 +592,113 @@ def _build_ops(mx):
             return [out_grad[0], in_data[-1], out_data[1], out_data[2]]
 
     ops["fpn_roi_align"] = (FPNRoIAlignProp, None)
+
+    # ---- _contrib_Proposal_v3: cls_prob, bbox_pred, im_info -> output [, score] ----
+    class ProposalV3(CustomOp):
+        def __init__(self, g):
+            super().__init__()
+            self.g = g
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            cls_prob, bbox_pred, im_info = in_data
+            _wait(cls_prob, bbox_pred, im_info)
+            g = self.g
+            B, A2, H, W = cls_prob.shape
+            A = A2 // 2
+            wsb = lib().cdll.sd_proposal_v3_workspace_bytes(B, A, H, W, g["pre"])
+            ws = _scratch(cls_prob, wsb)
+            fa = lambda v: (ctypes.c_float * len(v))(*v)
+            lib().call("sd_proposal_v3", _ptr(cls_prob), _ptr(bbox_pred), _ptr(im_info),
+                       _ptr(out_data[0]), _ptr(out_data[1]), B, A, H, W, g["pre"], g["post"],
+                       float(g["thr"]), g["min_size"], fa(g["scales"]), len(g["scales"]),
+                       fa(g["ratios"]), len(g["ratios"]), g["stride"], int(g["is_train"]), _ptr(ws),
+                       ctypes.c_size_t(wsb), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            for i in range(3):
+                self.assign(in_grad[i], req[i], 0)
+
+    class ProposalV3Prop(CustomOpProp):
+        def __init__(self, rpn_pre_nms_top_n="6000", rpn_post_nms_top_n="300", threshold="0.7",
+                     rpn_min_size="16", scales="(4,8,16,32)", ratios="(0.5,1,2)",
+                     feature_stride="16", output_score="False", iou_loss="False", is_train="False",
+                     workspace="256"):
+            super().__init__(need_top_grad=False)
+            if _bool(iou_loss):
+                raise ValueError("Proposal_v3: iou_loss=True is not supported")
+            self.g = dict(pre=int(rpn_pre_nms_top_n), post=int(rpn_post_nms_top_n),
+                          thr=float(threshold), min_size=int(rpn_min_size), scales=_tuple(scales),
+                          ratios=_tuple(ratios), stride=int(feature_stride),
+                          is_train=_bool(is_train))
+            self.num_visible_outputs = 2 if _bool(output_score) else 1
+
+        def list_arguments(self):
+            return ["cls_prob", "bbox_pred", "im_info"]
+
+        def list_outputs(self):
+            return ["output", "score"]
+
+        def infer_shape(self, in_shape):
+            d = in_shape[0]
+            if len(d) != 4:
+                raise ValueError("cls_prob should be (batch, 2 * num_anchors, H, W)")
+            g = self.g
+            A = d[1] // 2
+            if A != len(g["scales"]) * len(g["ratios"]):
+                raise ValueError("num_anchors != len(ratios) * len(scales)")
+            count = A * d[2] * d[3]
+            pre = min(g["pre"] if g["pre"] > 0 else count, count)
+            post = min(g["post"], pre) if g["is_train"] else g["post"]
+            return [d, (d[0], 4 * A, d[2], d[3]), (d[0], 3)], [(d[0], post, 4), (d[0], post, 1)]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return ProposalV3(self.g)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return []
+
+    ops["_contrib_Proposal_v3"] = (ProposalV3Prop, ("contrib", "Proposal_v3"))
+
+    # ---- get_top_proposal (models/FPN/get_top_proposal.py): bbox, score -> top_n of each ----
+    class GetTopProposal(CustomOp):
+        def __init__(self, top_n):
+            super().__init__()
+            self.top_n = top_n
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            bbox, score = in_data
+            _wait(bbox, score)
+            lib().call("sd_get_top_proposal", _ptr(bbox), _ptr(score), bbox.shape[0], bbox.shape[1],
+                       self.top_n, _ptr(out_data[0]), _ptr(out_data[1]), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            self.assign(in_grad[0], req[0], 0)
+            self.assign(in_grad[1], req[1], 0)
+
+    class GetTopProposalProp(CustomOpProp):
+        def __init__(self, top_n):
+            super().__init__(need_top_grad=False)
+            self.top_n = int(top_n)
+
+        def list_arguments(self):
+            return ["bbox", "score"]
+
+        def list_outputs(self):
+            return ["bbox", "score"]
+
+        def infer_shape(self, in_shape):
+            b = in_shape[0]
+            return in_shape, [(b[0], self.top_n, b[2]), (b[0], self.top_n, 1)]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return GetTopProposal(self.top_n)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return []
+
+    ops["get_top_proposal"] = (GetTopProposalProp, None)
     return ops
 
 

@@ -524,3 +524,51 @@ def deform_conv_backward(out_grad, x, offset, weight, pad=1, stride=1, dilate=1,
                _p(grads[1]), _p(grads[2]), r[0], r[1], r[2], N, C, H, W, F, kh, kw, pad, stride,
                dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
     return grads
+
+
+# --------------------------------------------------------------------------------------------------
+# _contrib_Proposal_v3 + get_top_proposal  (operator_cxx/contrib/proposal_v3{-inl.h,.cu},
+# models/FPN/get_top_proposal.py) -- SURVEY 8(f) rank 1
+# --------------------------------------------------------------------------------------------------
+def _farr(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def proposal_v3(cls_prob, bbox_pred, im_info, rpn_pre_nms_top_n=6000, rpn_post_nms_top_n=300,
+                threshold=0.7, rpn_min_size=16, scales=(4., 8., 16., 32.), ratios=(0.5, 1., 2.),
+                feature_stride=16, is_train=False):
+    """Proposal_v3: cls_prob (B,2A,H,W), bbox_pred (B,4A,H,W), im_info (B,3) ->
+    output (B,post,4), score (B,post,1)   (shapes proposal_v3-inl.h:196-214)."""
+    _chk(cls_prob, "cls_prob", ndim=4)
+    _chk(bbox_pred, "bbox_pred", ndim=4)
+    _chk(im_info, "im_info", ndim=2)
+    B, A2, H, W = cls_prob.shape
+    A = A2 // 2
+    if bbox_pred.shape != (B, 4 * A, H, W) or im_info.shape != (B, 3):
+        raise ValueError("bbox_pred must be (B,4A,H,W) and im_info (B,3)")
+    scales, ratios = list(scales), list(ratios)
+    count = A * H * W
+    pre = rpn_pre_nms_top_n if rpn_pre_nms_top_n > 0 else count
+    pre = min(pre, count)
+    post = int(rpn_post_nms_top_n) if not is_train else min(int(rpn_post_nms_top_n), pre)
+    out = torch.empty((B, post, 4), device=cls_prob.device, dtype=torch.float32)
+    score = torch.empty((B, post, 1), device=cls_prob.device, dtype=torch.float32)
+    wsb = lib().cdll.sd_proposal_v3_workspace_bytes(B, A, H, W, int(rpn_pre_nms_top_n))
+    ws = torch.empty(wsb, device=cls_prob.device, dtype=torch.uint8)
+    lib().call("sd_proposal_v3", _p(cls_prob), _p(bbox_pred), _p(im_info), _p(out), _p(score), B, A,
+               H, W, int(rpn_pre_nms_top_n), int(rpn_post_nms_top_n), float(threshold),
+               int(rpn_min_size), _farr(scales), len(scales), _farr(ratios), len(ratios),
+               int(feature_stride), int(bool(is_train)), _p(ws), ctypes.c_size_t(wsb), _stream())
+    return out, score
+
+
+def get_top_proposal(bbox, score, top_n):
+    """get_top_proposal CustomOp: bbox (B,N,4), score (B,N,1) -> (B,top_n,4), (B,top_n,1)."""
+    _chk(bbox, "bbox", ndim=3)
+    _chk(score, "score", ndim=3)
+    B, N, _ = bbox.shape
+    ob = torch.empty((B, int(top_n), 4), device=bbox.device, dtype=torch.float32)
+    os_ = torch.empty((B, int(top_n), 1), device=bbox.device, dtype=torch.float32)
+    lib().call("sd_get_top_proposal", _p(bbox), _p(score), B, N, int(top_n), _p(ob), _p(os_),
+               _stream())
+    return ob, os_

@@ -169,3 +169,19 @@ def proposal_target_inputs(seed, batch=2, num=2000, max_gt=100, n_gt=None):
         gt = np.concatenate([gt_boxes(seed + 101 * b, 1, max_gt, min_n=n, max_n=n)
                              for b, n in enumerate(n_gt)], 0)
     return proposals(seed + 1, gt, num, pad_rows=max(1, num // 50)), gt
+
+
+def rpn_outputs(seed, batch=2, num_anchors=3, height=50, width=84, stride=16, img_h=IMG_H,
+                img_w=IMG_W):
+    """(cls_prob (B,2A,H,W) softmax pairs, bbox_pred (B,4A,H,W), im_info (B,3)) for Proposal_v3."""
+    rs = np.random.RandomState(seed)
+    logit = rs.standard_normal((batch, 2, num_anchors, height, width)).astype(np.float32) * 2
+    e = np.exp(logit - logit.max(1, keepdims=True))
+    prob = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    cls_prob = prob.reshape(batch, 2 * num_anchors, height, width)
+    bbox_pred = (rs.standard_normal((batch, 4 * num_anchors, height, width)) * 0.3).astype(np.float32)
+    bbox_pred[:, 2::4][rs.rand(batch, num_anchors, height, width) < 0.01] = 6.0  # dw above the clip
+    im_info = np.array([[img_h, img_w, 1.0]] * batch, np.float32)
+    if batch > 1:
+        im_info[1] = [img_h - 64, img_w - 100, 1.5]
+    return cls_prob, bbox_pred, im_info

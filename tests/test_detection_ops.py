@@ -296,3 +296,58 @@ def test_proposal_target_cases(ops, oracle, case):
                                       return_index=True)
             np.testing.assert_array_equal(got[5].cpu().numpy(), want[5])
         np.testing.assert_array_equal(state.cpu().numpy(), rng.state_words())
+
+
+# ------------------------------------------------------------------------ Proposal_v3 (8(f)) ----
+def test_proposal_v3_anchor_known_answer(oracle):
+    # float/floor anchors agree with GenAnchor for the reference's settings
+    a = oracle.proposal_v3_anchors(4, [8], [0.5, 1, 2])
+    np.testing.assert_array_equal(a, [[-22, -10, 25, 13], [-14, -14, 17, 17], [-10, -22, 13, 25]])
+    for stride in (4, 8, 16, 32, 64):
+        np.testing.assert_array_equal(oracle.proposal_v3_anchors(stride, [8], [0.5, 1, 2]),
+                                      oracle.gen_base_anchors(stride, [8], [0.5, 1, 2]).astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(A=3, H=50, W=84, stride=16, pre=2000, post=2000, train=False),
+    dict(A=3, H=50, W=84, stride=16, pre=2000, post=1000, train=True),
+    dict(A=3, H=100, W=167, stride=8, pre=2000, post=2000, train=False),
+    dict(A=15, H=50, W=84, stride=16, pre=6000, post=300, train=False, scales=(2, 4, 8, 16, 32)),
+    dict(A=3, H=13, W=21, stride=64, pre=2000, post=2000, train=False),   # count < pre
+    dict(A=3, H=13, W=21, stride=64, pre=-1, post=100, train=True),
+    dict(A=3, H=25, W=42, stride=32, pre=1000, post=1500, train=True, thr=0.3, min_size=64)])
+def test_proposal_v3_matches_oracle(ops, oracle, cfg):
+    scales = cfg.get("scales", (8,))
+    ratios = (0.5, 1.0, 2.0)
+    cls, bb, info = synth.rpn_outputs(3, 2, cfg["A"], cfg["H"], cfg["W"], cfg["stride"])
+    thr, ms = cfg.get("thr", 0.7), cfg.get("min_size", 16)
+    want = oracle.proposal_v3(cls, bb, info, cfg["pre"], cfg["post"], thr, ms, scales, ratios,
+                              cfg["stride"], cfg["train"])
+    out, score = ops.proposal_v3(_t(cls), _t(bb), _t(info), cfg["pre"], cfg["post"], thr, ms, scales,
+                                 ratios, cfg["stride"], cfg["train"])
+    np.testing.assert_array_equal(score.cpu().numpy(), want[1])
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+
+
+@pytest.mark.gpu
+def test_proposal_v3_score_ties_are_stable(ops, oracle):
+    cls, bb, info = synth.rpn_outputs(5, 1, 3, 50, 84, 16)
+    cls[:, 3:] = np.round(cls[:, 3:] * 32) / 32   # thousands of exactly tied scores
+    want = oracle.proposal_v3(cls, bb, info, 1000, 1000, 0.7, 0, (8,), (0.5, 1, 2), 16, False)
+    out, score = ops.proposal_v3(_t(cls), _t(bb), _t(info), 1000, 1000, 0.7, 0, (8,), (0.5, 1, 2), 16)
+    np.testing.assert_array_equal(score.cpu().numpy(), want[1])
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+
+
+@pytest.mark.gpu
+def test_get_top_proposal(ops, oracle):
+    rs = np.random.RandomState(0)
+    bbox = rs.rand(2, 10000, 4).astype(np.float32) * 500
+    score = rs.rand(2, 10000, 1).astype(np.float32)
+    score[0, :200] = 0.5
+    for top_n in (2000, 10000, 12000):
+        wb, ws_ = oracle.get_top_proposal(bbox, score, top_n)
+        ob, os_ = ops.get_top_proposal(_t(bbox), _t(score), top_n)
+        np.testing.assert_array_equal(os_.cpu().numpy(), ws_)
+        np.testing.assert_array_equal(ob.cpu().numpy(), wb)

@@ -20,7 +20,8 @@ def test_registers_reference_operator_names(plugin):
     mx, props, _ = plugin
     assert set(props) == {"_contrib_ROIAlign_v2", "ROIPooling_v1", "ProposalTarget",
                           "_contrib_GenAnchor", "_contrib_NMS", "assign_layer_fpn",
-                          "_contrib_DeformableConvolution", "fpn_roi_align"}
+                          "_contrib_DeformableConvolution", "fpn_roi_align", "_contrib_Proposal_v3",
+                          "get_top_proposal"}
     for name in props:
         assert "sd_" + name in mx.registry
     # aliases on the symbol namespaces the reference graph uses
@@ -80,6 +81,20 @@ def test_other_props_shapes(plugin):
     assert ins[1] == (2, 72, 50, 84) and ins[2] == (256, 256, 3, 3) and outs == [(2, 256, 50, 84)]
     with pytest.raises(ValueError, match="no_bias"):
         props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="8")
+
+
+def test_proposal_v3_prop(plugin):
+    _, props, _ = plugin
+    p = props["_contrib_Proposal_v3"](rpn_pre_nms_top_n="2000", rpn_post_nms_top_n="2000",
+                                      feature_stride="16", scales="(8,)", ratios="(0.5, 1, 2)",
+                                      output_score="True", threshold="0.7", rpn_min_size="0")
+    assert p.list_arguments() == ["cls_prob", "bbox_pred", "im_info"]   # proposal_v3-inl.h:255-257
+    assert p.list_outputs() == ["output", "score"] and p.num_visible_outputs == 2
+    ins, outs = p.infer_shape([(2, 6, 50, 84), None, None])
+    assert ins[1] == (2, 12, 50, 84) and ins[2] == (2, 3)
+    assert outs == [(2, 2000, 4), (2, 2000, 1)]
+    t = props["get_top_proposal"](top_n="2000")
+    assert t.infer_shape([(2, 10000, 4), (2, 10000, 1)])[1] == [(2, 2000, 4), (2, 2000, 1)]
 
 
 def test_fused_fpn_roi_align_prop(plugin):
