@@ -274,6 +274,24 @@ int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* i
 int sd_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,
                         float* out_bbox, float* out_score, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * _contrib_DecodeBBox  (mx.sym.contrib.DecodeBBox / X.decode_bbox, symbol/builder.py:384-392) and
+ * the test-time per-class filter in front of soft-NMS -- SURVEY 8(f) rank 2
+ *   replaces DecodeBBoxOp::Forward  operator_cxx/contrib/decodebbox.cc:147-215 (host round trip +
+ *   BBoxTransformXYWH :34-80 / BBoxTransformXYXY :84-131)
+ *   rois (B,R,4)  bbox_pred (B,R,4K)  im_info (B,3) DEVICE  out (B,R,4K), or (B,R,4) when
+ *   class_agnostic (then the deltas of class 1 are used, decodebbox.cc:56)
+ * ---------------------------------------------------------------------------------------------- */
+int sd_decode_bbox(const float* rois, const float* bbox_pred, const float* im_info, float* out,
+                   int B, int R, int K, const float* bbox_mean_host, const float* bbox_std_host,
+                   int class_agnostic, int decode_xyxy, void* stream);
+/* detection_test.py:233-247 (do_nms): for every (image, class) the rows with
+ * cls_score > min_det_score as [x1,y1,x2,y2,score], row order kept -- written in the layout
+ * sd_soft_nms_batched reads: dets (B*K, R, 5), counts (B*K).  bbox (B,R,4*bbox_classes),
+ * bbox_classes = K (class specific boxes) or 1 (shared box). */
+int sd_det_filter(const float* bbox, const float* cls_score, int B, int R, int K, int bbox_classes,
+                  float min_det_score, float* dets, int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,13 @@ void orc_proposal_v3(const float* cls_prob, const float* bbox_pred, const float*
 void orc_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,
                           float* out_bbox, float* out_score);
 
+/* ---- _contrib_DecodeBBox: contrib/decodebbox.cc:34-131; test-time filter detection_test.py:233-247 */
+void orc_decode_bbox(const float* rois, const float* deltas, const float* im_info, float* out,
+                     int B, int R, int K, const float* means, const float* stds,
+                     int class_agnostic, int xyxy);
+void orc_det_filter(const float* bbox, const float* cls_score, int B, int R, int K, int Kb,
+                    float min_det_score, float* dets, int* counts);
+
 /* ---- soft_nms : operator_py/cython/cpu_nms.pyx:98-203 ---- */
 /* boxes (n,5) is updated in place (as the Cython copy is); returns new N; inds (n) out. */
 int orc_soft_nms(float* boxes, int64_t* inds, int n, float sigma, float Nt, float threshold,

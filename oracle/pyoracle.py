@@ -399,3 +399,31 @@ def get_top_proposal(bbox, score, top_n):
     os_ = np.empty((B, top_n, 1), np.float32)
     cdll().orc_get_top_proposal(pb, ps, B, N, int(top_n), ob.ctypes, os_.ctypes)
     return ob, os_
+
+
+# ------------------------------------------------------------------------------------------------
+# _contrib_DecodeBBox + test-time per-class filter
+# ------------------------------------------------------------------------------------------------
+def decode_bbox(rois, bbox_pred, im_info, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2),
+                class_agnostic=True, xyxy=False):
+    rois, pr = _f(rois)
+    bbox_pred, pb = _f(bbox_pred)
+    im_info, pi = _f(im_info)
+    B, R, _ = rois.shape
+    K = bbox_pred.shape[2] // 4
+    out = np.empty((B, R, 4 if class_agnostic else 4 * K), np.float32)
+    cdll().orc_decode_bbox(pr, pb, pi, out.ctypes, B, R, K, _fa(bbox_mean), _fa(bbox_std),
+                           int(class_agnostic), int(xyxy))
+    return out
+
+
+def det_filter(bbox, cls_score, min_det_score):
+    bbox, pb = _f(bbox)
+    cls_score, ps = _f(cls_score)
+    B, R, K = cls_score.shape
+    Kb = bbox.shape[2] // 4
+    dets = np.zeros((B * K, R, 5), np.float32)
+    counts = np.zeros(B * K, np.int32)
+    cdll().orc_det_filter(pb, ps, B, R, K, Kb, ctypes.c_float(min_det_score), dets.ctypes,
+                          counts.ctypes)
+    return dets, counts

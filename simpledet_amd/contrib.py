@@ -175,3 +175,11 @@ def get_top_proposal(bbox, score, top_n):
     """mxnext.tvm.get_top_proposal / models/FPN/get_top_proposal.py."""
     with torch.no_grad():
         return ops.get_top_proposal(bbox, score, top_n)
+
+
+def DecodeBBox(rois, bbox_pred, im_info, bbox_mean=(0., 0., 0., 0.), bbox_std=(.1, .1, .2, .2),
+               class_agnostic=True, bbox_decode_type="xywh"):
+    """mx.sym.contrib.DecodeBBox / X.decode_bbox (symbol/builder.py:384-392)."""
+    with torch.no_grad():
+        return ops.decode_bbox(rois, bbox_pred, im_info, bbox_mean, bbox_std, class_agnostic,
+                               bbox_decode_type)

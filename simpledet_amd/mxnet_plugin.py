@@ -699,6 +699,55 @@ def _build_ops(mx):
             return []
 
     ops["get_top_proposal"] = (GetTopProposalProp, None)
+
+    # ---- _contrib_DecodeBBox: rois, bbox_pred, im_info -> output ----
+    class DecodeBBox(CustomOp):
+        def __init__(self, g):
+            super().__init__()
+            self.g = g
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            _require_write(req[:1], ["output"])
+            rois, pred, info = in_data
+            _wait(rois, pred, info)
+            g = self.g
+            fa = lambda v: (ctypes.c_float * 4)(*v)
+            lib().call("sd_decode_bbox", _ptr(rois), _ptr(pred), _ptr(info), _ptr(out_data[0]),
+                       rois.shape[0], rois.shape[1], pred.shape[2] // 4, fa(g["mean"]), fa(g["std"]),
+                       int(g["agnostic"]), int(g["xyxy"]), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            for i in range(3):
+                self.assign(in_grad[i], req[i], 0)
+
+    class DecodeBBoxProp(CustomOpProp):
+        def __init__(self, bbox_mean="(0,0,0,0)", bbox_std="(0.1,0.1,0.2,0.2)",
+                     class_agnostic="True", bbox_decode_type="xywh"):
+            super().__init__(need_top_grad=False)
+            if bbox_decode_type not in ("xywh", "xyxy"):
+                raise ValueError("bbox_decode_type must be 'xywh' or 'xyxy'")
+            self.g = dict(mean=_tuple(bbox_mean, 4), std=_tuple(bbox_std, 4),
+                          agnostic=_bool(class_agnostic), xyxy=bbox_decode_type == "xyxy")
+
+        def list_arguments(self):
+            return ["rois", "bbox_pred", "im_info"]
+
+        def list_outputs(self):
+            return ["output"]
+
+        def infer_shape(self, in_shape):
+            d = in_shape[1]
+            out = (d[0], d[1], 4) if self.g["agnostic"] else tuple(d)
+            return in_shape, [out]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return DecodeBBox(self.g)
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return []
+
+    ops["_contrib_DecodeBBox"] = (DecodeBBoxProp, ("contrib", "DecodeBBox"))
     return ops
 
 

@@ -572,3 +572,40 @@ def get_top_proposal(bbox, score, top_n):
     lib().call("sd_get_top_proposal", _p(bbox), _p(score), B, N, int(top_n), _p(ob), _p(os_),
                _stream())
     return ob, os_
+
+
+# --------------------------------------------------------------------------------------------------
+# _contrib_DecodeBBox + test-time detection filter  (operator_cxx/contrib/decodebbox{-inl.h,.cc},
+# detection_test.py:233-247) -- SURVEY 8(f) rank 2
+# --------------------------------------------------------------------------------------------------
+def decode_bbox(rois, bbox_pred, im_info, bbox_mean=(0., 0., 0., 0.), bbox_std=(.1, .1, .2, .2),
+                class_agnostic=True, bbox_decode_type="xywh"):
+    """DecodeBBox: rois (B,R,4), bbox_pred (B,R,4K), im_info (B,3) -> (B,R,4) if class_agnostic
+    else (B,R,4K)  (decodebbox-inl.h:85-107)."""
+    _chk(rois, "rois", ndim=3)
+    _chk(bbox_pred, "bbox_pred", ndim=3)
+    _chk(im_info, "im_info", ndim=2)
+    if bbox_decode_type not in ("xywh", "xyxy"):
+        raise ValueError("bbox_decode_type must be 'xywh' or 'xyxy'")
+    B, R, _ = rois.shape
+    K = bbox_pred.shape[2] // 4
+    out = torch.empty((B, R, 4 if class_agnostic else 4 * K), device=rois.device,
+                      dtype=torch.float32)
+    lib().call("sd_decode_bbox", _p(rois), _p(bbox_pred), _p(im_info), _p(out), B, R, K,
+               _farr(bbox_mean), _farr(bbox_std), int(bool(class_agnostic)),
+               int(bbox_decode_type == "xyxy"), _stream())
+    return out
+
+
+def det_filter(bbox_xyxy, cls_score, min_det_score):
+    """Per (image, class) rows with score > min_det_score as [box, score] (detection_test.py:
+    236-247), in sd_soft_nms_batched's layout: dets (B*K,R,5), counts (B*K) int32."""
+    _chk(bbox_xyxy, "bbox_xyxy", ndim=3)
+    _chk(cls_score, "cls_score", ndim=3)
+    B, R, K = cls_score.shape
+    Kb = bbox_xyxy.shape[2] // 4
+    dets = torch.empty((B * K, R, 5), device=cls_score.device, dtype=torch.float32)
+    counts = torch.empty((B * K,), device=cls_score.device, dtype=torch.int32)
+    lib().call("sd_det_filter", _p(bbox_xyxy), _p(cls_score), B, R, K, Kb, float(min_det_score),
+               _p(dets), _p(counts), _stream())
+    return dets, counts

@@ -351,3 +351,55 @@ def test_get_top_proposal(ops, oracle):
         ob, os_ = ops.get_top_proposal(_t(bbox), _t(score), top_n)
         np.testing.assert_array_equal(os_.cpu().numpy(), ws_)
         np.testing.assert_array_equal(ob.cpu().numpy(), wb)
+
+
+# ------------------------------------------------- DecodeBBox + test-time filter (8(f) rank 2) --
+def _head_outputs(seed, B=2, R=1000, K=81):
+    rs = np.random.RandomState(seed)
+    rois = synth.random_rois(seed, B, R, degenerate=False)
+    deltas = (rs.standard_normal((B, R, 4 * K)) * 0.5).astype(np.float32)
+    logit = rs.standard_normal((B, R, K)).astype(np.float32) * 3
+    e = np.exp(logit - logit.max(-1, keepdims=True))
+    score = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    info = np.array([[800, 1333, 1.0], [736, 1233, 1.5]][:B], np.float32)
+    return rois, deltas, score, info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agnostic", [True, False])
+@pytest.mark.parametrize("kind", ["xywh", "xyxy"])
+def test_decode_bbox_bit_exact(ops, oracle, agnostic, kind):
+    rois, deltas, _, info = _head_outputs(0, K=2 if agnostic else 81)
+    want = oracle.decode_bbox(rois, deltas, info, (0.0, 0.01, 0.0, -0.02), (0.1, 0.1, 0.2, 0.2),
+                              agnostic, kind == "xyxy")
+    got = ops.decode_bbox(_t(rois), _t(deltas), _t(info), (0.0, 0.01, 0.0, -0.02),
+                          (0.1, 0.1, 0.2, 0.2), agnostic, kind)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared_box", [False, True])
+def test_test_time_pipeline_decode_filter_softnms(ops, oracle, shared_box):
+    """bbox head output -> DecodeBBox -> per-class filter -> batched soft-NMS, all on the device,
+    equals the reference's CPU sequence (decodebbox.cc -> detection_test.py do_nms -> soft_nms)."""
+    B, R, K = 2, 300, 12
+    rois, deltas, score, info = _head_outputs(1, B, R, K)
+    if shared_box:
+        boxes = oracle.decode_bbox(rois, deltas[:, :, :8].copy(), info, class_agnostic=True)
+        tb = ops.decode_bbox(_t(rois), _t(deltas[:, :, :8].copy()), _t(info), class_agnostic=True)
+    else:
+        boxes = oracle.decode_bbox(rois, deltas, info, class_agnostic=False)
+        tb = ops.decode_bbox(_t(rois), _t(deltas), _t(info), class_agnostic=False)
+    wd, wc = oracle.det_filter(boxes, score, 0.02)
+    dets, counts = ops.det_filter(tb, _t(score), 0.02)
+    np.testing.assert_array_equal(counts.cpu().numpy(), wc)
+    dn = dets.cpu().numpy()
+    for p in range(B * K):
+        np.testing.assert_array_equal(dn[p, :wc[p]], wd[p, :wc[p]])
+    od, oi, oc = ops.soft_nms_batched(dets, counts, 0.5, 0.5, 0.001, 1)
+    od, oi, oc = od.cpu().numpy(), oi.cpu().numpy(), oc.cpu().numpy()
+    for p in range(B * K):
+        wb, wi = oracle.soft_nms(wd[p, :wc[p]], 0.5, 0.5, 0.001, 1)
+        assert oc[p] == len(wi)
+        np.testing.assert_array_equal(od[p, :oc[p]], wb)
+        np.testing.assert_array_equal(oi[p, :oc[p]], wi)
