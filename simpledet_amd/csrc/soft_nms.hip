@@ -76,7 +76,8 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
   const int nwords = (Nmax + 63) / 64 + 1;
   float* PS = reinterpret_cast<float*>(FW + nwords);
   int* PP = reinterpret_cast<int*>(PS + NW);
-  int* CTRL = PP + NW;  // [0] = N, [1] = iteration stamp of the last removal
+  int* CTRL = PP + NW;  // [0] = N, [1] = step stamp of the last removal, [2..3] = queue lengths
+  int* LIST = CTRL + 4;
 
   int n = a.counts ? a.counts[p] : Nmax;
   n = n < 0 ? 0 : (n > Nmax ? Nmax : n);
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
   if (tid == 0) {
     CTRL[0] = n;
     CTRL[1] = -1;
+    CTRL[2] = 0;
+    CTRL[3] = 0;
   }
   __syncthreads();
 
@@ -128,51 +131,72 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
     }
     const double tarea = ((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0);
 
-    // ---- decay every remaining box; fold the next arg-max and the removal flags into the pass ----
+    // ---- pass 1 (all boxes, cheap): does the box overlap the selected one at all?  In the
+    // reference a box is rescored only when iw > 0 and ih > 0; (float)((double)d + 1.0) > 0 is
+    // exactly d > -1 for a float d.  Typically ~1% of the boxes overlap, so they are queued and the
+    // expensive IoU / decay arithmetic (double adds, IEEE divide) runs once per step on a dense set
+    // of lanes instead of in every 64-box chunk.  Untouched boxes enter the next arg-max here.
     Cand c{0.f, -1};
-    bool any_removed = false;
     const int M = N - (i + 1);
+    int* QL = LIST;                  // queue of overlapping positions
+    int* qn = CTRL + 2 + (i & 1);    // its length (two counters, alternating steps)
     for (int chunk = wave; chunk * kWave < M; chunk += NW) {
       const int rel = chunk * kWave + lane;
       const int pos = i + 1 + rel;
-      bool removed = false;
+      bool ovl = false;
       if (rel < M) {
         float x1, y1, x2, y2, s;
         if (pos == maxpos) {  // receives the old box i (the swap of cpu_nms.pyx:136-150)
           x1 = ix1; y1 = iy1; x2 = ix2; y2 = iy2; s = si;
-          X1[pos] = x1; Y1[pos] = y1; X2[pos] = x2; Y2[pos] = y2; IND[pos] = ii;
+          X1[pos] = x1; Y1[pos] = y1; X2[pos] = x2; Y2[pos] = y2; IND[pos] = ii; S[pos] = s;
         } else {
           x1 = X1[pos]; y1 = Y1[pos]; x2 = X2[pos]; y2 = Y2[pos]; s = S[pos];
         }
-        const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
-        const float iw = (float)((double)(pmin(tx2, x2) - pmax(tx1, x1)) + 1.0);
-        float ns = s;
-        if (iw > 0) {
-          const float ih = (float)((double)(pmin(ty2, y2) - pmax(ty1, y1)) + 1.0);
-          if (ih > 0) {
-            const float ua = (float)((tarea + (double)area) - (double)(iw * ih));
-            const float ov = iw * ih / ua;
-            float weight;
-            if (a.method == 1) weight = ov > a.Nt ? (float)(1.0 - (double)ov) : 1.f;
-            else if (a.method == 2) weight = (float)exp((double)(-(ov * ov) / a.sigma));
-            else weight = ov > a.Nt ? 0.f : 1.f;
-            ns = weight * s;
-            removed = ns < a.thr;
-          }
-        }
-        if (pos == maxpos || ns != s || !(ns == ns)) S[pos] = ns;
-        if (!removed && ns == ns) c = better(c, Cand{ns, pos});
+        const float dw = pmin(tx2, x2) - pmax(tx1, x1), dh = pmin(ty2, y2) - pmax(ty1, y1);
+        ovl = dw > -1.f && dh > -1.f;
+        if (!ovl && s == s) c = better(c, Cand{s, pos});
       }
-      const unsigned long long fw = __ballot(removed);
-      if (lane == 0) FW[chunk] = fw;
-      any_removed |= fw != 0;
+      const unsigned long long bal = __ballot(ovl);
+      if (bal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(qn, __popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ovl) QL[base + __popcll(bal & ((1ull << lane) - 1))] = pos;
+      }
+      if (lane == 0) FW[chunk] = 0ull;
+    }
+    if (tid == 0) CTRL[2 + ((i + 1) & 1)] = 0;  // the other counter, for the next step
+    __syncthreads();
+    // ---- pass 2 (queued boxes only): IoU, decay, removal flag ----
+    bool any_removed = false;
+    const int nq = *qn;
+    for (int e = tid; e < nq; e += THREADS) {
+      const int pos = QL[e], rel = pos - (i + 1);
+      const float x1 = X1[pos], y1 = Y1[pos], x2 = X2[pos], y2 = Y2[pos], s = S[pos];
+      const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+      const float iw = (float)((double)(pmin(tx2, x2) - pmax(tx1, x1)) + 1.0);
+      const float ih = (float)((double)(pmin(ty2, y2) - pmax(ty1, y1)) + 1.0);
+      const float ua = (float)((tarea + (double)area) - (double)(iw * ih));
+      const float ov = iw * ih / ua;
+      float weight;
+      if (a.method == 1) weight = ov > a.Nt ? (float)(1.0 - (double)ov) : 1.f;
+      else if (a.method == 2) weight = (float)exp((double)(-(ov * ov) / a.sigma));
+      else weight = ov > a.Nt ? 0.f : 1.f;
+      const float ns = weight * s;
+      S[pos] = ns;
+      if (ns < a.thr) {
+        any_removed = true;
+        atomicOr(&FW[rel >> 6], 1ull << (rel & 63));
+      } else if (ns == ns) {
+        c = better(c, Cand{ns, pos});
+      }
     }
     c = wave_best(c);
     if (lane == 0) {
       PS[wave] = c.s;
       PP[wave] = c.pos;
-      if (any_removed) CTRL[1] = i;
     }
+    if (any_removed) CTRL[1] = i;
     __syncthreads();
     have_best = true;
     if (CTRL[1] == i) {
@@ -258,7 +282,7 @@ extern "C" int sd_soft_nms_batched(const float* dets, const int32_t* counts, int
   SD_REQUIRE(dets && out_dets && out_inds, "null tensor pointer");
   constexpr int T = 256;
   const size_t lds = (((size_t)6 * Nmax + 1) & ~(size_t)1) * 4 + ((size_t)(Nmax + 63) / 64 + 1) * 8 +
-                     (size_t)(T / kWave) * 8 + 16;
+                     (size_t)(T / kWave) * 8 + 16 + (size_t)Nmax * 4;
   SD_REQUIRE(lds <= 160 * 1024, "soft_nms: Nmax=%d needs %zu B of LDS (limit 160 KB)", Nmax, lds);
   SoftArgs a{dets, counts, out_dets, out_inds, out_counts, P, Nmax, sigma, Nt, threshold, method};
   auto k = soft_nms_kernel<T>;
