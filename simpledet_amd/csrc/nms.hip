@@ -15,7 +15,8 @@
 //   3. nms_scan_kernel    one wave per image replaces the reference's host loop, with no barrier:
 //                         lane = box of the current 64-box block, "already suppressed" is an OR of
 //                         (T word & keep word) along the box's own row of T (independent loads),
-//                         the diagonal word is resolved with scalar ops, one ballot per kept box.
+//                         the diagonal word is resolved in rounds of two ballots: every live box
+//                         without a live suppressor is kept at once (rounds = longest chain).
 //                         Kept boxes are written straight to out/score; the tail is zero padded.
 // No host round trip, no device synchronisation, one stream.
 #include "common.h"
@@ -172,41 +173,100 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(ScanArgs a) {
   float* score = a.score + (long)img * a.post;
   int* keep_index = a.keep_index ? a.keep_index + (long)img * a.post : nullptr;
   int nkeep = 0;
-  for (int rb = 0; rb < a.nb; ++rb) {
-    if (nkeep >= a.post) break;  // only the first `post` kept boxes are ever output
-    const int c = rb * kWave + lane;
-    const bool valid = c < a.pre;
-    const unsigned long long* Tc = T + (long)(valid ? c : 0) * a.nb;
-    unsigned long long acc = 0;
-    for (int w0 = 0; w0 < rb; w0 += 16) {
-      unsigned long long t[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) t[e] = (w0 + e < rb) ? Tc[w0 + e] : 0ull;
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (w0 + e < rb) acc |= t[e] & kw[w0 + e];
-    }
-    const unsigned long long diag = valid ? Tc[rb] : 0ull;
-    unsigned long long cur = __ballot(acc != 0 || !valid);
+  // greedy resolve of one 64-box block given "suppressed by earlier blocks" (acc) and the
+  // block's diagonal word; writes the kept boxes, returns the keep mask
+  auto resolve = [&](int rb, bool valid, unsigned long long acc, unsigned long long diag,
+                     float4 bx, float sc, int ord) {
+    // diag (lane j) = the earlier boxes of this block that would suppress box j.  A live box none
+    // of whose potential suppressors is still live is kept -- all such boxes at once -- and
+    // whatever they suppress leaves the live set: the number of rounds is the longest suppression
+    // chain inside the block (1-3 in practice), not the number of kept boxes.
+    unsigned long long cur = __ballot(acc != 0 || !valid);  // resolved: suppressed or kept
     unsigned long long keepmask = 0;
-    unsigned long long cand = ~cur;
-    while (cand) {  // wave-uniform: one trip per kept box of this block
-      const int k = __ffsll((long long)cand) - 1;
-      keepmask |= 1ull << k;
-      cur |= __ballot((diag >> k) & 1ull) | (1ull << k);
-      cand = ~cur;
+    unsigned long long live = ~cur;
+    while (live) {
+      const unsigned long long fre = __ballot(((live >> lane) & 1ull) && (diag & live) == 0);
+      keepmask |= fre;
+      const unsigned long long sup = __ballot((diag & fre) != 0);
+      cur |= fre | sup;
+      live = ~cur;
     }
     if (lane == 0) kw[rb] = keepmask;
     // PrepareOutput (nms.cu:207-233) for the boxes kept in this block
     if (keepmask & (1ull << lane)) {
       const int rank = nkeep + __popcll(keepmask & ((1ull << lane) - 1));
       if (rank < a.post) {
-        reinterpret_cast<float4*>(out)[rank] = boxes[c];
-        score[rank] = sscore[c];
-        if (keep_index) keep_index[rank] = order[c];
+        reinterpret_cast<float4*>(out)[rank] = bx;
+        score[rank] = sc;
+        if (keep_index) keep_index[rank] = ord;
       }
     }
     nkeep += __popcll(keepmask);
+  };
+  // everything a block needs from global memory (its row of T, its diagonal row word, its box)
+  // is fetched one block ahead so that no load latency sits on the block-to-block chain
+  struct Pre {
+    float4 bx;
+    float sc;
+    int ord;
+  };
+  auto fetch = [&](int c, bool valid) {
+    Pre p{make_float4(0.f, 0.f, 0.f, 0.f), 0.f, -1};
+    if (valid) {
+      p.bx = boxes[c];
+      p.sc = sscore[c];
+      p.ord = order[c];
+    }
+    return p;
+  };
+  constexpr int NBF = 32;  // fast path: the next block's row of T is fetched during this block's resolve
+  if (a.nb <= NBF) {
+    unsigned long long cw[NBF + 1];  // words 0..rb of the current block's boxes (word rb = diagonal)
+#pragma unroll
+    for (int w = 0; w <= NBF; ++w) cw[w] = 0;
+    if (lane < a.pre) cw[0] = T[(long)lane * a.nb];
+    Pre cp = fetch(lane, lane < a.pre);
+    for (int rb = 0; rb < a.nb; ++rb) {
+      if (nkeep >= a.post) break;  // only the first `post` kept boxes are ever output
+      const int c = rb * kWave + lane;
+      const bool valid = c < a.pre;
+      // issue the loads of block rb + 1 now; they complete while this block is resolved
+      unsigned long long nw[NBF + 1];
+      const int cn = c + kWave;
+      const bool nvalid = rb + 1 < a.nb && cn < a.pre;
+      const unsigned long long* Tn = T + (long)(nvalid ? cn : 0) * a.nb;
+#pragma unroll
+      for (int w = 0; w <= NBF; ++w) nw[w] = (nvalid && w <= rb + 1) ? Tn[w] : 0ull;
+      const Pre np = fetch(cn, nvalid);
+      unsigned long long acc = 0, diag = 0;
+#pragma unroll
+      for (int w = 0; w <= NBF; ++w) {
+        if (w < rb) acc |= cw[w] & kw[w];
+        if (w == rb) diag = cw[w];
+      }
+      resolve(rb, valid, acc, diag, cp.bx, cp.sc, cp.ord);
+#pragma unroll
+      for (int w = 0; w <= NBF; ++w) cw[w] = nw[w];
+      cp = np;
+    }
+  } else {
+    for (int rb = 0; rb < a.nb; ++rb) {
+      if (nkeep >= a.post) break;
+      const int c = rb * kWave + lane;
+      const bool valid = c < a.pre;
+      const unsigned long long* Tc = T + (long)(valid ? c : 0) * a.nb;
+      unsigned long long acc = 0;
+      for (int w0 = 0; w0 < rb; w0 += 16) {
+        unsigned long long t[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t[e] = (w0 + e < rb) ? Tc[w0 + e] : 0ull;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (w0 + e < rb) acc |= t[e] & kw[w0 + e];
+      }
+      const Pre p = fetch(c, valid);
+      resolve(rb, valid, acc, valid ? Tc[rb] : 0ull, p.bx, p.sc, p.ord);
+    }
   }
   if (nkeep > a.post) nkeep = a.post;
   __threadfence_block();  // the kept rows written above are read back below (same wave)
@@ -288,33 +348,74 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(PropArgs a) {
 // and updates below (elements before that digit) -- all threads get the same values
 template <typename KeyFn>
 __device__ __forceinline__ int radix_digit(int count, int shift, unsigned mask, unsigned prefix,
-                                           int want, int* hist, int* below, KeyFn key_of) {
+                                           int want, int* hist, int* below, int* bucket,
+                                           KeyFn key_of) {
   const int tid = threadIdx.x, T = blockDim.x;
   for (int i = tid; i < 256; i += T) hist[i] = 0;
   __syncthreads();
-  for (int i = tid; i < count; i += T) {
-    const unsigned k = key_of(i);
-    if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+  // RPN scores share a handful of exponent bytes, so plain per-lane LDS atomics would serialise on
+  // a few counters: lanes with the same digit are merged (ballot) into one atomic per wave
+  constexpr int UN = 8;  // keys fetched per thread before any of them is counted (latency)
+  for (int i0 = 0; i0 < count; i0 += UN * T) {
+    unsigned kk[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * T + tid;
+      kk[u] = i < count ? key_of(i) : ~prefix;  // ~prefix never matches under a non-empty mask
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * T + tid;
+      int dg = -1;
+      if (i < count && (kk[u] & mask) == prefix) dg = (int)((kk[u] >> shift) & 255);
+      unsigned long long todo = __ballot(dg >= 0);
+      for (int round = 0; round < 4 && todo; ++round) {  // popular digits first, merged
+        const int leader = __ffsll((long long)todo) - 1;
+        const int d0 = __builtin_amdgcn_readlane(dg, leader);
+        const unsigned long long same = __ballot(dg == d0);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d0], __popcll(same));
+        if (dg == d0) dg = -1;
+        todo &= ~same;
+      }
+      if (dg >= 0) atomicAdd(&hist[dg], 1);  // whatever is left is spread over many counters
+    }
   }
   __syncthreads();
-  int run = 0, digit = 255, lower = 0;
-  for (int d = 0; d < 256; ++d) {  // every thread scans the same 256 counters (LDS broadcast)
-    const int c = hist[d];
-    if (run + c >= want) {
-      digit = d;
-      lower = run;
-      break;
+  // wave 0 scans the 256 counters (4 per lane + a wave prefix sum) and publishes the digit where
+  // the running count reaches `want`
+  if (threadIdx.x < kWave) {
+    const int lane = threadIdx.x;
+    const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2],
+              c3 = hist[4 * lane + 3];
+    const int tot = c0 + c1 + c2 + c3;
+    int incl = tot;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
     }
-    run += c;
+    const int excl = incl - tot;
+    if (excl < want && want <= incl) {  // exactly one lane
+      int run = excl, d = 4 * lane, sz = c0;
+      if (run + c0 < want) { run += c0; d = 4 * lane + 1; sz = c1;
+        if (run + c1 < want) { run += c1; d = 4 * lane + 2; sz = c2;
+          if (run + c2 < want) { run += c2; d = 4 * lane + 3; sz = c3; } } }
+      hist[256] = d;
+      hist[257] = run;
+      hist[258] = sz;
+    }
   }
+  __syncthreads();
+  const int digit = hist[256], lower = hist[257], size = hist[258];
   *below = lower;
+  *bucket = size;
   __syncthreads();
   return digit;
 }
 
 __global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // P2 composite keys
-  __shared__ int hist[256];
+  __shared__ int hist[260];
   __shared__ int ncand;
   const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const float* sc = a.score_all + (long)img * a.count;
@@ -322,37 +423,52 @@ __global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
   auto skey = [&](int i) { return ordered_desc_bits(sc[i]); };  // ascending key = best score first
   // ---- the pre-th smallest score key ----
   unsigned prefix = 0, mask = 0;
-  int want = a.pre;
+  int want = a.pre, last_bucket = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     int below;
-    const int d = radix_digit(a.count, shift, mask, prefix, want, hist, &below, skey);
+    const int d = radix_digit(a.count, shift, mask, prefix, want, hist, &below, &last_bucket, skey);
     want -= below;
     prefix |= (unsigned)d << shift;
     mask |= 255u << shift;
   }
   const unsigned Tkey = prefix;  // `want` of the elements with this key are still needed
-  // ---- ties on the score: the lowest rows win (stable sort); select the want-th smallest row ----
-  unsigned ipre = 0, imask = 0;
-  int iwant = want;
-  auto ikey = [&](int i) { return skey(i) == Tkey ? (unsigned)i : 0xffffffffu; };
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    int below;
-    // rows that do not carry Tkey map to 0xffffffff and never match a prefix below 2^24 rows ...
-    const int d = radix_digit(a.count, shift, imask, ipre, iwant, hist, &below, ikey);
-    iwant -= below;
-    ipre |= (unsigned)d << shift;
-    imask |= 255u << shift;
+  const int n_eq = last_bucket;  // how many elements carry exactly this key
+  // ---- ties on the score: the lowest rows win (stable sort); select the want-th smallest row
+  //      (skipped when every tied element is taken, the usual case) ----
+  unsigned Irow = 0xffffffffu;  // ties with row <= Irow are taken
+  if (want < n_eq) {
+    unsigned ipre = 0, imask = 0;
+    int iwant = want;
+    auto ikey = [&](int i) { return skey(i) == Tkey ? (unsigned)i : 0xffffffffu; };
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      int below, bucket;
+      // rows that do not carry Tkey map to 0xffffffff and never match a prefix below 2^24 rows
+      const int d = radix_digit(a.count, shift, imask, ipre, iwant, hist, &below, &bucket, ikey);
+      iwant -= below;
+      ipre |= (unsigned)d << shift;
+      imask |= 255u << shift;
+    }
+    Irow = ipre;
   }
-  const unsigned Irow = ipre;  // ties with row <= Irow are taken
   // ---- unordered compaction of the selected rows into composite keys, then sort ----
   if (tid == 0) ncand = 0;
   for (int i = tid; i < a.P2; i += T) keys[i] = ~0ull;
   __syncthreads();
-  for (int i = tid; i < a.count; i += T) {
-    const unsigned k = skey(i);
-    if (k < Tkey || (k == Tkey && (unsigned)i <= Irow)) {
-      const int pos = atomicAdd(&ncand, 1);
-      if (pos < a.P2) keys[pos] = ((unsigned long long)k << 32) | (unsigned)i;
+  for (int i0 = 0; i0 < a.count; i0 += 8 * T) {
+    unsigned kk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * T + tid;
+      kk[u] = i < a.count ? skey(i) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * T + tid;
+      const unsigned k = kk[u];
+      if (i < a.count && (k < Tkey || (k == Tkey && (unsigned)i <= Irow))) {
+        const int pos = atomicAdd(&ncand, 1);
+        if (pos < a.P2) keys[pos] = ((unsigned long long)k << 32) | (unsigned)i;
+      }
     }
   }
   __syncthreads();
