@@ -112,6 +112,14 @@ def run(seed=0, cpu=True):
         t = _time_cpu(lambda: orc.soft_nms(sd[0], 0.5, 0.5, 0.001, 1), min_s=0.3)
         res["soft_nms"]["cpu_ms_per_problem"] = t
         res["soft_nms"]["cpu_problems_per_s_1core"] = 1e3 / t
+        try:  # the reference's own Cython soft_nms (oracle/_ref, built from /root/reference)
+            from oracle._ref import cpu_nms as _ref_nms
+            t0 = time.perf_counter()
+            for q in range(2):
+                _ref_nms.soft_nms(sd[q], np.float32(0.5), np.float32(0.5), np.float32(0.001), np.uint8(1))
+            res["soft_nms"]["reference_cython_ms_per_problem"] = (time.perf_counter() - t0) * 1e3 / 2
+        except Exception:
+            pass
 
     # ---- ROIPooling_v1: C4 map (2,1024,50,84), 1024 rois, 7x7 ----
     rs = np.random.RandomState(seed)
