@@ -39,7 +39,7 @@ def _time_cpu(fn, min_s=0.5, max_iter=20):
             return dt * 1e3 / n
 
 
-def run(seed=0, cpu=True):
+def run(seed=0, cpu=True, only=None):
     import torch
     from simpledet_amd import ops, synth
     res = {}
@@ -50,112 +50,127 @@ def run(seed=0, cpu=True):
     def T(a):
         return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
+    def want(name):  # `only`: iterable of section names (A/B runs), None = everything
+        return only is None or name in only
+
     # ---- GenAnchor: P2..P6, A = 3 (pure write: 16 B per anchor) ----
-    shapes = list(synth.FPN_SHAPES) + [(13, 21)]
-    strides = [4, 8, 16, 32, 64]
-    ms = _time_gpu(lambda: [ops.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
-    nbytes = sum(16 * h * w * 3 for h, w in shapes)
-    res["gen_anchor"] = {"ms": ms, "bytes": nbytes, "GBs": nbytes / ms / 1e6, "launches": 5}
-    if orc:
-        res["gen_anchor"]["cpu_ms"] = _time_cpu(
-            lambda: [orc.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
+    if want("gen_anchor"):
+        shapes = list(synth.FPN_SHAPES) + [(13, 21)]
+        strides = [4, 8, 16, 32, 64]
+        ms = _time_gpu(lambda: [ops.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
+        nbytes = sum(16 * h * w * 3 for h, w in shapes)
+        res["gen_anchor"] = {"ms": ms, "bytes": nbytes, "GBs": nbytes / ms / 1e6, "launches": 5}
+        if orc:
+            res["gen_anchor"]["cpu_ms"] = _time_cpu(
+                lambda: [orc.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
 
     # ---- ProposalTarget: B=2, 2000 proposals, 100 gt slots, 512 rois, 81 classes ----
-    rois, gt = synth.proposal_target_inputs(seed, 2, 2000, 100)
-    tr, tg = T(rois), T(gt)
-    state = ops.glibc_rand_state(1)
-    ms = _time_gpu(lambda: ops.proposal_target(tr, tg, 81, 2, 512, rng_state=state))
-    res["proposal_target"] = {"ms": ms, "images_per_s": 2 / ms * 1e3}
-    if orc:
-        p = orc.make_pt_param(81, 2, 512)
-        rng = orc.GlibcRand(1)
-        res["proposal_target"]["cpu_ms"] = _time_cpu(lambda: orc.proposal_target(rois, gt, p, rng=rng))
+    if want("proposal_target"):
+        rois, gt = synth.proposal_target_inputs(seed, 2, 2000, 100)
+        tr, tg = T(rois), T(gt)
+        state = ops.glibc_rand_state(1)
+        ms = _time_gpu(lambda: ops.proposal_target(tr, tg, 81, 2, 512, rng_state=state))
+        res["proposal_target"] = {"ms": ms, "images_per_s": 2 / ms * 1e3}
+        if orc:
+            p = orc.make_pt_param(81, 2, 512)
+            rng = orc.GlibcRand(1)
+            res["proposal_target"]["cpu_ms"] = _time_cpu(lambda: orc.proposal_target(rois, gt, p, rng=rng))
 
     # ---- _contrib_NMS: B=2 x 2000 boxes, thr 0.7, post 1000 (train proposals) ----
-    dets = np.stack([synth.nms_dets(seed + i, 2000) for i in range(2)])
-    td = T(dets)
-    ms = _time_gpu(lambda: ops.nms(td, 2000, 1000, 0.7))
-    res["nms"] = {"ms": ms, "images_per_s": 2 / ms * 1e3, "pair_iou_per_s": 2 * 2000 * 1999 / 2 / ms * 1e3,
-                  "config": "B=2, N=2000, post 1000, thr 0.7"}
-    if orc:
-        res["nms"]["cpu_ms"] = _time_cpu(lambda: orc.nms(dets, 2000, 1000, 0.7))
+    if want("nms"):
+        dets = np.stack([synth.nms_dets(seed + i, 2000) for i in range(2)])
+        td = T(dets)
+        ms = _time_gpu(lambda: ops.nms(td, 2000, 1000, 0.7))
+        res["nms"] = {"ms": ms, "images_per_s": 2 / ms * 1e3, "pair_iou_per_s": 2 * 2000 * 1999 / 2 / ms * 1e3,
+                      "config": "B=2, N=2000, post 1000, thr 0.7"}
+        if orc:
+            res["nms"]["cpu_ms"] = _time_cpu(lambda: orc.nms(dets, 2000, 1000, 0.7))
 
     # ---- Proposal_v3 over the five FPN levels + get_top_proposal ----
-    lv = [synth.rpn_outputs(seed + i, 2, 3, h, w, st) for i, ((h, w), st) in
-          enumerate(zip(list(synth.FPN_SHAPES) + [(13, 21)], [4, 8, 16, 32, 64]))]
-    tl = [(T(c), T(b), T(i)) for c, b, i in lv]
+    if want("proposal_v3_fpn"):
+        lv = [synth.rpn_outputs(seed + i, 2, 3, h, w, st) for i, ((h, w), st) in
+              enumerate(zip(list(synth.FPN_SHAPES) + [(13, 21)], [4, 8, 16, 32, 64]))]
+        tl = [(T(c), T(b), T(i)) for c, b, i in lv]
 
-    def rpn_proposals():
-        outs = [ops.proposal_v3(c, b, i, 2000, 2000, 0.7, 0, (8,), (0.5, 1, 2), st)
-                for (c, b, i), st in zip(tl, [4, 8, 16, 32, 64])]
-        return ops.get_top_proposal(torch.cat([o[0] for o in outs], 1),
-                                    torch.cat([o[1] for o in outs], 1), 2000)
-    ms = _time_gpu(rpn_proposals, iters=10, warm=2)
-    res["proposal_v3_fpn"] = {"ms": ms, "images_per_s": 2 / ms * 1e3,
-                              "config": "B=2, P2-P6, 267k anchors/img, pre/post 2000 per level + top 2000"}
-    if orc:
-        c, b, i = lv[2]
-        t = _time_cpu(lambda: orc.proposal_v3(c, b, i, 2000, 2000, 0.7, 0, (8,), (0.5, 1, 2), 16),
-                      min_s=0.3, max_iter=5)
-        res["proposal_v3_fpn"]["cpu_ms_p4_level_only"] = t
+        def rpn_proposals():
+            outs = [ops.proposal_v3(c, b, i, 2000, 2000, 0.7, 0, (8,), (0.5, 1, 2), st)
+                    for (c, b, i), st in zip(tl, [4, 8, 16, 32, 64])]
+            return ops.get_top_proposal(torch.cat([o[0] for o in outs], 1),
+                                        torch.cat([o[1] for o in outs], 1), 2000)
+        ms = _time_gpu(rpn_proposals, iters=10, warm=2)
+        res["proposal_v3_fpn"] = {"ms": ms, "images_per_s": 2 / ms * 1e3,
+                                  "config": "B=2, P2-P6, 267k anchors/img, pre/post 2000 per level + top 2000"}
+        if orc:
+            c, b, i = lv[2]
+            t = _time_cpu(lambda: orc.proposal_v3(c, b, i, 2000, 2000, 0.7, 0, (8,), (0.5, 1, 2), 16),
+                          min_s=0.3, max_iter=5)
+            res["proposal_v3_fpn"]["cpu_ms_p4_level_only"] = t
 
     # ---- batched soft-NMS: 16 images x 80 classes x 1000 boxes (BASELINE configs[2]) ----
-    P, n = 16 * 80, 1000
-    base = np.stack([synth.nms_dets(seed + 100 + i, n) for i in range(16)])
-    sd = np.repeat(base, 80, axis=0)
-    sd[:, :, 4] *= np.linspace(0.5, 1.0, P, dtype=np.float32)[:, None]  # distinct problems
-    tsd = T(sd)
-    ms = _time_gpu(lambda: ops.soft_nms_batched(tsd, None, 0.5, 0.5, 0.001, 1), iters=5, warm=1)
-    res["soft_nms"] = {"ms": ms, "problems": P, "boxes": n, "problems_per_s": P / ms * 1e3,
-                       "config": "1280 problems x 1000 boxes, linear, Nt 0.5, thr 0.001"}
-    if orc:
-        t = _time_cpu(lambda: orc.soft_nms(sd[0], 0.5, 0.5, 0.001, 1), min_s=0.3)
-        res["soft_nms"]["cpu_ms_per_problem"] = t
-        res["soft_nms"]["cpu_problems_per_s_1core"] = 1e3 / t
-        try:  # the reference's own Cython soft_nms (oracle/_ref, built from /root/reference)
-            from oracle._ref import cpu_nms as _ref_nms
-            t0 = time.perf_counter()
-            for q in range(2):
-                _ref_nms.soft_nms(sd[q], np.float32(0.5), np.float32(0.5), np.float32(0.001), np.uint8(1))
-            res["soft_nms"]["reference_cython_ms_per_problem"] = (time.perf_counter() - t0) * 1e3 / 2
-        except Exception:
-            pass
+    if want("soft_nms"):
+        P, n = 16 * 80, 1000
+        base = np.stack([synth.nms_dets(seed + 100 + i, n) for i in range(16)])
+        sd = np.repeat(base, 80, axis=0)
+        sd[:, :, 4] *= np.linspace(0.5, 1.0, P, dtype=np.float32)[:, None]  # distinct problems
+        tsd = T(sd)
+        ms = _time_gpu(lambda: ops.soft_nms_batched(tsd, None, 0.5, 0.5, 0.001, 1), iters=5, warm=1)
+        res["soft_nms"] = {"ms": ms, "problems": P, "boxes": n, "problems_per_s": P / ms * 1e3,
+                           "config": "1280 problems x 1000 boxes, linear, Nt 0.5, thr 0.001"}
+        if orc:
+            t = _time_cpu(lambda: orc.soft_nms(sd[0], 0.5, 0.5, 0.001, 1), min_s=0.3)
+            res["soft_nms"]["cpu_ms_per_problem"] = t
+            res["soft_nms"]["cpu_problems_per_s_1core"] = 1e3 / t
+            try:  # the reference's own Cython soft_nms (oracle/_ref, built from /root/reference)
+                from oracle._ref import cpu_nms as _ref_nms
+                t0 = time.perf_counter()
+                for q in range(2):
+                    _ref_nms.soft_nms(sd[q], np.float32(0.5), np.float32(0.5), np.float32(0.001), np.uint8(1))
+                res["soft_nms"]["reference_cython_ms_per_problem"] = (time.perf_counter() - t0) * 1e3 / 2
+            except Exception:
+                pass
 
     # ---- ROIPooling_v1: C4 map (2,1024,50,84), 1024 rois, 7x7 ----
-    rs = np.random.RandomState(seed)
-    data = torch.randn((2, 1024, 50, 84), device="cuda")
-    r = synth.random_rois(seed, 1, 1024)[0]
-    prois = T(np.concatenate([rs.randint(0, 2, (1024, 1)).astype(np.float32), r], 1))
-    o, idx = ops.roi_pool_v1_forward(data, prois, (7, 7), 1 / 16.0)
-    dy = torch.randn_like(o)
-    dx = torch.empty_like(data)
-    ms_f = _time_gpu(lambda: ops.roi_pool_v1_forward(data, prois, (7, 7), 1 / 16.0))
-    ms_b = _time_gpu(lambda: ops.roi_pool_v1_backward(dy, prois, idx, data.shape, 1 / 16.0, d_data=dx))
-    alg = 4 * data.numel() + 20 * 1024 + 2 * 4 * o.numel()
-    res["roi_pool_v1"] = {"fwd_ms": ms_f, "bwd_ms": ms_b, "algorithmic_bytes": alg,
-                          "fwd_GBs": alg / ms_f / 1e6, "fwd_frac": alg / ms_f / 1e6 / PEAK_HBM_GBS}
-    del data, o, idx, dy, dx
+    if want("roi_pool_v1"):
+        rs = np.random.RandomState(seed)
+        data = torch.randn((2, 1024, 50, 84), device="cuda")
+        r = synth.random_rois(seed, 1, 1024)[0]
+        prois = T(np.concatenate([rs.randint(0, 2, (1024, 1)).astype(np.float32), r], 1))
+        o, idx = ops.roi_pool_v1_forward(data, prois, (7, 7), 1 / 16.0)
+        dy = torch.randn_like(o)
+        dx = torch.empty_like(data)
+        ms_f = _time_gpu(lambda: ops.roi_pool_v1_forward(data, prois, (7, 7), 1 / 16.0))
+        ms_b = _time_gpu(lambda: ops.roi_pool_v1_backward(dy, prois, idx, data.shape, 1 / 16.0, d_data=dx))
+        alg = 4 * data.numel() + 20 * 1024 + 2 * 4 * o.numel()
+        res["roi_pool_v1"] = {"fwd_ms": ms_f, "bwd_ms": ms_b, "algorithmic_bytes": alg,
+                              "fwd_GBs": alg / ms_f / 1e6, "fwd_frac": alg / ms_f / 1e6 / PEAK_HBM_GBS}
+        del data, o, idx, dy, dx
 
     # ---- DeformableConvolution: x (16,256,50,84), 3x3, dg 4, F 256 ----
-    N, C, H, W, F = 16, 256, 50, 84, 256
-    x = torch.randn((N, C, H, W), device="cuda")
-    off = torch.randn((N, 72, H, W), device="cuda") * 2
-    wt = torch.randn((F, C, 3, 3), device="cuda") * 0.05
-    ms_i = _time_gpu(lambda: ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
-    ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=5, warm=1)
-    y = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)
-    dyc = torch.randn_like(y)
-    grads = (torch.empty_like(x), torch.empty_like(off), torch.empty_like(wt))
-    ms_b = _time_gpu(lambda: ops.deform_conv_backward(dyc, x, off, wt, 1, 1, 1, 4, grads=grads),
-                     iters=3, warm=1)
-    P_ = H * W
-    im2col_bytes = N * (4 * (C + 72) * P_ + 4 * 9 * C * P_)
-    flops = 2.0 * N * F * 9 * C * P_
-    gemm_ms = max(ms_f - ms_i, 1e-6)
-    res["deform_conv"] = {
-        "im2col_ms": ms_i, "im2col_GBs": im2col_bytes / ms_i / 1e6,
-        "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
-        "fwd_ms": ms_f, "bwd_ms": ms_b, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
-        "gemm_frac_of_f32_mfma_peak": flops / gemm_ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
-        "config": "x (16,256,50,84), 3x3 pad 1, 4 deformable groups, 256 filters, fp32"}
+    if want("deform_conv"):
+        N, C, H, W, F = 16, 256, 50, 84, 256
+        x = torch.randn((N, C, H, W), device="cuda")
+        off = torch.randn((N, 72, H, W), device="cuda") * 2
+        wt = torch.randn((F, C, 3, 3), device="cuda") * 0.05
+        ms_i = _time_gpu(lambda: ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
+        ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=5, warm=1)
+        y = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)
+        dyc = torch.randn_like(y)
+        grads = (torch.empty_like(x), torch.empty_like(off), torch.empty_like(wt))
+        ms_b = _time_gpu(lambda: ops.deform_conv_backward(dyc, x, off, wt, 1, 1, 1, 4, grads=grads),
+                         iters=3, warm=1)
+        colm = ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4)
+        ms_c2i = _time_gpu(lambda: ops.deform_col2im(colm, off, x.shape, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
+        ms_crd = _time_gpu(lambda: ops.deform_col2im_coord(colm, x, off, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
+        del colm
+        P_ = H * W
+        im2col_bytes = N * (4 * (C + 72) * P_ + 4 * 9 * C * P_)
+        flops = 2.0 * N * F * 9 * C * P_
+        gemm_ms = max(ms_f - ms_i, 1e-6)
+        res["deform_conv"] = {
+            "im2col_ms": ms_i, "im2col_GBs": im2col_bytes / ms_i / 1e6,
+            "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
+            "col2im_ms": ms_c2i, "col2im_coord_ms": ms_crd,
+            "fwd_ms": ms_f, "bwd_ms": ms_b, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
+            "gemm_frac_of_f32_mfma_peak": flops / gemm_ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
+            "config": "x (16,256,50,84), 3x3 pad 1, 4 deformable groups, 256 filters, fp32"}
     return res

@@ -162,13 +162,17 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
     const float offset_w = off[(long)(2 * tap + 1) * P + p];
     const float cur_inv_h_data = h_in + i * g.dil_h + offset_h;
     const float cur_inv_w_data = w_in + j * g.dil_w + offset_w;
-    const int cur_h = (int)cur_inv_h_data, cur_w = (int)cur_inv_w_data;
+    const int cur_h = (int)cur_inv_h_data;
     // quick reject: every touched row lies in [cur_h - 1, cur_h + 1]
     if (cur_h + 1 < row0 || cur_h - 1 >= row1) continue;
     const float cur_top_grad = cp[idx];
-    for (int dy = -2; dy <= 2; dy++)
-      for (int dxx = -2; dxx <= 2; dxx++) {
-        const int hh = cur_h + dy, ww = cur_w + dxx;
+    // The reference walks the 5x5 neighbourhood of (cur_h, cur_w) and keeps the pixels with
+    // |inv_h - hh| < 1 and |inv_w - ww| < 1: those are floor() and floor() + 1 of each coordinate
+    // (both always inside the 5x5 window), so only these four are visited.
+    const int fh = (int)floorf(cur_inv_h_data), fw = (int)floorf(cur_inv_w_data);
+    for (int dy = 0; dy <= 1; dy++)
+      for (int dxx = 0; dxx <= 1; dxx++) {
+        const int hh = fh + dy, ww = fw + dxx;
         if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W && fabsf(cur_inv_h_data - hh) < 1 &&
             fabsf(cur_inv_w_data - ww) < 1) {
           const float w = get_gradient_weight(cur_inv_h_data, cur_inv_w_data, hh, ww, g.H, g.W);
@@ -250,6 +254,242 @@ __global__ __launch_bounds__(256) void deform_col2im_coord_kernel(const float* _
   }
   float* out = doff + ((long)n * g.dgroup * 2 * K2 + c_off) * P + p;
   *out = req_add ? *out + val : val;
+}
+
+
+// ---- LDS-plane variants (the default when a channel plane fits in LDS and kh*kw <= 9) ----------
+// The gathers are the expensive part of the per-lane kernels above (4 scattered 4-byte loads per
+// col element through the vector L1).  Here a workgroup owns (image, deformable group, tile of T
+// output pixels): every lane computes the sampling state of its pixel's kh*kw taps ONCE (packed
+// corner index + the four bilinear weights, kept in registers for all channels), then the
+// workgroup walks the group's channels: the channel plane is copied to LDS with coalesced 16-byte
+// loads and each lane takes its 4 corners per tap from LDS.  x is read from HBM/L2 in full lines,
+// the col stores stay contiguous along the pixel axis, and the bilinear expression is evaluated in
+// the same order as before (bit-identical col).
+constexpr int kDcnMaxTaps = 9;
+
+__device__ __forceinline__ void dcn_stage_plane(float* xs, const float* __restrict__ xp, int plane,
+                                                bool vec, int tid, int T) {
+  if (vec) {
+    const float4* s4 = reinterpret_cast<const float4*>(xp);
+    float4* d4 = reinterpret_cast<float4*>(xs);
+    for (int i = tid; i < plane / 4; i += T) d4[i] = s4[i];
+  } else {
+    for (int i = tid; i < plane; i += T) xs[i] = xp[i];
+  }
+}
+
+// packed corner state: bits 0-27 index of (h_low, w_low), bit 28 w_high - w_low, bit 29
+// h_high - h_low, bit 30 "inside the image"; 0 = outside (reads corner 0, contributes exactly 0)
+constexpr int kDcnInside = 1 << 30;
+__device__ __forceinline__ int dcn_pack(bool ok, int h_low, int w_low, int h_high, int w_high,
+                                        int W) {
+  if (!ok) return 0;
+  return (h_low * W + w_low) | ((w_high - w_low) << 28) | ((h_high - h_low) << 29) | kDcnInside;
+}
+
+// The four corners of a packed sample from the staged plane: two adjacent-pair LDS reads (the
+// compiler fuses each pair into one ds_read2_b32) and selects for the clamped border cases, where
+// the reference reads the low corner again.  The unused neighbour may lie past the staged plane
+// (the launch pads the LDS buffer by W + 1 floats); it is discarded by the select.
+struct Corners {
+  float x1, x2, x3, x4;
+};
+__device__ __forceinline__ Corners dcn_corners(const float* xs, int in, int W) {
+  const int o1 = in & 0xfffffff;
+  const float a = xs[o1], b = xs[o1 + 1];
+  const float c = xs[o1 + W], d = xs[o1 + W + 1];
+  const bool dw = (in >> 28) & 1, dh = (in >> 29) & 1;
+  Corners r;
+  r.x1 = a;
+  r.x2 = dw ? b : a;
+  r.x3 = dh ? c : a;
+  r.x4 = dh ? (dw ? d : c) : r.x2;
+  return r;
+}
+
+// grid: x = pixel tiles, y = group * nsplit + channel split, z = image.  NT = kh*kw when known at
+// compile time (9 for the reference's 3x3 layers), 0 = run-time tap count <= kDcnMaxTaps
+template <int T, int NT>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                              float* __restrict__ col, DcnGeom g, int nsplit, int vec, int nt) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const int P = g.Ho * g.Wo, K2 = NT ? NT : g.kh * g.kw, plane = g.H * g.W;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x * T + tid;
+  const bool live = p < P;
+  const int grp = blockIdx.y / nsplit, cs = blockIdx.y % nsplit;
+  const int n = blockIdx.z;
+  const int cpg = g.C / g.dgroup;
+  const int cchunk = (cpg + nsplit - 1) / nsplit;
+  const int c0 = cs * cchunk, c1 = iminr(c0 + cchunk, cpg);
+  int info[kDcnMaxTaps];
+  float w1[kDcnMaxTaps], w2[kDcnMaxTaps], w3[kDcnMaxTaps], w4[kDcnMaxTaps];
+  {
+    const int h_col = live ? p / g.Wo : 0, w_col = live ? p % g.Wo : 0;
+    const int h_in = h_col * g.stride_h - g.pad_h, w_in = w_col * g.stride_w - g.pad_w;
+    const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P + (live ? p : 0);
+    float oh[kDcnMaxTaps], ow[kDcnMaxTaps];
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) {  // all offset loads in flight together
+      oh[tap] = ow[tap] = 0.f;
+      if (tap < K2) {
+        oh[tap] = off[(long)(2 * tap) * P];
+        ow[tap] = off[(long)(2 * tap + 1) * P];
+      }
+    }
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
+      info[tap] = 0;
+      w1[tap] = w2[tap] = w3[tap] = w4[tap] = 0.f;
+      if (tap < K2) {
+        const Sample s = im2col_sample(g, h_in, w_in, tap / g.kw, tap % g.kw, oh[tap], ow[tap]);
+        info[tap] = dcn_pack(s.ok && live, s.h_low, s.w_low, s.h_high, s.w_high, g.W);
+        w1[tap] = s.w1; w2[tap] = s.w2; w3[tap] = s.w3; w4[tap] = s.w4;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one tap's temporaries at a time (register pressure)
+    }
+  }
+  for (int c = c0; c < c1; ++c) {
+    const long ch = (long)n * g.C + (long)grp * cpg + c;
+    __syncthreads();  // the previous channel's readers are done
+    dcn_stage_plane(xs, x + ch * plane, plane, vec != 0, tid, T);
+    __syncthreads();
+    float* out = col + ch * K2 * P;  // wave-uniform base + 32-bit lane offset
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
+      if (tap < K2) {
+        asm volatile("" : "+v"(info[tap]));  // keep the unpacking inside the loop (registers)
+        const int in = info[tap];
+        const Corners q = dcn_corners(xs, in, g.W);
+        float val = (w1[tap] * q.x1 + w2[tap] * q.x2 + w3[tap] * q.x3 + w4[tap] * q.x4);
+        if (!(in & kDcnInside)) val = 0.f;
+        if (live) {
+          if (nt) __builtin_nontemporal_store(val, out + (tap * P + p));
+          else out[tap * P + p] = val;
+        }
+      }
+    }
+  }
+}
+
+// Offset gradient with the same ownership: both directions of a tap share the four corner values,
+// the sum over the group's channels runs in registers in ascending channel order (as the per-lane
+// kernel and the reference do).  grid: x = pixel tiles, y = group, z = image
+template <int T, int NT>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void deform_col2im_coord_lds_kernel(const float* __restrict__ col, const float* __restrict__ x,
+                                    const float* __restrict__ offset, float* __restrict__ doff,
+                                    DcnGeom g, int req_add, int vec) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const int P = g.Ho * g.Wo, K2 = NT ? NT : g.kh * g.kw, plane = g.H * g.W;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x * T + tid;
+  const bool live = p < P;
+  const int grp = blockIdx.y, n = blockIdx.z;
+  const int cpg = g.C / g.dgroup;
+  int info[kDcnMaxTaps];
+  // (wl + 1 - aw) == 1 - (aw - wl) bit for bit (aw - wl is exact, both are one rounding of the
+  // same real number), so only the two fractions are kept per tap
+  float fb[kDcnMaxTaps], fd[kDcnMaxTaps];
+  float val_h[kDcnMaxTaps], val_w[kDcnMaxTaps];
+  {
+    const int h_out = live ? p / g.Wo : 0, w_out = live ? p % g.Wo : 0;
+    const int h_in = h_out * g.stride_h - g.pad_h, w_in = w_out * g.stride_w - g.pad_w;
+    const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P + (live ? p : 0);
+    float oh[kDcnMaxTaps], ow[kDcnMaxTaps];
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
+      oh[tap] = ow[tap] = 0.f;
+      if (tap < K2) {
+        oh[tap] = off[(long)(2 * tap) * P];
+        ow[tap] = off[(long)(2 * tap + 1) * P];
+      }
+    }
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
+      info[tap] = 0;
+      fb[tap] = fd[tap] = 0.f;
+      val_h[tap] = val_w[tap] = 0.f;
+      if (tap < K2) {
+        float inv_h = h_in + (tap / g.kw) * g.dil_h + oh[tap];
+        float inv_w = w_in + (tap % g.kw) * g.dil_w + ow[tap];
+        if (inv_h < 0 || inv_w < 0 || inv_h >= g.H || inv_w >= g.W) inv_h = inv_w = -1;
+        float argmax_h = inv_h, argmax_w = inv_w;
+        const bool zero = argmax_h < 0 || argmax_h > g.H || argmax_w < 0 || argmax_w > g.W;
+        int hl = (int)argmax_h, wl = (int)argmax_w, hh, wh;
+        if (hl >= g.H - 1) {
+          hh = hl = g.H - 1;
+          argmax_h = (float)hl;
+        } else {
+          hh = hl + 1;
+        }
+        if (wl >= g.W - 1) {
+          wh = wl = g.W - 1;
+          argmax_w = (float)wl;
+        } else {
+          wh = wl + 1;
+        }
+        info[tap] = dcn_pack(!zero && live, hl, wl, hh, wh, g.W);
+        fb[tap] = (argmax_w - wl);  // direction h: -(1 - fb), -fb, +(1 - fb), +fb
+        fd[tap] = (argmax_h - hl);  // direction w: -(1 - fd), +(1 - fd), -fd, +fd
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  for (int c = 0; c < cpg; ++c) {
+    const long ch = (long)n * g.C + (long)grp * cpg + c;
+    // the col values of this channel do not depend on the staged plane: issue their loads first
+    // so that their latency overlaps the staging
+    const float* cp = col + ch * K2 * P;  // wave-uniform base + 32-bit lane offset
+    const int pl = live ? p : 0;
+    float cv[kDcnMaxTaps];
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) cv[tap] = tap < K2 ? cp[tap * P + pl] : 0.f;
+    __syncthreads();
+    dcn_stage_plane(xs, x + ch * plane, plane, vec != 0, tid, T);
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
+      if (tap < K2) {
+        // opaque to the optimiser: otherwise every product / select derived from the per-tap
+        // state is hoisted out of the channel loop and the kernel spills
+        asm volatile("" : "+v"(info[tap]), "+v"(fb[tap]), "+v"(fd[tap]));
+        const int in = info[tap];
+        const Corners q = dcn_corners(xs, in, g.W);
+        const float x1 = q.x1, x2 = q.x2, x3 = q.x3, x4 = q.x4;
+        const float fa = 1 - fb[tap], fc = 1 - fd[tap];
+        float wh_ = 0;
+        wh_ += (-1 * fa) * x1;
+        wh_ += (-1 * fb[tap]) * x2;
+        wh_ += fa * x3;
+        wh_ += fb[tap] * x4;
+        float ww_ = 0;
+        ww_ += (-1 * fc) * x1;
+        ww_ += fc * x2;
+        ww_ += (-1 * fd[tap]) * x3;
+        ww_ += fd[tap] * x4;
+        if (in & kDcnInside) {
+          val_h[tap] += wh_ * cv[tap];
+          val_w[tap] += ww_ * cv[tap];
+        }
+      }
+      if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // three taps' corners in flight at most
+    }
+  }
+  if (live) {
+    float* out = doff + ((long)n * g.dgroup + grp) * 2 * K2 * P + p;
+#pragma unroll
+    for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
+      if (tap < K2) {
+        float* oh = out + (long)(2 * tap) * P;
+        float* ow = out + (long)(2 * tap + 1) * P;
+        *oh = req_add ? *oh + val_h[tap] : val_h[tap];
+        *ow = req_add ? *ow + val_w[tap] : val_w[tap];
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -442,8 +682,24 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
   if (N == 0) return SD_OK;
   SD_REQUIRE(x && offset && col, "null tensor pointer");
   const int P = g.Ho * g.Wo;
-  hipLaunchKernelGGL(deform_im2col_kernel, dim3(cdiv(P, 256), dgroup * kh * kw, N), dim3(256), 0,
-                     (hipStream_t)stream, x, offset, col, g);
+  const size_t lds = ((size_t)H * W + W + 1) * sizeof(float);
+  if (kh * kw <= kDcnMaxTaps && lds <= 64 * 1024 && (long)H * W < (1L << 28) &&
+      tuning("dcn_im2col", 1) == 1) {
+    constexpr int T = 256;
+    const int vec = ((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    const int nt = tuning("dcn_im2col_nt", 1);
+    int nsplit = tuning("dcn_im2col_split", 1);
+    if (nsplit < 1 || nsplit > C / dgroup) nsplit = 1;
+    if (kh * kw == 9)
+      hipLaunchKernelGGL((deform_im2col_lds_kernel<T, 9>), dim3(cdiv(P, T), dgroup * nsplit, N),
+                         dim3(T), lds, (hipStream_t)stream, x, offset, col, g, nsplit, vec, nt);
+    else
+      hipLaunchKernelGGL((deform_im2col_lds_kernel<T, 0>), dim3(cdiv(P, T), dgroup * nsplit, N),
+                         dim3(T), lds, (hipStream_t)stream, x, offset, col, g, nsplit, vec, nt);
+  } else {
+    hipLaunchKernelGGL(deform_im2col_kernel, dim3(cdiv(P, 256), dgroup * kh * kw, N), dim3(256), 0,
+                       (hipStream_t)stream, x, offset, col, g);
+  }
   SD_LAUNCH_CHECK();
   return SD_OK;
 }
@@ -488,9 +744,23 @@ extern "C" int sd_deform_col2im_coord(const float* col, const float* x, const fl
   if (N == 0 || req == SD_REQ_NULL) return SD_OK;
   SD_REQUIRE(col && x && offset && d_offset, "null tensor pointer");
   const int P = g.Ho * g.Wo;
-  hipLaunchKernelGGL(deform_col2im_coord_kernel, dim3(cdiv(P, 256), dgroup * 2 * kh * kw, N),
-                     dim3(256), 0, (hipStream_t)stream, col, x, offset, d_offset, g,
-                     req == SD_REQ_ADD ? 1 : 0);
+  const size_t lds = ((size_t)H * W + W + 1) * sizeof(float);
+  if (kh * kw <= kDcnMaxTaps && lds <= 64 * 1024 && (long)H * W < (1L << 28) &&
+      tuning("dcn_coord", 1) == 1) {
+    constexpr int T = 256;
+    const int vec = ((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    if (kh * kw == 9)
+      hipLaunchKernelGGL((deform_col2im_coord_lds_kernel<T, 9>), dim3(cdiv(P, T), dgroup, N),
+                         dim3(T), lds, (hipStream_t)stream, col, x, offset, d_offset, g,
+                         req == SD_REQ_ADD ? 1 : 0, vec);
+    else
+      hipLaunchKernelGGL((deform_col2im_coord_lds_kernel<T, 0>), dim3(cdiv(P, T), dgroup, N),
+                         dim3(T), lds, (hipStream_t)stream, col, x, offset, d_offset, g,
+                         req == SD_REQ_ADD ? 1 : 0, vec);
+  } else
+    hipLaunchKernelGGL(deform_col2im_coord_kernel, dim3(cdiv(P, 256), dgroup * 2 * kh * kw, N),
+                       dim3(256), 0, (hipStream_t)stream, col, x, offset, d_offset, g,
+                       req == SD_REQ_ADD ? 1 : 0);
   SD_LAUNCH_CHECK();
   return SD_OK;
 }

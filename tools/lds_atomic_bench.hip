@@ -12,12 +12,27 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int span) {
   unsigned x = threadIdx.x * 2654435761u + blockIdx.x;
   for (int i = 0; i < iters; ++i) {
     x = x * 1664525u + 1013904223u;
-    int idx = (x >> 8) % span;
+    int idx = (x >> 8) & (span - 1);  // span is a power of two: keep the loop LDS- not VALU-bound
     if (MODE == 0) __hip_atomic_fetch_add(&bf[idx], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if (MODE == 1) __hip_atomic_fetch_add(&bu[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if (MODE == 2) __hip_atomic_fetch_add(&buf64[idx >> 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if (MODE == 3) bf[idx] += 1.0f;
     else if (MODE == 4) __hip_atomic_fetch_max(&bu[idx], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if (MODE == 5) {  // the float CAS add the RoIAlign / DCN backward planes use
+      int* ip = reinterpret_cast<int*>(&bf[idx]);
+      int old = *ip;
+      while (true) {
+        const int assumed = old;
+        old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + 1.0f));
+        if (old == assumed) break;
+      }
+    } else if (MODE == 6) {  // 64-bit fixed point: float -> int64 conversion + ds_add_u64
+      const float v = __int_as_float(0x3f800000 | (x & 0x7fffff));
+      __hip_atomic_fetch_add(&buf64[idx >> 1], (unsigned long long)(long long)(v * 1048576.f),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (MODE == 7) {  // returning integer add (latency exposed)
+      x += __hip_atomic_fetch_add(&bu[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   __syncthreads();
   float s = 0;
@@ -46,6 +61,9 @@ int main() {
     run<2>("ds_add_u64", span);
     run<3>("plain rmw f32", span);
     run<4>("ds_max_u32", span);
+    run<5>("cas add f32", span);
+    run<6>("cvt + add_u64", span);
+    run<7>("ds_add_rtn_u32", span);
   }
   return 0;
 }
