@@ -308,6 +308,49 @@ __device__ __forceinline__ Corners dcn_corners(const float* xs, int in, int W) {
   return r;
 }
 
+// The part of a channel plane this workgroup's samples can touch: the contiguous float range
+// [min first corner, max last corner] over all inside taps of all lanes (exact, whatever the
+// offsets are: wild offsets simply widen it to the whole plane).  Only that range is staged per
+// channel -- with offsets of a few pixels a 256-pixel tile needs ~1/3 of a 50x84 plane.  The packed
+// corner indices are rebased to the start of the range (a multiple of 4 floats when the 16-byte
+// path is used).  rng: two ints of LDS.
+__device__ __forceinline__ void dcn_window(int (&info)[kDcnMaxTaps], int W, int plane, bool vec,
+                                           int* rng, int tid, int& start, int& count) {
+  if (tid == 0) {
+    rng[0] = 0x7fffffff;
+    rng[1] = -1;
+  }
+  __syncthreads();
+  int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+  for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
+    const int in = info[tap];
+    if (in & kDcnInside) {
+      const int o1 = in & 0xfffffff;
+      lo = iminr(lo, o1);
+      hi = imaxr(hi, o1 + (((in >> 29) & 1) ? W : 0) + ((in >> 28) & 1));
+    }
+  }
+  if (hi >= 0) {
+    atomicMin(&rng[0], lo);
+    atomicMax(&rng[1], hi);
+  }
+  __syncthreads();
+  lo = rng[0];
+  hi = rng[1];
+  if (hi < 0) {
+    start = 0;
+    count = 0;
+    return;
+  }
+  start = vec ? (lo & ~3) : lo;
+  const int end = vec ? iminr((hi + 4) & ~3, plane) : hi + 1;
+  count = end - start;
+#pragma unroll
+  for (int tap = 0; tap < kDcnMaxTaps; ++tap)
+    if (info[tap] & kDcnInside) info[tap] -= start;
+}
+
 // grid: x = pixel tiles, y = group * nsplit + channel split, z = image.  NT = kh*kw when known at
 // compile time (9 for the reference's 3x3 layers), 0 = run-time tap count <= kDcnMaxTaps
 template <int T, int NT>
@@ -351,10 +394,13 @@ void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restri
       __builtin_amdgcn_sched_barrier(0);  // one tap's temporaries at a time (register pressure)
     }
   }
+  int wstart, wcount;
+  dcn_window(info, g.W, plane, vec != 0, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart,
+             wcount);
   for (int c = c0; c < c1; ++c) {
     const long ch = (long)n * g.C + (long)grp * cpg + c;
     __syncthreads();  // the previous channel's readers are done
-    dcn_stage_plane(xs, x + ch * plane, plane, vec != 0, tid, T);
+    dcn_stage_plane(xs, x + ch * plane + wstart, wcount, vec != 0, tid, T);
     __syncthreads();
     float* out = col + ch * K2 * P;  // wave-uniform base + 32-bit lane offset
 #pragma unroll
@@ -438,6 +484,9 @@ void deform_col2im_coord_lds_kernel(const float* __restrict__ col, const float* 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  int wstart, wcount;
+  dcn_window(info, g.W, plane, vec != 0, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart,
+             wcount);
   for (int c = 0; c < cpg; ++c) {
     const long ch = (long)n * g.C + (long)grp * cpg + c;
     // the col values of this channel do not depend on the staged plane: issue their loads first
@@ -448,7 +497,7 @@ void deform_col2im_coord_lds_kernel(const float* __restrict__ col, const float* 
 #pragma unroll
     for (int tap = 0; tap < kDcnMaxTaps; ++tap) cv[tap] = tap < K2 ? cp[tap * P + pl] : 0.f;
     __syncthreads();
-    dcn_stage_plane(xs, x + ch * plane, plane, vec != 0, tid, T);
+    dcn_stage_plane(xs, x + ch * plane + wstart, wcount, vec != 0, tid, T);
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
@@ -682,7 +731,7 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
   if (N == 0) return SD_OK;
   SD_REQUIRE(x && offset && col, "null tensor pointer");
   const int P = g.Ho * g.Wo;
-  const size_t lds = ((size_t)H * W + W + 1) * sizeof(float);
+  const size_t lds = ((size_t)H * W + W + 8) * sizeof(float);
   if (kh * kw <= kDcnMaxTaps && lds <= 64 * 1024 && (long)H * W < (1L << 28) &&
       tuning("dcn_im2col", 1) == 1) {
     constexpr int T = 256;
@@ -744,7 +793,7 @@ extern "C" int sd_deform_col2im_coord(const float* col, const float* x, const fl
   if (N == 0 || req == SD_REQ_NULL) return SD_OK;
   SD_REQUIRE(col && x && offset && d_offset, "null tensor pointer");
   const int P = g.Ho * g.Wo;
-  const size_t lds = ((size_t)H * W + W + 1) * sizeof(float);
+  const size_t lds = ((size_t)H * W + W + 8) * sizeof(float);
   if (kh * kw <= kDcnMaxTaps && lds <= 64 * 1024 && (long)H * W < (1L << 28) &&
       tuning("dcn_coord", 1) == 1) {
     constexpr int T = 256;

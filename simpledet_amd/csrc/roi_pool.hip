@@ -2,11 +2,17 @@
 //   reference: operator_cxx/roi_pooling_v1.cu:48-113 (forward), :115-152 (backward scatter),
 //              roi_pooling_v1.cc:39-126 (CPU forward, same result), roi_pooling_v1-inl.h:70-133
 //              (pre-fill, req handling).
-// The op has no Python call site in the reference: it is kept API-complete and
-// simple.  forward: one wave per (roi, channel), lane = output bin, so the three tensors are
-// written with contiguous stores and the bins of one RoI share their cache lines; the roi
-// geometry is computed once per wave in registers.  backward: dX[argmax] += dY with hardware
-// fp32 atomics after an asynchronous zero-fill.
+// forward: one wave per (roi, channel), lane = output bin, so the three tensors are written with
+//   contiguous stores and the bins of one RoI share their cache lines; the RoI geometry is computed
+//   once per wave in registers.  The kernel is bound by the instruction count of the per-bin scan
+//   (~10 VALU per visited pixel; 435 M visits for 1024 RoIs x 1024 channels), not by memory: an
+//   LDS-window variant (coalesced staging, several channels in flight, channel-major XCD order) was
+//   measured at the same 0.7 ms and removed.
+// backward (roi_pool_bwd_lds_kernel): workgroup = (image, channel, row band) with the band of dX
+//   in LDS; the bins of the image's RoIs whose arg-max falls in the band are added with an LDS
+//   compare-and-swap and the band is written once: no zero-fill pass, no global atomics
+//   (1.71 -> 0.24 ms on the C4 shape).  roi_pool_bwd = 0 selects the reference structure
+//   (zero-fill + global atomics), also the fallback when the RoI list does not fit in LDS.
 #include "common.h"
 #include "../../include/simpledet_ops.h"
 #include <float.h>
@@ -100,6 +106,52 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(PoolBwdArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-plane backward
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pool_lds_add(float* p, float v) {
+  int* ip = reinterpret_cast<int*>(p);
+  int old = *ip;
+  while (true) {
+    const int assumed = old;
+    old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + v));
+    if (old == assumed) break;
+  }
+}
+
+// grid: x = channel, y = row band, z = image
+__global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(PoolBwdArgs a, int band_rows,
+                                                               int req_add) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = 512;
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x, b = blockIdx.z;
+  const int row0 = blockIdx.y * band_rows, row1 = iminr(row0 + band_rows, a.H);
+  const int band_elems = (row1 - row0) * a.W;
+  const int plane_pad = (band_elems + 3) & ~3;
+  float* plane = smem;
+  int* list = reinterpret_cast<int*>(smem + plane_pad);
+  int* nlist = list + a.K;
+  for (int i = tid; i < plane_pad; i += T) plane[i] = 0.f;
+  if (tid == 0) *nlist = 0;
+  __syncthreads();
+  for (int n = tid; n < a.K; n += T)
+    if ((int)a.rois[(long)n * 5] == b) list[atomicAdd(nlist, 1)] = n;
+  __syncthreads();
+  const int nitems = *nlist * a.PP;
+  const int lo = row0 * a.W, hi = row1 * a.W;
+  for (int it = tid; it < nitems; it += T) {
+    const int n = list[it / a.PP], bin = it % a.PP;
+    const long idx = ((long)n * a.C + c) * a.PP + bin;
+    const int argmax = (int)a.maxidx[idx];
+    if (argmax >= lo && argmax < hi) pool_lds_add(plane + (argmax - lo), a.dy[idx]);
+  }
+  __syncthreads();
+  float* dst = a.dx + (((long)b * a.C + c) * a.H + row0) * a.W;
+  for (int i = tid; i < band_elems; i += T) dst[i] = req_add ? dst[i] + plane[i] : plane[i];
+}
+
 }  // namespace sd
 
 using namespace sd;
@@ -136,14 +188,31 @@ extern "C" int sd_roi_pool_v1_bwd(const float* out_grad, const float* rois, cons
   const size_t dx_bytes = (size_t)B * C * H * W * sizeof(float);
   if (req_data != SD_REQ_NULL && dx_bytes) {
     SD_REQUIRE(d_data, "d_data is null");
-    if (req_data == SD_REQ_WRITE) SD_HIP_CHECK(hipMemsetAsync(d_data, 0, dx_bytes, st));
     const long count = (long)K * C * pooled_h * pooled_w;
-    if (count) {
-      SD_REQUIRE(out_grad && rois && maxidx, "null tensor pointer");
-      PoolBwdArgs a{out_grad, rois, maxidx, d_data, B, C, H, W, K, pooled_h * pooled_w};
-      const int grid = (int)((count + 255) / 256 < kNumCU * 32 ? (count + 255) / 256 : kNumCU * 32);
-      hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+    SD_REQUIRE(count == 0 || (out_grad && rois && maxidx), "null tensor pointer");
+    PoolBwdArgs a{out_grad, rois, maxidx, d_data, B, C, H, W, K, pooled_h * pooled_w};
+    // row bands of at most 36 KB so that four workgroups share a CU
+    const long budget = 36 * 1024;
+    int nb = (int)(((long)H * W * 4 + budget - 1) / budget);
+    if (nb < 1) nb = 1;
+    int rows = (H + nb - 1) / nb;
+    nb = (H + rows - 1) / rows;
+    const size_t lds = (size_t)((((long)rows * W + 3) & ~3L) * 4) + (size_t)(K + 4) * 4;
+    if (lds <= 150 * 1024 && C <= 65535 * 32 && nb <= 65535 && B <= 65535 &&
+        tuning("roi_pool_bwd", 1) == 1) {
+      if (lds > 64 * 1024)
+        SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_pool_bwd_lds_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(roi_pool_bwd_lds_kernel, dim3(C, nb, B), dim3(512), lds, st, a, rows,
+                         req_data == SD_REQ_ADD ? 1 : 0);
       SD_LAUNCH_CHECK();
+    } else {
+      if (req_data == SD_REQ_WRITE) SD_HIP_CHECK(hipMemsetAsync(d_data, 0, dx_bytes, st));
+      if (count) {
+        const int grid = (int)((count + 255) / 256 < kNumCU * 32 ? (count + 255) / 256 : kNumCU * 32);
+        hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+        SD_LAUNCH_CHECK();
+      }
     }
   }
   if (req_rois == SD_REQ_WRITE && K > 0) {  // roi_pooling_v1-inl.h:130-132
