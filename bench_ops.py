@@ -151,7 +151,7 @@ def run(seed=0, cpu=True, only=None):
         x = torch.randn((N, C, H, W), device="cuda")
         off = torch.randn((N, 72, H, W), device="cuda") * 2
         wt = torch.randn((F, C, 3, 3), device="cuda") * 0.05
-        ms_i = _time_gpu(lambda: ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
+        ms_i = _time_gpu(lambda: ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4), iters=20, warm=2)
         ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=5, warm=1)
         y = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)
         dyc = torch.randn_like(y)
@@ -159,8 +159,8 @@ def run(seed=0, cpu=True, only=None):
         ms_b = _time_gpu(lambda: ops.deform_conv_backward(dyc, x, off, wt, 1, 1, 1, 4, grads=grads),
                          iters=3, warm=1)
         colm = ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4)
-        ms_c2i = _time_gpu(lambda: ops.deform_col2im(colm, off, x.shape, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
-        ms_crd = _time_gpu(lambda: ops.deform_col2im_coord(colm, x, off, (3, 3), 1, 1, 1, 4), iters=5, warm=1)
+        ms_c2i = _time_gpu(lambda: ops.deform_col2im(colm, off, x.shape, (3, 3), 1, 1, 1, 4), iters=10, warm=2)
+        ms_crd = _time_gpu(lambda: ops.deform_col2im_coord(colm, x, off, (3, 3), 1, 1, 1, 4), iters=20, warm=2)
         del colm
         P_ = H * W
         im2col_bytes = N * (4 * (C + 72) * P_ + 4 * 9 * C * P_)

@@ -102,12 +102,14 @@ int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois, const float* 
                          int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
                          float roi_canonical_level, void* stream);
 /* The same fused op with the arg-max kept as ONE byte per output (row sample * 3 + column sample,
- * 255 = nothing pooled) plus a small per-RoI table of the sample coordinates
- * (coords: B*R x 2 x 3*pooled floats, 172 KB at the baseline) instead of two fp32 planes: the
- * arg-max is state between this op's own forward and backward, not part of the reference's graph
- * interface.  The backward looks the float coordinate up in the table, i.e. gets exactly the value
- * the float planes would have held.  Cuts the forward's writes from 3 to 1.25 planes and the
- * backward's reads likewise (7x7 and 14x14 pooling). */
+ * 255 = nothing pooled) plus a small per-RoI table (coords: B*R x 9*(pooled_h+pooled_w) 4-byte
+ * words, 516 KB at the baseline; per RoI: 3*(ph+pw) fp32 sample coordinates, then 3*(ph+pw) pairs
+ * {clamped neighbours lo | hi << 16, interpolation fraction} derived from them with the backward's
+ * own expressions) instead of two fp32 planes: the arg-max is state between this op's own forward
+ * and backward, not part of the reference's graph interface.  The backward looks the pair up, i.e.
+ * uses exactly the values the float planes would have produced, without floor / clamp / divide
+ * per gradient element.  Cuts the forward's writes from 3 to 1.25 planes and the backward's reads
+ * likewise (7x7 and 14x14 pooling).  coords must be 8-byte aligned. */
 int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_host,
                                 const int* Ws_host, const int* strides_host, int nlvl,
                                 const float* rois, float* out, uint8_t* argmax, float* coords, int B,

@@ -314,8 +314,13 @@ __device__ __forceinline__ Corners dcn_corners(const float* xs, int in, int W) {
 // channel -- with offsets of a few pixels a 256-pixel tile needs ~1/3 of a 50x84 plane.  The packed
 // corner indices are rebased to the start of the range (a multiple of 4 floats when the 16-byte
 // path is used).  rng: two ints of LDS.
-__device__ __forceinline__ void dcn_window(int (&info)[kDcnMaxTaps], int W, int plane, bool vec,
+__device__ __forceinline__ void dcn_window(int (&info)[kDcnMaxTaps], int W, int plane, int vec,
                                            int* rng, int tid, int& start, int& count) {
+  if (vec & 2) {  // A/B: stage whole planes
+    start = 0;
+    count = plane;
+    return;
+  }
   if (tid == 0) {
     rng[0] = 0x7fffffff;
     rng[1] = -1;
@@ -343,8 +348,8 @@ __device__ __forceinline__ void dcn_window(int (&info)[kDcnMaxTaps], int W, int 
     count = 0;
     return;
   }
-  start = vec ? (lo & ~3) : lo;
-  const int end = vec ? iminr((hi + 4) & ~3, plane) : hi + 1;
+  start = (vec & 1) ? (lo & ~3) : lo;
+  const int end = (vec & 1) ? iminr((hi + 4) & ~3, plane) : hi + 1;
   count = end - start;
 #pragma unroll
   for (int tap = 0; tap < kDcnMaxTaps; ++tap)
@@ -395,12 +400,12 @@ void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restri
     }
   }
   int wstart, wcount;
-  dcn_window(info, g.W, plane, vec != 0, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart,
+  dcn_window(info, g.W, plane, vec, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart,
              wcount);
   for (int c = c0; c < c1; ++c) {
     const long ch = (long)n * g.C + (long)grp * cpg + c;
     __syncthreads();  // the previous channel's readers are done
-    dcn_stage_plane(xs, x + ch * plane + wstart, wcount, vec != 0, tid, T);
+    dcn_stage_plane(xs, x + ch * plane + wstart, wcount, (vec & 1) != 0, tid, T);
     __syncthreads();
     float* out = col + ch * K2 * P;  // wave-uniform base + 32-bit lane offset
 #pragma unroll
@@ -485,7 +490,7 @@ void deform_col2im_coord_lds_kernel(const float* __restrict__ col, const float* 
     }
   }
   int wstart, wcount;
-  dcn_window(info, g.W, plane, vec != 0, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart,
+  dcn_window(info, g.W, plane, vec, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart,
              wcount);
   for (int c = 0; c < cpg; ++c) {
     const long ch = (long)n * g.C + (long)grp * cpg + c;
@@ -497,7 +502,7 @@ void deform_col2im_coord_lds_kernel(const float* __restrict__ col, const float* 
 #pragma unroll
     for (int tap = 0; tap < kDcnMaxTaps; ++tap) cv[tap] = tap < K2 ? cp[tap * P + pl] : 0.f;
     __syncthreads();
-    dcn_stage_plane(xs, x + ch * plane + wstart, wcount, vec != 0, tid, T);
+    dcn_stage_plane(xs, x + ch * plane + wstart, wcount, (vec & 1) != 0, tid, T);
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < kDcnMaxTaps; ++tap) {
@@ -735,7 +740,8 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
   if (kh * kw <= kDcnMaxTaps && lds <= 64 * 1024 && (long)H * W < (1L << 28) &&
       tuning("dcn_im2col", 1) == 1) {
     constexpr int T = 256;
-    const int vec = ((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    const int vec = (((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0) |
+                    (tuning("dcn_window", 1) ? 0 : 2);
     const int nt = tuning("dcn_im2col_nt", 1);
     int nsplit = tuning("dcn_im2col_split", 1);
     if (nsplit < 1 || nsplit > C / dgroup) nsplit = 1;
@@ -797,7 +803,8 @@ extern "C" int sd_deform_col2im_coord(const float* col, const float* x, const fl
   if (kh * kw <= kDcnMaxTaps && lds <= 64 * 1024 && (long)H * W < (1L << 28) &&
       tuning("dcn_coord", 1) == 1) {
     constexpr int T = 256;
-    const int vec = ((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    const int vec = (((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0) |
+                    (tuning("dcn_window", 1) ? 0 : 2);
     if (kh * kw == 9)
       hipLaunchKernelGGL((deform_col2im_coord_lds_kernel<T, 9>), dim3(cdiv(P, T), dgroup, N),
                          dim3(T), lds, (hipStream_t)stream, col, x, offset, d_offset, g,

@@ -239,6 +239,10 @@ __device__ __forceinline__ int axis_samples(int p, int pooled, float start_c, fl
   return cnt;
 }
 
+// words of fwd->bwd state per RoI and per pooled row/column: 3 sample coordinates + 3 (packed
+// neighbours, fraction) pairs; layout per RoI: [3*(PH+PW) coordinates | 3*(PH+PW) pairs]
+constexpr int kCoordWords = 9;
+
 // coordinate of sample k of axis bin p: the same float expressions as axis_samples / the
 // reference loop (start + stride, then += max(stride, 0.01f) per further sample), so a packed
 // arg-max (k, l) decodes to exactly the float the forward would have stored
@@ -259,6 +263,24 @@ __device__ __forceinline__ float sample_coord(int p, int pooled, float start_c, 
   return v;
 }
 
+// Backward-ready form of one table coordinate: the two clamped neighbour indices packed as
+// lo | hi << 16 (-1: the coordinate is the "nothing pooled" sentinel) and the interpolation
+// fraction, computed with exactly the expressions of the backward (floor / ceil / clamp,
+// (v - lo) / (hi - lo), 0.5 when lo == hi).  The backward of the packed path then needs no
+// floor, ceil, clamp or division per gradient element.
+__device__ __forceinline__ void store_tap(float* dst, float v, int size) {
+  int packed = -1;
+  float frac = 0.f;
+  if (v != -1.f) {
+    const int lo = iminr(imaxr((int)floorf(v), 0), size - 1);
+    const int hi = iminr(imaxr((int)ceilf(v), 0), size - 1);
+    frac = (lo == hi) ? 0.5f : (v - (float)lo) / (float)(hi - lo);
+    packed = lo | (hi << 16);
+  }
+  reinterpret_cast<int*>(dst)[0] = packed;
+  dst[1] = frac;
+}
+
 // sample-coordinate table of the packed arg-max: coords[roi][0][p*3 + k] = row coordinate of sample
 // k of bin row p, coords[roi][1][q*3 + l] = column coordinate (2 * 3 * P floats per RoI)
 __global__ __launch_bounds__(64) void roi_coords_kernel(const float* rois, int nroi, RoiLevels L,
@@ -268,11 +290,18 @@ __global__ __launch_bounds__(64) void roi_coords_kernel(const float* rois, int n
   int lvl = 0;
   if (L.nlvl > 1) lvl = fpn_level(r[0], r[1], r[2], r[3], L);
   if (lvl < 0) return;
-  float* c = coords + (long)n * 3 * (PH + PW);
-  for (int e = lane; e < 3 * PH; e += 64)
-    c[e] = sample_coord(e / 3, PH, r[1], r[3], L.scale[lvl], L.H[lvl], e % 3);
-  for (int e = lane; e < 3 * PW; e += 64)
-    c[3 * PH + e] = sample_coord(e / 3, PW, r[0], r[2], L.scale[lvl], L.W[lvl], e % 3);
+  float* c = coords + (long)n * kCoordWords * (PH + PW);
+  float* taps = c + 3 * (PH + PW);
+  for (int e = lane; e < 3 * PH; e += 64) {
+    const float v = sample_coord(e / 3, PH, r[1], r[3], L.scale[lvl], L.H[lvl], e % 3);
+    c[e] = v;
+    store_tap(taps + 2 * e, v, L.H[lvl]);
+  }
+  for (int e = lane; e < 3 * PW; e += 64) {
+    const float v = sample_coord(e / 3, PW, r[0], r[2], L.scale[lvl], L.W[lvl], e % 3);
+    c[3 * PH + e] = v;
+    store_tap(taps + 2 * (3 * PH + e), v, L.W[lvl]);
+  }
 }
 
 template <int PH, int PW, int NROI, bool PK>
@@ -379,7 +408,9 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
         v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
                 : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
       }
-      a.coords[(long)t.n * 3 * (PH + PW) + j] = v;
+      float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
+      base[j] = v;
+      store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
     }
   }
 
@@ -966,47 +997,89 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
   __syncthreads();
   int nitems = *nlist * PP;
   if (a.ablate & 1) nitems = 0;
-  const long roi_stride = (long)a.C * PP;
+  // wave-uniform bases + 32-bit lane offsets (the launcher checks R*C*PP < 2^31)
+  const int roi_stride = a.C * PP;
   const long img_base = (long)img * a.R * roi_stride + (long)c * PP;
+  const float* dyb = a.dy + img_base;
+  const float* axb = PK ? nullptr : a.ax + img_base;
+  const float* ayb = PK ? nullptr : a.ay + img_base;
+  const unsigned char* amb = PK ? a.amax8 + img_base : nullptr;
+  // packed path: the forward's (neighbours, fraction) pairs of this image's RoIs
+  const float* tapb =
+      PK ? a.coords + (long)img * a.R * kCoordWords * (PH + PW) + 3 * (PH + PW) : nullptr;
 
   for (int it0 = tid; it0 < nitems; it0 += U * THREADS) {
-    float vx[U], vy[U], vg[U];
+    // per item: packed (low | high << 16) neighbour rows / columns (< 0: nothing to add), the two
+    // interpolation fractions and the gradient
+    int py[U], px[U];
+    float fy[U], fx[U], vg[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       const int it = it0 + k * THREADS;
-      vx[k] = -1.f;
-      vy[k] = -1.f;
+      py[k] = -1;
+      px[k] = -1;
+      fy[k] = fx[k] = vg[k] = 0.f;
       if (it < nitems) {
         const int r = list[it / PP], bin = it % PP;
-        const long idx = img_base + (long)r * roi_stride + bin;
+        const int idx = r * roi_stride + bin;
         if (PK) {
-          const int code = a.amax8[idx];
+          const int code = amb[idx];
           if (code != 255) {
-            const float* ct = a.coords + ((long)img * a.R + r) * (3 * (PH + PW));
-            vy[k] = ct[(bin / PW) * 3 + code / 3];
-            vx[k] = ct[3 * PH + (bin % PW) * 3 + code % 3];
+            const float* tb = tapb + r * (kCoordWords * (PH + PW));
+            const float2 ey = *reinterpret_cast<const float2*>(tb + 2 * ((bin / PW) * 3 + code / 3));
+            const float2 ex =
+                *reinterpret_cast<const float2*>(tb + 2 * (3 * PH + (bin % PW) * 3 + code % 3));
+            py[k] = __float_as_int(ey.x);
+            fy[k] = ey.y;
+            px[k] = __float_as_int(ex.x);
+            fx[k] = ex.y;
           }
-        } else {
-          vx[k] = a.ax[idx];
-          vy[k] = a.ay[idx];
+        } else {  // float arg-max planes: only the loads here, the arithmetic after all of them
+          fx[k] = axb[idx];
+          fy[k] = ayb[idx];
+          py[k] = 0;
         }
-        vg[k] = a.dy[idx];
+        vg[k] = dyb[idx];
       }
     }
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-      const float a_x = vx[k], a_y = vy[k];
-      if (a_x != -1.f && a_y != -1.f) {
-        const float g = vg[k];
-        int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
-        int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
-        int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
-        int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
-        float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
-        float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
+      if (!PK && py[k] == 0) {
+        const float a_x = fx[k], a_y = fy[k];
+        py[k] = -1;
+        if (a_x != -1.f && a_y != -1.f) {
+          const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+          const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+          const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+          const int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+          fy[k] = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
+          fx[k] = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
+          py[k] = hlow | (hhigh << 16);
+          px[k] = wleft | (wright << 16);
+        }
+      }
+      if ((py[k] | px[k]) >= 0) {
+        const float g = vg[k], alpha = fy[k], beta = fx[k];
+        const int hlow = py[k] & 0xffff, hhigh = py[k] >> 16;
+        const int wleft = px[k] & 0xffff, wright = px[k] >> 16;
         const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
         const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
         const int o0 = (hlow - row0) * W, o1 = (hhigh - row0) * W;
+        if (a.ablate & 24) {  // profiling only: plain read-modify-write (8) / one store per item (16)
+          if (a.ablate & 8) {
+            if (hlow >= row0 && hlow < row1) {
+              plane[o0 + wleft] += w00;
+              plane[o0 + wright] += w01;
+            }
+            if (hhigh >= row0 && hhigh < row1) {
+              plane[o1 + wleft] += w10;
+              plane[o1 + wright] += w11;
+            }
+          } else if (hlow >= row0 && hlow < row1) {
+            plane[o0 + wleft] = w00 + w01 + w10 + w11;
+          }
+          continue;
+        }
         if (hlow >= row0 && hlow < row1) {
           lds_add_cas(plane + o0 + wleft, w00);
           lds_add_cas(plane + o0 + wright, w01);
@@ -1045,8 +1118,10 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
   size_t lds_max = 0;
   long work[SD_MAX_FPN_LEVELS];
   int nl = 0;
+  if ((long)a.R * a.C * a.PP >= (1L << 31)) return SD_ERR_UNSUPPORTED;  // 32-bit lane offsets
   for (int l = 0; l < nlvl; ++l) {
     if (!a.dx[l]) continue;
+    if (a.L.H[l] > 32767 || a.L.W[l] > 32767) return SD_ERR_UNSUPPORTED;  // packed neighbour pairs
     const long plane_bytes = (long)a.L.H[l] * a.L.W[l] * 4;
     int nb = (int)((plane_bytes + budget - 1) / budget);
     if (nb < 1) nb = 1;
@@ -1060,10 +1135,18 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
     work[l] = (long)a.B * nb * a.C;
     a.order[nl++] = l;
   }
-  // largest level first so the long workgroups start early
+  // Launch order = expected duration of ONE workgroup, longest first: a level that fits in one
+  // band sees all of its image's RoIs in every workgroup (2x the items of a P2 band at the
+  // baseline), so the few-band levels go first and the many short P2 bands fill the tail.
+  // (knob roi_align_bwd_order = 1: most workgroups first, the previous order)
+  const bool by_count = tuning("roi_align_bwd_order", 0) == 1;
   for (int i = 0; i < nl; ++i)
     for (int j = i + 1; j < nl; ++j)
-      if (work[a.order[j]] > work[a.order[i]]) {
+      if (by_count ? work[a.order[j]] > work[a.order[i]]
+                   : (a.nbands[a.order[j]] < a.nbands[a.order[i]] ||
+                      (a.nbands[a.order[j]] == a.nbands[a.order[i]] &&
+                       (long)a.L.H[a.order[j]] * a.L.W[a.order[j]] >
+                           (long)a.L.H[a.order[i]] * a.L.W[a.order[i]]))) {
         const int t = a.order[i];
         a.order[i] = a.order[j];
         a.order[j] = t;

@@ -35,6 +35,7 @@ Knob g_knobs[] = {
     {"roi_align_bwd", 0, false},         // 0 global atomics, 1 per-level LDS planes, 2 fused (default)
     {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 36
     {"roi_align_bwd_accum", 0, false},   // per-level plane path only: 1 int64 fixed point, 0 float CAS
+    {"roi_align_bwd_order", 0, false},   // 0 longest workgroups first (default), 1 most workgroups first
     {"roi_align_bwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
     {"roi_align_bwd_threads", 0, false}, // 256 or 512 (default)
     {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes (default)
@@ -45,6 +46,7 @@ Knob g_knobs[] = {
     {"dcn_im2col", 0, false},        // 1 LDS-plane im2col (default), 0 per-lane global gathers
     {"dcn_im2col_split", 0, false},  // channel splits per (image, group, pixel tile), default 1
     {"dcn_im2col_nt", 0, false},     // 1 non-temporal col stores (default)
+    {"dcn_window", 0, false},        // 1 stage only the touched range of each plane (default)
     {"dcn_coord", 0, false},         // 1 LDS-plane offset gradient (default), 0 per-lane gathers
 };
 std::mutex g_mu;

@@ -159,8 +159,8 @@ def fpn_roi_align_forward(feats, rois, rcnn_stride, pooled_size, roi_canonical_s
 def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_canonical_scale=224,
                                  roi_canonical_level=4):
     """The fused extractor with a one-byte arg-max: -> out (B,R,C,ph,pw) fp32, argmax (B,R,C,ph,pw)
-    uint8 (row sample * 3 + column sample, 255 = nothing pooled), coords (B,R,2,3*ph... ) fp32
-    sample-coordinate table.  (argmax, coords) are state between this op's forward and backward
+    uint8 (row sample * 3 + column sample, 255 = nothing pooled), coords (B,R,9*(ph+pw)) 4-byte
+    words: per RoI 3*(ph+pw) fp32 sample coordinates, then 3*(ph+pw) {neighbours, fraction} pairs.  (argmax, coords) are state between this op's forward and backward
     only; fpn_roi_align_backward_packed decodes them."""
     _chk(rois, "rois", ndim=3)
     if len(feats) != len(rcnn_stride):
@@ -177,7 +177,7 @@ def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_cano
     shape = (B, R, C, ph, pw)
     out = torch.empty(shape, device=rois.device, dtype=torch.float32)
     amax = torch.empty(shape, device=rois.device, dtype=torch.uint8)
-    coords = torch.empty((B, R, 3 * (ph + pw)), device=rois.device, dtype=torch.float32)
+    coords = torch.empty((B, R, 9 * (ph + pw)), device=rois.device, dtype=torch.float32)
     wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, R)
     ws = torch.empty(wsb, device=rois.device, dtype=torch.uint8)
     lib().call("sd_fpn_roi_align_fwd_packed", _parr(feats), _iarr([f.shape[2] for f in feats]),

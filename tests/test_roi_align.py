@@ -368,7 +368,7 @@ def test_fpn_packed_argmax_forward_backward(ops, oracle, variant):
     ok = code != 255
     ty = np.take_along_axis(con[:, :, None, None, None, :21].repeat(16, 2).repeat(7, 3).repeat(7, 4),
                             np.where(ok, pp[None, None, None] * 3 + code // 3, 0)[..., None], -1)[..., 0]
-    tx = np.take_along_axis(con[:, :, None, None, None, 21:].repeat(16, 2).repeat(7, 3).repeat(7, 4),
+    tx = np.take_along_axis(con[:, :, None, None, None, 21:42].repeat(16, 2).repeat(7, 3).repeat(7, 4),
                             np.where(ok, qq[None, None, None] * 3 + code % 3, 0)[..., None], -1)[..., 0]
     np.testing.assert_array_equal(np.where(ok, ty, -1), want[2])
     np.testing.assert_array_equal(np.where(ok, tx, -1), want[1])
