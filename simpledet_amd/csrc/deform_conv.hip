@@ -153,33 +153,70 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
   const int cpg = g.C / g.dgroup, grp = c / cpg;
   const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P;
   const float* cp = col + ((long)n * g.C + c) * K2 * P;
-  for (int idx = tid; idx < K2 * P; idx += 256) {
-    const int tap = idx / P, p = idx - tap * P;
-    const int i = tap / g.kw, j = tap % g.kw;
-    const int h_out = p / g.Wo, w_out = p % g.Wo;
+  // taps outer (wave-uniform), pixels inner with (h_out, w_out) advanced incrementally: no integer
+  // division per col element
+  const int step_h = 256 / g.Wo, step_w = 256 % g.Wo;
+  for (int tap = 0; tap < K2; ++tap) {
+   const int i = tap / g.kw, j = tap % g.kw;
+   int h_out = tid / g.Wo, w_out = tid % g.Wo;
+   for (int p = tid; p < P; p += 256, h_out += step_h, w_out += step_w) {
+    if (w_out >= g.Wo) {
+      w_out -= g.Wo;
+      ++h_out;
+    }
+    const int idx = tap * P + p;
     const int h_in = h_out * g.stride_h - g.pad_h, w_in = w_out * g.stride_w - g.pad_w;
-    const float offset_h = off[(long)(2 * tap) * P + p];
-    const float offset_w = off[(long)(2 * tap + 1) * P + p];
+    const float offset_h = off[(2 * tap) * P + p];
+    const float offset_w = off[(2 * tap + 1) * P + p];
     const float cur_inv_h_data = h_in + i * g.dil_h + offset_h;
     const float cur_inv_w_data = w_in + j * g.dil_w + offset_w;
     const int cur_h = (int)cur_inv_h_data;
     // quick reject: every touched row lies in [cur_h - 1, cur_h + 1]
     if (cur_h + 1 < row0 || cur_h - 1 >= row1) continue;
     const float cur_top_grad = cp[idx];
-    // The reference walks the 5x5 neighbourhood of (cur_h, cur_w) and keeps the pixels with
-    // |inv_h - hh| < 1 and |inv_w - ww| < 1: those are floor() and floor() + 1 of each coordinate
-    // (both always inside the 5x5 window), so only these four are visited.
+    // The reference walks the 5x5 neighbourhood of (cur_h, cur_w), keeps the pixels with
+    // |inv_h - hh| < 1 and |inv_w - ww| < 1 and weighs them with get_gradient_weight().  Those
+    // pixels are floor() and floor() + 1 of each coordinate (always inside the 5x5 window), and the
+    // clamped corner rows / columns of get_gradient_weight() depend on the sample only: they are
+    // computed once per col element, the per-pixel part is the factor selection of its if-chain.
+    float ah = cur_inv_h_data, aw = cur_inv_w_data;
+    if (ah < 0 || ah > g.H || aw < 0 || aw > g.W) continue;  // the function returns 0 for all pixels
+    int hl = (int)ah, wl = (int)aw, hh_, wh_;
+    if (hl >= g.H - 1) {
+      hh_ = hl = g.H - 1;
+      ah = (float)hl;
+    } else {
+      hh_ = hl + 1;
+    }
+    if (wl >= g.W - 1) {
+      wh_ = wl = g.W - 1;
+      aw = (float)wl;
+    } else {
+      wh_ = wl + 1;
+    }
     const int fh = (int)floorf(cur_inv_h_data), fw = (int)floorf(cur_inv_w_data);
-    for (int dy = 0; dy <= 1; dy++)
+#pragma unroll
+    for (int dy = 0; dy <= 1; dy++) {
+      const int hh = fh + dy;
+      if (!(hh >= 0 && hh < g.H && fabsf(cur_inv_h_data - hh) < 1)) continue;
+      float fhv;
+      if (hh == hl) fhv = (hh + 1 - ah);
+      else if (hh == hh_) fhv = (ah + 1 - hh);
+      else continue;
+      if (!(hh >= row0 && hh < row1)) continue;
+#pragma unroll
       for (int dxx = 0; dxx <= 1; dxx++) {
-        const int hh = fh + dy, ww = fw + dxx;
-        if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W && fabsf(cur_inv_h_data - hh) < 1 &&
-            fabsf(cur_inv_w_data - ww) < 1) {
-          const float w = get_gradient_weight(cur_inv_h_data, cur_inv_w_data, hh, ww, g.H, g.W);
-          if (hh >= row0 && hh < row1 && w != 0.f)
-            lds_add_cas_f32(plane + (hh - row0) * g.W + ww, w * cur_top_grad);
-        }
+        const int ww = fw + dxx;
+        if (!(ww >= 0 && ww < g.W && fabsf(cur_inv_w_data - ww) < 1)) continue;
+        float fwv;
+        if (ww == wl) fwv = (ww + 1 - aw);
+        else if (ww == wh_) fwv = (aw + 1 - ww);
+        else continue;
+        const float w = fhv * fwv;
+        if (w != 0.f) lds_add_cas_f32(plane + (hh - row0) * g.W + ww, w * cur_top_grad);
       }
+    }
+   }
   }
   __syncthreads();
   float* d = dx + (((long)n * g.C + c) * g.H + row0) * g.W;
