@@ -46,15 +46,28 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
   if (b.s > a.s || (b.s == a.s && b.pos < a.pos)) return b;
   return a;
 }
-__device__ __forceinline__ Cand wave_best(Cand c) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Cand d;
-    d.s = __shfl_xor(c.s, o);
-    d.pos = __shfl_xor(c.pos, o);
-    c = better(c, d);
-  }
-  return c;
+// Wave arg-max on the DPP network (row shifts inside 16-lane rows, then two row broadcasts; the
+// result lands in lane 63): VALU latency per step instead of a ds_bpermute round trip per shuffle.
+// Returns wave-uniform values.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Cand dpp_step(Cand c) {
+  Cand d;
+  // lanes without a source keep "none" (pos = -1), which better() ignores
+  d.s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c.s), CTRL, ROW_MASK, 0xf, false));
+  d.pos = __builtin_amdgcn_update_dpp(-1, c.pos, CTRL, ROW_MASK, 0xf, false);
+  return better(c, d);
+}
+__device__ __forceinline__ Cand wave_best_dpp(Cand c) {
+  c = dpp_step<0x111, 0xf>(c);  // row_shr:1
+  c = dpp_step<0x112, 0xf>(c);  // row_shr:2
+  c = dpp_step<0x114, 0xf>(c);  // row_shr:4
+  c = dpp_step<0x118, 0xf>(c);  // row_shr:8
+  c = dpp_step<0x142, 0xa>(c);  // row_bcast:15 into rows 1 and 3
+  c = dpp_step<0x143, 0xc>(c);  // row_bcast:31 into rows 2 and 3
+  Cand r;
+  r.s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.s), 63));
+  r.pos = __builtin_amdgcn_readlane(c.pos, 63);
+  return r;
 }
 
 template <int THREADS>
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
         const float sc = S[pos];
         if (sc == sc) c = better(c, Cand{sc, pos});
       }
-      c = wave_best(c);
+      c = wave_best_dpp(c);
       if (lane == 0) {
         PS[wave] = c.s;
         PP[wave] = c.pos;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
         c = better(c, Cand{ns, pos});
       }
     }
-    c = wave_best(c);
+    c = wave_best_dpp(c);
     if (lane == 0) {
       PS[wave] = c.s;
       PP[wave] = c.pos;
@@ -280,16 +293,24 @@ extern "C" int sd_soft_nms_batched(const float* dets, const int32_t* counts, int
     return SD_OK;
   }
   SD_REQUIRE(dets && out_dets && out_inds, "null tensor pointer");
-  constexpr int T = 256;
+  int T = tuning("soft_nms_threads", 256);
+  if (T != 64 && T != 128) T = 256;
   const size_t lds = (((size_t)6 * Nmax + 1) & ~(size_t)1) * 4 + ((size_t)(Nmax + 63) / 64 + 1) * 8 +
                      (size_t)(T / kWave) * 8 + 16 + (size_t)Nmax * 4;
   SD_REQUIRE(lds <= 160 * 1024, "soft_nms: Nmax=%d needs %zu B of LDS (limit 160 KB)", Nmax, lds);
   SoftArgs a{dets, counts, out_dets, out_inds, out_counts, P, Nmax, sigma, Nt, threshold, method};
-  auto k = soft_nms_kernel<T>;
-  if (lds > 64 * 1024)
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-  hipLaunchKernelGGL(k, dim3(P), dim3(T), lds, (hipStream_t)stream, a);
+#define SD_SOFT(TT)                                                                              \
+  do {                                                                                           \
+    auto k = soft_nms_kernel<TT>;                                                                \
+    if (lds > 64 * 1024)                                                                         \
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds));                                               \
+    hipLaunchKernelGGL(k, dim3(P), dim3(TT), lds, (hipStream_t)stream, a);                       \
+  } while (0)
+  if (T == 64) SD_SOFT(64);
+  else if (T == 128) SD_SOFT(128);
+  else SD_SOFT(256);
+#undef SD_SOFT
   SD_LAUNCH_CHECK();
   return SD_OK;
 }

@@ -1,16 +1,19 @@
 #!/bin/bash
-# kernel-trace stats of the secondary ops (bench_ops.run without the CPU legs)
-OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-ops}
+# Profile of the secondary ops (bench_ops.run without the CPU legs): kernel-trace stats + PMC passes
+# (FETCH_SIZE, WRITE_SIZE, L2 hit/miss), one counter group per run, never combined with tracing.
+#   usage: tools/prof_ops.sh <tag>      -> gpurun_out/<tag>/{kernel_stats.csv,pmc_summary.json,summary.txt}
+TAG=${1:-ops}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python -c "
-import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT')
-import torch, bench_ops
-torch.cuda.set_device(0)
-bench_ops.run(cpu=False)" > $OUT/kt.log 2>&1
-python - <<PY
-import csv
-for r in list(csv.DictReader(open("$OUT/kt/kt_kernel_stats.csv"))):
-    if "sd::" in r["Name"]:
-        print("%-100s calls %5s avg %9.1f us" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3))
-PY
+PY="import sys; sys.path.insert(0, '$ROOT'); import torch, bench_ops; torch.cuda.set_device(0); bench_ops.run(cpu=False)"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python -c "$PY" > $OUT/kt.log 2>&1
+i=0
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc$i -o pmc -- python -c "$PY" > $OUT/pmc$i.log 2>&1
+done
+cd $ROOT
+python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
