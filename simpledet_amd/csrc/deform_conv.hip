@@ -601,67 +601,84 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BK = 16;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
 
-// load a BK x 128 operand tile (k-major in registers: 8 values per thread) from a matrix whose
-// element (r, k) sits at base[r*sr + k*sk]; rows r0.., k from k0
-template <bool KCONTIG>
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, long sr, long sk, int r0,
-                                          int k0, int R, int K, int tid, float (&v)[8]) {
-  if (KCONTIG) {
-    // thread -> row tid/2, k segment (tid%2)*8 .. +8
-    const int r = r0 + (tid >> 1), ks = k0 + (tid & 1) * 8;
-    const float* p = base + (long)r * sr + ks;
-    if (r < R && ks + 7 < K && ((((uintptr_t)p) & 15) == 0)) {
-      const float4 a = *reinterpret_cast<const float4*>(p);
-      const float4 b = *reinterpret_cast<const float4*>(p + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
+// Operand tile of ROWS rows x BK k-values, k-major in LDS.  Global element (r, k) sits at
+// base[r*sr + k*sk] with one of the strides equal to 1.  NV = values per thread.
+template <int ROWS, bool KCONTIG>
+struct TileIO {
+  // KCONTIG: unit = (row, 8 consecutive k): 2*ROWS units; else unit = (k, 4 consecutive rows): 4*ROWS
+  static constexpr int UNITS = KCONTIG ? 2 * ROWS : 4 * ROWS;
+  static constexpr int PER = KCONTIG ? 8 : 4;
+  static constexpr int TRIPS = (UNITS + 255) / 256;
+  static constexpr int NV = TRIPS * PER;
+  static constexpr int LD = ROWS + 4;
+
+  static __device__ __forceinline__ void load(const float* __restrict__ base, long sr, long sk,
+                                              int r0, int k0, int R, int K, int tid,
+                                              float (&v)[NV]) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (r < R && ks + e < K) ? p[e] : 0.f;
-    }
-  } else {
-    // thread -> k row (tid/32) and (tid/32)+8, 4 consecutive r at (tid%32)*4
-    const int rr = r0 + (tid & 31) * 4;
+    for (int t = 0; t < TRIPS; ++t) {
+      const int u = tid + t * 256;
+      if (UNITS % 256 != 0 && u >= UNITS) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = k0 + (tid >> 5) + h * 8;
-      const float* p = base + (long)k * sk + rr;
-      if (k < K && rr + 3 < R && ((((uintptr_t)p) & 15) == 0)) {
-        const float4 a = *reinterpret_cast<const float4*>(p);
-        v[h * 4 + 0] = a.x; v[h * 4 + 1] = a.y; v[h * 4 + 2] = a.z; v[h * 4 + 3] = a.w;
+        for (int e = 0; e < PER; ++e) v[t * PER + e] = 0.f;
+        continue;
+      }
+      if (KCONTIG) {
+        const int r = r0 + (u >> 1), ks = k0 + (u & 1) * 8;
+        const float* p = base + (long)r * sr + ks;
+        if (r < R && ks + 7 < K && ((((uintptr_t)p) & 15) == 0)) {
+          const float4 a = *reinterpret_cast<const float4*>(p);
+          const float4 b = *reinterpret_cast<const float4*>(p + 4);
+          v[t * 8 + 0] = a.x; v[t * 8 + 1] = a.y; v[t * 8 + 2] = a.z; v[t * 8 + 3] = a.w;
+          v[t * 8 + 4] = b.x; v[t * 8 + 5] = b.y; v[t * 8 + 6] = b.z; v[t * 8 + 7] = b.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[t * 8 + e] = (r < R && ks + e < K) ? p[e] : 0.f;
+        }
       } else {
+        constexpr int QR = ROWS / 4;  // 4-row groups per k row
+        const int k = k0 + u / QR, rr = r0 + (u % QR) * 4;
+        const float* p = base + (long)k * sk + rr;
+        if (k < K && rr + 3 < R && ((((uintptr_t)p) & 15) == 0)) {
+          const float4 a = *reinterpret_cast<const float4*>(p);
+          v[t * 4 + 0] = a.x; v[t * 4 + 1] = a.y; v[t * 4 + 2] = a.z; v[t * 4 + 3] = a.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[h * 4 + e] = (k < K && rr + e < R) ? p[e] : 0.f;
+          for (int e = 0; e < 4; ++e) v[t * 4 + e] = (k < K && rr + e < R) ? p[e] : 0.f;
+        }
       }
     }
   }
-}
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const float (&v)[8]) {
-  // LDS tile T[k][128 + pad]
-  constexpr int LD = 128 + 4;
-  if (KCONTIG) {
-    const int r = tid >> 1, ks = (tid & 1) * 8;
+  static __device__ __forceinline__ void store(float* __restrict__ T, int tid, const float (&v)[NV]) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) T[(ks + e) * LD + r] = v[e];
-  } else {
-    const int rr = (tid & 31) * 4;
+    for (int t = 0; t < TRIPS; ++t) {
+      const int u = tid + t * 256;
+      if (UNITS % 256 != 0 && u >= UNITS) continue;
+      if (KCONTIG) {
+        const int r = u >> 1, ks = (u & 1) * 8;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = (tid >> 5) + h * 8;
-      *reinterpret_cast<float4*>(&T[k * LD + rr]) =
-          make_float4(v[h * 4], v[h * 4 + 1], v[h * 4 + 2], v[h * 4 + 3]);
+        for (int e = 0; e < 8; ++e) T[(ks + e) * LD + r] = v[t * 8 + e];
+      } else {
+        constexpr int QR = ROWS / 4;
+        const int k = u / QR, rr = (u % QR) * 4;
+        *reinterpret_cast<float4*>(&T[k * LD + rr]) =
+            make_float4(v[t * 4], v[t * 4 + 1], v[t * 4 + 2], v[t * 4 + 3]);
+      }
     }
   }
-}
+};
 
-template <bool AK, bool BKC>
+// 128 x (64*J) x 16 tiles, 4 waves as 2 x 2, each wave 64 x (32*J): 2 x J accumulators of 32x32
+template <bool AK, bool BKC, int J>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
-  constexpr int LD = 128 + 4;
-  __shared__ __attribute__((aligned(16))) float As[BK * LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+  using TA = TileIO<BM, AK>;
+  using TB = TileIO<64 * J, BKC>;
+  constexpr int BN = 64 * J;
+  __shared__ __attribute__((aligned(16))) float As[BK * TA::LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * TB::LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // tile order: consecutive blocks walk the M tiles of one N panel (the B/col panel stays hot)
   const int tm = blockIdx.x % a.tiles_m, tn = blockIdx.x / a.tiles_m;
@@ -670,41 +687,41 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
   const float* B = a.B + (long)b * a.strideB;
   float* C = a.C + (long)b * a.strideC;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;  // wave's 64x64 quadrant
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (32 * J);  // the wave's 64 x 32J block
 
-  floatx16 acc[2][2];
+  floatx16 acc[2][J];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < J; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float ra[8], rb[8];
+  float ra[TA::NV], rb[TB::NV];
   // A tile: rows = m, "row stride" sam, k stride sak.  B tile: rows = n, row stride sbn, k stride sbk
-  load_tile<AK>(A, AK ? a.sam : 0, AK ? 1 : a.sak, m0, 0, a.M, a.K, tid, ra);
-  load_tile<BKC>(B, BKC ? a.sbn : 0, BKC ? 1 : a.sbk, n0, 0, a.N, a.K, tid, rb);
+  TA::load(A, AK ? a.sam : 0, AK ? 1 : a.sak, m0, 0, a.M, a.K, tid, ra);
+  TB::load(B, BKC ? a.sbn : 0, BKC ? 1 : a.sbk, n0, 0, a.N, a.K, tid, rb);
   for (int k0 = 0; k0 < a.K; k0 += BK) {
     __syncthreads();
-    store_tile<AK>(As, tid, ra);
-    store_tile<BKC>(Bs, tid, rb);
+    TA::store(As, tid, ra);
+    TB::store(Bs, tid, rb);
     __syncthreads();
     if (k0 + BK < a.K) {
-      load_tile<AK>(A, AK ? a.sam : 0, AK ? 1 : a.sak, m0, k0 + BK, a.M, a.K, tid, ra);
-      load_tile<BKC>(B, BKC ? a.sbn : 0, BKC ? 1 : a.sbk, n0, k0 + BK, a.N, a.K, tid, rb);
+      TA::load(A, AK ? a.sam : 0, AK ? 1 : a.sak, m0, k0 + BK, a.M, a.K, tid, ra);
+      TB::load(B, BKC ? a.sbn : 0, BKC ? 1 : a.sbk, n0, k0 + BK, a.N, a.K, tid, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const int kr = kk + (lane >> 5);
-      float av[2], bv[2];
+      float av[2], bv[J];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = As[kr * LD + wm + i * 32 + (lane & 31)];
+      for (int i = 0; i < 2; ++i) av[i] = As[kr * TA::LD + wm + i * 32 + (lane & 31)];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = Bs[kr * LD + wn + j * 32 + (lane & 31)];
+      for (int j = 0; j < J; ++j) bv[j] = Bs[kr * TB::LD + wn + j * 32 + (lane & 31)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < J; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
   }
@@ -712,7 +729,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < J; ++j) {
       const int col = n0 + wn + j * 32 + (lane & 31);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -728,18 +745,45 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
     }
 }
 
+// Tile width by wave quantisation: the grid is only a few tiles per CU (4.1 for the DCN forward
+// product with 128-wide tiles), so the last partial round costs up to a full tile time.  Pick the
+// J in {1, 2, 3} that maximises  (tiles / CU) / ceil(tiles / CU)  x  (N / padded N)  x  the measured
+// intrinsic rate of the variant (64- and 128-wide: ~102 TF on the DCN products, 6 and 3 waves per
+// SIMD; 192-wide: ~96 TF, 2 waves per SIMD); ties go to the narrower tile (more waves resident).
+template <bool AK, bool BKC>
+static void launch_gemm_j(const GemmArgs& g, int J, dim3 grid, hipStream_t st) {
+  if (J == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 1>), grid, dim3(256), 0, st, g);
+  else if (J == 2) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 2>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 3>), grid, dim3(256), 0, st, g);
+}
+
 static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return SD_OK;
   g.tiles_m = cdiv(g.M, BM);
-  g.tiles_n = cdiv(g.N, BN);
+  int J = tuning("deform_gemm_j", 0);
+  if (J < 1 || J > 3) {
+    double best = -1.0;
+    for (int j = 1; j <= 3; ++j) {
+      const int tn = cdiv(g.N, 64 * j);
+      const double per_cu = (double)g.tiles_m * tn * batch / kNumCU;
+      const double rounds = per_cu <= 1.0 ? 1.0 : (double)(long)(per_cu + 0.999999);
+      double eff = (per_cu <= 1.0 ? per_cu : per_cu / rounds) * ((double)g.N / ((double)tn * 64 * j));
+      if (j == 3) eff *= 0.94;
+      if (eff > best) {
+        best = eff;
+        J = j;
+      }
+    }
+  }
+  g.tiles_n = cdiv(g.N, 64 * J);
   const dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
   const bool ak = g.sak == 1, bk = g.sbk == 1;
   SD_REQUIRE(ak || g.sam == 1, "GEMM: A needs a unit stride");
   SD_REQUIRE(bk || g.sbn == 1, "GEMM: B needs a unit stride");
-  if (ak && bk) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, g);
-  else if (ak) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, g);
-  else if (bk) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, g);
+  if (ak && bk) launch_gemm_j<true, true>(g, J, grid, st);
+  else if (ak) launch_gemm_j<true, false>(g, J, grid, st);
+  else if (bk) launch_gemm_j<false, true>(g, J, grid, st);
+  else launch_gemm_j<false, false>(g, J, grid, st);
   SD_LAUNCH_CHECK();
   return SD_OK;
 }

@@ -25,3 +25,13 @@ for name, f_t, f_s in [
 ]:
     a, b = t(f_t), t(f_s)
     print("%s torch %.3f ms %.1f TF | sd_gemm_f32 %.3f ms %.1f TF" % (name, a, fl / a / 1e9, b, fl / b / 1e9))
+
+# tile-width A/B (sd_gemm_f32 only)
+from simpledet_amd._lib import lib
+for J in (1, 2, 3, 0):
+    lib().set_tuning("deform_gemm_j", J)
+    r = []
+    for f_s in (lambda: ops.gemm_f32(w, col), lambda: ops.gemm_f32(w, dy, trans_a=True),
+                lambda: ops.gemm_f32(dy, col, trans_b=True)):
+        r.append(fl / t(f_s) / 1e9)
+    print("J=%d (0 = auto): %.1f / %.1f / %.1f TF" % (J, r[0], r[1], r[2]))
