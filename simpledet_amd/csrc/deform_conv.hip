@@ -601,14 +601,15 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-constexpr int BM = 128, BK = 16;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
+constexpr int BM = 128;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
 
 // Operand tile of ROWS rows x BK k-values, k-major in LDS.  Global element (r, k) sits at
 // base[r*sr + k*sk] with one of the strides equal to 1.  NV = values per thread.
-template <int ROWS, bool KCONTIG>
+template <int ROWS, bool KCONTIG, int BK>
 struct TileIO {
   // KCONTIG: unit = (row, 8 consecutive k): 2*ROWS units; else unit = (k, 4 consecutive rows): 4*ROWS
-  static constexpr int UNITS = KCONTIG ? 2 * ROWS : 4 * ROWS;
+  static constexpr int SEGS = BK / 8;
+  static constexpr int UNITS = KCONTIG ? SEGS * ROWS : (BK / 4) * ROWS;
   static constexpr int PER = KCONTIG ? 8 : 4;
   static constexpr int TRIPS = (UNITS + 255) / 256;
   static constexpr int NV = TRIPS * PER;
@@ -626,7 +627,7 @@ struct TileIO {
         continue;
       }
       if (KCONTIG) {
-        const int r = r0 + (u >> 1), ks = k0 + (u & 1) * 8;
+        const int r = r0 + u / SEGS, ks = k0 + (u % SEGS) * 8;
         const float* p = base + (long)r * sr + ks;
         if (r < R && ks + 7 < K && ((((uintptr_t)p) & 15) == 0)) {
           const float4 a = *reinterpret_cast<const float4*>(p);
@@ -658,7 +659,7 @@ struct TileIO {
       const int u = tid + t * 256;
       if (UNITS % 256 != 0 && u >= UNITS) continue;
       if (KCONTIG) {
-        const int r = u >> 1, ks = (u & 1) * 8;
+        const int r = u / SEGS, ks = (u % SEGS) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) T[(ks + e) * LD + r] = v[t * 8 + e];
       } else {
@@ -672,10 +673,10 @@ struct TileIO {
 };
 
 // 128 x (64*J) x 16 tiles, 4 waves as 2 x 2, each wave 64 x (32*J): 2 x J accumulators of 32x32
-template <bool AK, bool BKC, int J>
+template <bool AK, bool BKC, int J, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
-  using TA = TileIO<BM, AK>;
-  using TB = TileIO<64 * J, BKC>;
+  using TA = TileIO<BM, AK, BK>;
+  using TB = TileIO<64 * J, BKC, BK>;
   constexpr int BN = 64 * J;
   __shared__ __attribute__((aligned(16))) float As[BK * TA::LD];
   __shared__ __attribute__((aligned(16))) float Bs[BK * TB::LD];
@@ -752,9 +753,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
 // SIMD; 192-wide: ~96 TF, 2 waves per SIMD); ties go to the narrower tile (more waves resident).
 template <bool AK, bool BKC>
 static void launch_gemm_j(const GemmArgs& g, int J, dim3 grid, hipStream_t st) {
-  if (J == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 1>), grid, dim3(256), 0, st, g);
-  else if (J == 2) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 2>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 3>), grid, dim3(256), 0, st, g);
+  const bool k32 = tuning("deform_gemm_bk", 16) == 32;
+  if (J == 1 && k32) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 1, 32>), grid, dim3(256), 0, st, g);
+  else if (J == 2 && k32) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 2, 32>), grid, dim3(256), 0, st, g);
+  else if (J == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 1, 16>), grid, dim3(256), 0, st, g);
+  else if (J == 2) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 2, 16>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 3, 16>), grid, dim3(256), 0, st, g);
 }
 
 static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {

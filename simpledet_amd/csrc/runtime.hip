@@ -43,6 +43,7 @@ Knob g_knobs[] = {
     {"soft_nms_threads", 0, false},
     {"proposal_target_shuffle", 0, false},
     {"deform_gemm", 0, false},
+    {"deform_gemm_bk", 0, false},    // K extent of a GEMM tile: 16 (default) or 32
     {"deform_gemm_j", 0, false},     // GEMM tile width 64*J (1..3), 0 = by wave quantisation (default)
     {"dcn_im2col", 0, false},        // 1 LDS-plane im2col (default), 0 per-lane global gathers
     {"dcn_im2col_split", 0, false},  // channel splits per (image, group, pixel tile), default 1

@@ -28,10 +28,11 @@ for name, f_t, f_s in [
 
 # tile-width A/B (sd_gemm_f32 only)
 from simpledet_amd._lib import lib
-for J in (1, 2, 3, 0):
+for J, bk in ((1, 16), (2, 16), (3, 16), (0, 16), (1, 32), (2, 32)):
     lib().set_tuning("deform_gemm_j", J)
+    lib().set_tuning("deform_gemm_bk", bk)
     r = []
     for f_s in (lambda: ops.gemm_f32(w, col), lambda: ops.gemm_f32(w, dy, trans_a=True),
                 lambda: ops.gemm_f32(dy, col, trans_b=True)):
         r.append(fl / t(f_s) / 1e9)
-    print("J=%d (0 = auto): %.1f / %.1f / %.1f TF" % (J, r[0], r[1], r[2]))
+    print("J=%d (0 = auto) BK=%d: %.1f / %.1f / %.1f TF" % (J, bk, r[0], r[1], r[2]))
