@@ -17,7 +17,12 @@ def _case(seed, N=2, C=8, H=9, W=11, F=6, k=3, pad=1, stride=1, dil=1, dg=4, off
     x = rs.standard_normal((N, C, H, W)).astype(np.float32)
     off = (rs.standard_normal((N, dg * 2 * k * k, Ho, Wo)) * off_scale).astype(np.float32)
     w = (rs.standard_normal((F, C, k, k)) * 0.2).astype(np.float32)
-    return x, off, w, dict(pad=pad, stride=stride, dil=dil, dgroup=dg)
+    return x, off, w, dict(pad=pad, stride=stride, dil=dil, dgroup=dg, kernel=(k, k))
+
+
+def _nok(kw):
+    """kwargs without the kernel size (taken from the weight shape by the convolution entry points)"""
+    return {k: v for k, v in kw.items() if k != "kernel"}
 
 
 def _conv_ref(x, w, pad, stride, dil):
@@ -39,7 +44,7 @@ def _conv_ref(x, w, pad, stride, dil):
 @pytest.mark.parametrize("cfg", [dict(), dict(stride=2), dict(pad=2, dil=2), dict(pad=0)])
 def test_oracle_zero_offset_is_ordinary_convolution(oracle, cfg):
     x, off, w, kw = _case(0, off_scale=0.0, **cfg)
-    y = oracle.deform_conv_fwd(x, off, w, **kw)
+    y = oracle.deform_conv_fwd(x, off, w, **_nok(kw))
     np.testing.assert_allclose(y, _conv_ref(x, w, kw["pad"], kw["stride"], kw["dil"]), rtol=1e-4,
                                atol=1e-4)
 
@@ -99,10 +104,16 @@ def _t(a):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [dict(), dict(stride=2), dict(pad=2, dil=2), dict(dg=1, C=6),
-                                 dict(H=25, W=42, C=16, F=20, off_scale=3.0)])
+                                 dict(H=25, W=42, C=16, F=20, off_scale=3.0),
+                                 dict(H=12, W=16),                      # 16-byte staging path
+                                 dict(H=20, W=24, off_scale=40.0),     # wild offsets: whole-plane window, many outside
+                                 dict(H=20, W=24, off_scale=0.0),      # zero offsets: minimal window
+                                 dict(k=1, pad=0, H=12, W=16),         # run-time tap count
+                                 dict(k=5, pad=2, H=12, W=16, dg=2)])  # 25 taps: per-lane fallback kernels
 def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
     x, off, w, kw = _case(7, **cfg)
-    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
+    a = dict(kernel=kw["kernel"], pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"],
+             num_deformable_group=kw["dgroup"])
     col = ops.deform_im2col(_t(x), _t(off), **a).cpu().numpy()
     want = np.stack([oracle.deform_im2col(x[n], off[n], **{k: v for k, v in kw.items()})
                      for n in range(x.shape[0])])
@@ -114,6 +125,35 @@ def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
     do = ops.deform_col2im_coord(_t(g), _t(x), _t(off), **a).cpu().numpy()
     wdo = np.stack([oracle.deform_col2im_coord(g[n], x[n], off[n], **kw) for n in range(x.shape[0])])
     np.testing.assert_allclose(do, wdo, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_lds_plane_kernels_equal_per_lane_kernels(ops):
+    """The LDS-plane im2col / offset-gradient kernels against the per-lane (reference-structure)
+    kernels they replace, at a size with several pixel tiles and the layer's 3x3 / 4-group setup."""
+    import torch
+    from simpledet_amd._lib import lib
+    x, off, w, kw = _case(11, N=2, C=32, H=28, W=36, F=8, dg=4, off_scale=2.5)
+    a = dict(pad=1, stride=1, dilate=1, num_deformable_group=4)
+    tx, to = _t(x), _t(off)
+    col1 = ops.deform_im2col(tx, to, **a)
+    g = torch.randn_like(col1)
+    do1 = ops.deform_col2im_coord(g, tx, to, **a)
+    for k in ("dcn_im2col", "dcn_coord"):
+        lib().set_tuning(k, 0)
+    try:
+        col0 = ops.deform_im2col(tx, to, **a)
+        do0 = ops.deform_col2im_coord(g, tx, to, **a)
+    finally:
+        for k in ("dcn_im2col", "dcn_coord"):
+            lib().set_tuning(k, 1)
+    lib().set_tuning("dcn_window", 0)
+    try:
+        col2 = ops.deform_im2col(tx, to, **a)
+    finally:
+        lib().set_tuning("dcn_window", 1)
+    assert torch.equal(col1, col0) and torch.equal(col1, col2)
+    assert torch.equal(do1, do0)  # same products, same channel order
 
 
 @pytest.mark.gpu
@@ -146,7 +186,7 @@ def test_deform_conv_forward_backward(ops, oracle, cfg):
     x, off, w, kw = _case(11, **cfg)
     a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
     y = ops.deform_conv_forward(_t(x), _t(off), _t(w), **a).cpu().numpy()
-    want = oracle.deform_conv_fwd(x, off, w, **kw)
+    want = oracle.deform_conv_fwd(x, off, w, **_nok(kw))
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(y - want).max() <= 1e-4 * scale
     # backward vs oracle pieces: dcol = W^T dy ; dx = col2im(dcol) ; doff = col2im_coord(dcol) ;

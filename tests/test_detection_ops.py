@@ -59,6 +59,58 @@ def test_roi_pool_forward_backward(ops, oracle, case):
         ops.roi_pool_v1_backward(_t(dy), _t(rois), idx, data.shape, scale, req_data=2)
 
 
+@pytest.mark.gpu
+def test_roi_pool_backward_bands_and_fallback(ops, oracle):
+    """A plane larger than one LDS band (2 bands of a 120x100 map) and the global-atomic structure
+    (knob roi_pool_bwd=0) against the LDS-plane kernel; conservation / arg-max properties at the C4
+    baseline shape; a batch index outside [0, B) (undefined behaviour in the reference, which reads
+    out of bounds) is rejected defensively: 0 / -1 forward, no gradient."""
+    import torch
+    from simpledet_amd._lib import lib
+    data, rois = _pool_case(4, B=3, C=3, H=120, W=100, K=60, stride=8)
+    scale = 1 / 8.0
+    want, widx = oracle.roi_pool_v1_fwd(data, rois, (7, 7), scale)
+    out, idx = ops.roi_pool_v1_forward(_t(data), _t(rois), (7, 7), scale)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    np.testing.assert_array_equal(idx.cpu().numpy(), widx)
+    dy = np.random.RandomState(3).standard_normal(want.shape).astype(np.float32)
+    wdx = oracle.roi_pool_v1_bwd(dy, rois, widx, data.shape, scale)
+    dx, _ = ops.roi_pool_v1_backward(_t(dy), _t(rois), idx, data.shape, scale)
+    np.testing.assert_allclose(dx.cpu().numpy(), wdx, rtol=1e-5, atol=1e-5)
+    lib().set_tuning("roi_pool_bwd", 0)
+    try:
+        dx0, _ = ops.roi_pool_v1_backward(_t(dy), _t(rois), idx, data.shape, scale)
+    finally:
+        lib().set_tuning("roi_pool_bwd", 1)
+    np.testing.assert_allclose(dx0.cpu().numpy(), wdx, rtol=1e-5, atol=1e-5)
+    # conservation at the C4 baseline shape: every pooled gradient lands in exactly one pixel
+    g = torch.Generator(device="cuda").manual_seed(0)
+    big = torch.randn((2, 64, 50, 84), device="cuda", generator=g)
+    r = synth.random_rois(1, 1, 256)[0]
+    br = _t(np.concatenate([np.random.RandomState(1).randint(0, 2, (256, 1)).astype(np.float32), r], 1))
+    o, ix = ops.roi_pool_v1_forward(big, br, (7, 7), 1 / 16.0)
+    gy = torch.rand_like(o)
+    gx, _ = ops.roi_pool_v1_backward(gy, br, ix, big.shape, 1 / 16.0)
+    tot = float((gy * (ix >= 0)).double().sum())
+    assert abs(float(gx.double().sum()) - tot) <= 1e-6 * max(1.0, abs(tot))
+    # the pooled value is the feature at the recorded arg-max
+    flat = big.reshape(2, 64, -1)
+    b = br[:, 0].long()
+    sel = ix >= 0
+    gathered = torch.gather(flat[b], 2, ix.clamp(min=0).long().reshape(256, 64, 49)).reshape(o.shape)
+    assert torch.equal(gathered[sel], o[sel])
+    bad = br.clone()
+    bad[3, 0] = 7
+    bad[4, 0] = -1
+    o2, ix2 = ops.roi_pool_v1_forward(big, bad, (7, 7), 1 / 16.0)
+    assert float(o2[3:5].abs().max()) == 0 and float((ix2[3:5] + 1).abs().max()) == 0
+    gx2, _ = ops.roi_pool_v1_backward(gy, bad, ix2, big.shape, 1 / 16.0)
+    keep = torch.ones(256, dtype=torch.bool, device="cuda")
+    keep[3:5] = False
+    tot2 = float((gy * (ix2 >= 0))[keep].double().sum())
+    assert abs(float(gx2.double().sum()) - tot2) <= 1e-6 * max(1.0, abs(tot2))
+
+
 # ----------------------------------------------------------------------------------- GenAnchor --
 @pytest.mark.gpu
 @pytest.mark.parametrize("stride,shape", [(4, (200, 334)), (8, (100, 167)), (16, (50, 84)),
