@@ -306,6 +306,12 @@ struct PropArgs {
   float anchors[kMaxAnchors * 4];
   int A, H, W, stride, count, pre, P2;
   float min_size;
+  // multi-workgroup top-k (large levels): per image 4 x 256 digit counters, a candidate counter and
+  // P2 candidate keys in global memory; G workgroups per image
+  int* ghist;
+  int* gncand;
+  unsigned long long* gcand;
+  int G;
 };
 
 __global__ __launch_bounds__(256) void proposal_decode_kernel(PropArgs a) {
@@ -413,13 +419,44 @@ __device__ __forceinline__ int radix_digit(int count, int shift, unsigned mask, 
   return digit;
 }
 
+// gather of the sorted rows + FilterBoxKernel (proposal_v3.cu:211-235)
+__device__ __forceinline__ void proposal_gather_filter(const PropArgs& a, int img,
+                                                       const unsigned long long* keys, int tid,
+                                                       int T) {
+  const float* sc = a.score_all + (long)img * a.count;
+  const float4* bx = a.boxes_all + (long)img * a.count;
+  const float im_h = a.im_info[img * 3 + 0], im_w = a.im_info[img * 3 + 1];
+  const float scale = a.im_info[img * 3 + 2];
+  for (int i = tid; i < a.pre; i += T) {
+    const int src = (int)(unsigned)(keys[i] & 0xffffffffu);
+    float4 d = bx[src];
+    float s = sc[src];
+    const float ws_orig_scale = (d.z - d.x) / scale + 1.0f;
+    const float hs_orig_scale = (d.w - d.y) / scale + 1.0f;
+    const float min_size_max = fmaxr(a.min_size, 1.0f);
+    const float ws = d.z - d.x + 1.0f, hs = d.w - d.y + 1.0f;
+    const float x_ctr = d.x + ws / 2.0f, y_ctr = d.y + hs / 2.0f;
+    if (ws_orig_scale < min_size_max || hs_orig_scale < min_size_max || x_ctr >= im_w ||
+        y_ctr >= im_h) {
+      d.x -= min_size_max / 2;
+      d.y -= min_size_max / 2;
+      d.z += min_size_max / 2;
+      d.w += min_size_max / 2;
+      s = -1.0f;
+    }
+    const long o = (long)img * a.pre + i;
+    a.ws.order[o] = src;
+    a.ws.boxes[o] = d;
+    a.ws.score[o] = s;
+  }
+}
+
 __global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // P2 composite keys
   __shared__ int hist[260];
   __shared__ int ncand;
   const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const float* sc = a.score_all + (long)img * a.count;
-  const float4* bx = a.boxes_all + (long)img * a.count;
   auto skey = [&](int i) { return ordered_desc_bits(sc[i]); };  // ascending key = best score first
   // ---- the pre-th smallest score key ----
   unsigned prefix = 0, mask = 0;
@@ -473,32 +510,154 @@ __global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
   }
   __syncthreads();
   bitonic_sort_lds(keys, a.P2, tid, T);
-  // ---- gather + FilterBoxKernel (proposal_v3.cu:211-235) ----
-  const float im_h = a.im_info[img * 3 + 0], im_w = a.im_info[img * 3 + 1];
-  const float scale = a.im_info[img * 3 + 2];
-  for (int i = tid; i < a.pre; i += T) {
-    const int src = (int)(unsigned)(keys[i] & 0xffffffffu);
-    float4 d = bx[src];
-    float s = sc[src];
-    const float ws_orig_scale = (d.z - d.x) / scale + 1.0f;
-    const float hs_orig_scale = (d.w - d.y) / scale + 1.0f;
-    const float min_size_max = fmaxr(a.min_size, 1.0f);
-    const float ws = d.z - d.x + 1.0f, hs = d.w - d.y + 1.0f;
-    const float x_ctr = d.x + ws / 2.0f, y_ctr = d.y + hs / 2.0f;
-    if (ws_orig_scale < min_size_max || hs_orig_scale < min_size_max || x_ctr >= im_w ||
-        y_ctr >= im_h) {
-      d.x -= min_size_max / 2;
-      d.y -= min_size_max / 2;
-      d.z += min_size_max / 2;
-      d.w += min_size_max / 2;
-      s = -1.0f;
+  proposal_gather_filter(a, img, keys, tid, T);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-workgroup top-k for the large pyramid levels.  The single-workgroup radix select above is
+// bound by ONE CU's instruction rate (P2: 200 k scores x 5 passes = 543 us).  Here G workgroups per
+// image split the scores: four histogram launches (one 8-bit digit each: local LDS histogram ->
+// at most 256 global atomics per workgroup), one compaction launch (selected rows appended to a
+// global candidate list with wave-aggregated atomics) and the finishing workgroup (LDS sort of the
+// <= P2 candidates, gather, FilterBox).  Every workgroup re-derives the prefix from the global
+// counters of the earlier digits (256 loads + a wave scan), so nothing is read back by the host.
+// ------------------------------------------------------------------------------------------------
+struct TopkState {
+  unsigned prefix, mask;
+  int want;  // rank still wanted inside the matching set
+  int n_eq;  // size of the selected bucket of the last resolved digit
+};
+
+// resolve digits 0 .. npass-1 from the global counters (every thread of the calling workgroup gets
+// the same values; hist: LDS scratch of 260 ints)
+__device__ __forceinline__ TopkState topk_resolve(const int* __restrict__ gh, int npass, int pre,
+                                                  int* hist) {
+  TopkState s{0u, 0u, pre, 0};
+  for (int p = 0; p < npass; ++p) {
+    const int shift = 24 - 8 * p;
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+      const int lane = threadIdx.x;
+      const int* h = gh + p * 256;
+      const int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+      const int tot = c0 + c1 + c2 + c3;
+      int incl = tot;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      const int excl = incl - tot;
+      if (excl < s.want && s.want <= incl) {  // exactly one lane
+        int run = excl, d = 4 * lane, sz = c0;
+        if (run + c0 < s.want) { run += c0; d = 4 * lane + 1; sz = c1;
+          if (run + c1 < s.want) { run += c1; d = 4 * lane + 2; sz = c2;
+            if (run + c2 < s.want) { run += c2; d = 4 * lane + 3; sz = c3; } } }
+        hist[256] = d;
+        hist[257] = run;
+        hist[258] = sz;
+      }
     }
-    const long o = (long)img * a.pre + i;
-    a.ws.order[o] = src;
-    a.ws.boxes[o] = d;
-    a.ws.score[o] = s;
+    __syncthreads();
+    s.want -= hist[257];
+    s.prefix |= (unsigned)hist[256] << shift;
+    s.mask |= 255u << shift;
+    s.n_eq = hist[258];
+  }
+  __syncthreads();
+  return s;
+}
+
+// grid (G, B): digit `pass` of the score keys of this workgroup's chunk
+__global__ __launch_bounds__(256) void topk_hist_kernel(PropArgs a, int pass) {
+  __shared__ int hist[260];
+  __shared__ int lh[256];
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const float* sc = a.score_all + (long)img * a.count;
+  int* gh = a.ghist + (long)img * 4 * 256;
+  const TopkState s = topk_resolve(gh, pass, a.pre, hist);
+  lh[tid] = 0;
+  __syncthreads();
+  const int shift = 24 - 8 * pass;
+  const int chunk = (a.count + a.G - 1) / a.G;
+  const int lo = blockIdx.x * chunk, hi = iminr(lo + chunk, a.count);
+  for (int i = lo + tid; i < hi; i += 256) {
+    const unsigned k = ordered_desc_bits(sc[i]);
+    if ((k & s.mask) == s.prefix) atomicAdd(&lh[(k >> shift) & 255], 1);
+  }
+  __syncthreads();
+  if (lh[tid]) atomicAdd(&gh[pass * 256 + tid], lh[tid]);
+}
+
+// grid (G, B): rows strictly better than the threshold key, plus the ties when all of them are taken
+__global__ __launch_bounds__(256) void topk_compact_kernel(PropArgs a) {
+  __shared__ int hist[260];
+  const int img = blockIdx.y, tid = threadIdx.x, lane = tid & (kWave - 1);
+  const float* sc = a.score_all + (long)img * a.count;
+  const TopkState s = topk_resolve(a.ghist + (long)img * 4 * 256, 4, a.pre, hist);
+  const unsigned Tkey = s.prefix;
+  const bool all_ties = s.want >= s.n_eq;
+  unsigned long long* cand = a.gcand + (long)img * a.P2;
+  const int chunk = (a.count + a.G - 1) / a.G;
+  const int lo = blockIdx.x * chunk, hi = iminr(lo + chunk, a.count);
+  for (int i0 = lo; i0 < hi; i0 += 256) {
+    const int i = i0 + tid;
+    unsigned k = 0xffffffffu;
+    if (i < hi) k = ordered_desc_bits(sc[i]);
+    const bool take = i < hi && (k < Tkey || (k == Tkey && all_ties));
+    const unsigned long long bal = __ballot(take);
+    if (bal) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&a.gncand[img], __popcll(bal));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (take) {
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1));
+        if (pos < a.P2) cand[pos] = ((unsigned long long)k << 32) | (unsigned)i;
+      }
+    }
   }
 }
+
+// one workgroup per image: ties that are only partly taken (rare), sort, gather + FilterBox
+__global__ __launch_bounds__(1024) void topk_finish_kernel(PropArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // P2 composite keys
+  __shared__ int hist[260];
+  __shared__ int ncand;
+  const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const float* sc = a.score_all + (long)img * a.count;
+  auto skey = [&](int i) { return ordered_desc_bits(sc[i]); };
+  const TopkState s = topk_resolve(a.ghist + (long)img * 4 * 256, 4, a.pre, hist);
+  const unsigned Tkey = s.prefix;
+  const unsigned long long* cand = a.gcand + (long)img * a.P2;
+  const int nc = iminr(a.gncand[img], a.P2);
+  for (int i = tid; i < a.P2; i += T) keys[i] = i < nc ? cand[i] : ~0ull;
+  if (tid == 0) ncand = nc;
+  __syncthreads();
+  if (s.want < s.n_eq) {
+    // only the `want` lowest rows among the ties are taken: select the want-th smallest tied row
+    unsigned ipre = 0, imask = 0;
+    int iwant = s.want;
+    auto ikey = [&](int i) { return skey(i) == Tkey ? (unsigned)i : 0xffffffffu; };
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      int below, bucket;
+      const int d = radix_digit(a.count, shift, imask, ipre, iwant, hist, &below, &bucket, ikey);
+      iwant -= below;
+      ipre |= (unsigned)d << shift;
+      imask |= 255u << shift;
+    }
+    const unsigned Irow = ipre;
+    for (int i = tid; i < a.count; i += T) {
+      if (skey(i) == Tkey && (unsigned)i <= Irow) {
+        const int pos = atomicAdd(&ncand, 1);
+        if (pos < a.P2) keys[pos] = ((unsigned long long)Tkey << 32) | (unsigned)i;
+      }
+    }
+    __syncthreads();
+  }
+  bitonic_sort_lds(keys, a.P2, tid, T);
+  proposal_gather_filter(a, img, keys, tid, T);
+}
+
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -620,8 +779,11 @@ extern "C" size_t sd_proposal_v3_workspace_bytes(int B, int A, int H, int W, int
   int pre, post;
   proposal_dims((int)count, pre_nms_top_n, 1, 1, &pre, &post);
   const int nb = (pre + 63) / 64;
+  int P2 = 64;
+  while (P2 < pre) P2 <<= 1;
   return nms_layout(B, pre, nb, nullptr, nullptr) + align_up((size_t)B * count * 16, 256) +
-         align_up((size_t)B * count * 4, 256) + 512;
+         align_up((size_t)B * count * 4, 256) + align_up((size_t)B * (4 * 256 + 1) * 4, 256) +
+         align_up((size_t)B * P2 * 8, 256) + 512;
 }
 
 extern "C" int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info,
@@ -652,6 +814,14 @@ extern "C" int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, con
   off += align_up((size_t)B * count * 16, 256);
   a.score_all = reinterpret_cast<float*>(base + off);
   off += align_up((size_t)B * count * 4, 256);
+  int P2 = 64;
+  while (P2 < pre) P2 <<= 1;
+  a.ghist = reinterpret_cast<int*>(base + off);  // B x 4 x 256 counters, then B candidate counters
+  a.gncand = a.ghist + (size_t)B * 4 * 256;
+  const size_t counters_bytes = (size_t)B * (4 * 256 + 1) * 4;
+  off += align_up(counters_bytes, 256);
+  a.gcand = reinterpret_cast<unsigned long long*>(base + off);
+  off += align_up((size_t)B * P2 * 8, 256);
   const size_t need = off + (size_t)(base - (char*)workspace);
   if (!workspace || workspace_bytes < need)
     return fail(SD_ERR_WORKSPACE, "Proposal workspace too small: %zu < %zu bytes", workspace_bytes,
@@ -660,17 +830,33 @@ extern "C" int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, con
   a.cls_prob = cls_prob; a.bbox_pred = bbox_pred; a.im_info = im_info;
   a.A = A; a.H = H; a.W = W; a.stride = feature_stride; a.count = count; a.pre = pre;
   a.min_size = (float)rpn_min_size;
-  int P2 = 64;
-  while (P2 < pre) P2 <<= 1;
   a.P2 = P2;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(proposal_decode_kernel, dim3((count + 255) / 256, B), dim3(256), 0, st, a);
   SD_LAUNCH_CHECK();
   const size_t lds = (size_t)P2 * sizeof(unsigned long long);
-  if (lds > 64 * 1024)
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)proposal_topk_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(proposal_topk_kernel, dim3(B), dim3(1024), lds, st, a);
+  // levels with many anchors: the select is spread over G workgroups per image (6 short launches);
+  // small levels keep the single-workgroup kernel (knob proposal_topk: 1 forces it, 2 forces multi)
+  const int mode = tuning("proposal_topk", 0);
+  const bool multi = mode == 2 || (mode != 1 && count >= 32768);
+  if (multi) {
+    int G = (count + 4095) / 4096;
+    if (G > 64) G = 64;
+    a.G = G;
+    SD_HIP_CHECK(hipMemsetAsync(a.ghist, 0, counters_bytes, st));
+    for (int pass = 0; pass < 4; ++pass)
+      hipLaunchKernelGGL(topk_hist_kernel, dim3(G, B), dim3(256), 0, st, a, pass);
+    hipLaunchKernelGGL(topk_compact_kernel, dim3(G, B), dim3(256), 0, st, a);
+    if (lds > 64 * 1024)
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)topk_finish_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(topk_finish_kernel, dim3(B), dim3(1024), lds, st, a);
+  } else {
+    if (lds > 64 * 1024)
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)proposal_topk_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(proposal_topk_kernel, dim3(B), dim3(1024), lds, st, a);
+  }
   SD_LAUNCH_CHECK();
   MaskArgs ma{a.ws, pre, nb, nb * (nb + 1) / 2, threshold, 1};  // IoU >= threshold (:319)
   hipLaunchKernelGGL(nms_mask_kernel, dim3((ma.npairs + 3) / 4, B), dim3(256), 0, st, ma);

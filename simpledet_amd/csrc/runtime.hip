@@ -39,6 +39,7 @@ Knob g_knobs[] = {
     {"roi_align_bwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
     {"roi_align_bwd_threads", 0, false}, // 256 or 512 (default)
     {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes (default)
+    {"proposal_topk", 0, false},         // 0 by level size (default), 1 single workgroup, 2 multi-workgroup
     {"nms_scan", 0, false},              // 0 single-wave scan, 1 (default) block scan
     {"soft_nms_threads", 0, false},
     {"proposal_target_shuffle", 0, false},

@@ -369,25 +369,38 @@ def test_proposal_v3_anchor_known_answer(oracle):
     dict(A=3, H=13, W=21, stride=64, pre=2000, post=2000, train=False),   # count < pre
     dict(A=3, H=13, W=21, stride=64, pre=-1, post=100, train=True),
     dict(A=3, H=25, W=42, stride=32, pre=1000, post=1500, train=True, thr=0.3, min_size=64)])
-def test_proposal_v3_matches_oracle(ops, oracle, cfg):
+@pytest.mark.parametrize("topk", [0, 1, 2])  # by level size / single workgroup / multi-workgroup
+def test_proposal_v3_matches_oracle(ops, oracle, cfg, topk):
+    from simpledet_amd._lib import lib
     scales = cfg.get("scales", (8,))
     ratios = (0.5, 1.0, 2.0)
     cls, bb, info = synth.rpn_outputs(3, 2, cfg["A"], cfg["H"], cfg["W"], cfg["stride"])
     thr, ms = cfg.get("thr", 0.7), cfg.get("min_size", 16)
     want = oracle.proposal_v3(cls, bb, info, cfg["pre"], cfg["post"], thr, ms, scales, ratios,
                               cfg["stride"], cfg["train"])
-    out, score = ops.proposal_v3(_t(cls), _t(bb), _t(info), cfg["pre"], cfg["post"], thr, ms, scales,
-                                 ratios, cfg["stride"], cfg["train"])
+    lib().set_tuning("proposal_topk", topk)
+    try:
+        out, score = ops.proposal_v3(_t(cls), _t(bb), _t(info), cfg["pre"], cfg["post"], thr, ms,
+                                     scales, ratios, cfg["stride"], cfg["train"])
+    finally:
+        lib().set_tuning("proposal_topk", 0)
     np.testing.assert_array_equal(score.cpu().numpy(), want[1])
     np.testing.assert_array_equal(out.cpu().numpy(), want[0])
 
 
 @pytest.mark.gpu
-def test_proposal_v3_score_ties_are_stable(ops, oracle):
+@pytest.mark.parametrize("topk", [1, 2])
+def test_proposal_v3_score_ties_are_stable(ops, oracle, topk):
+    from simpledet_amd._lib import lib
     cls, bb, info = synth.rpn_outputs(5, 1, 3, 50, 84, 16)
     cls[:, 3:] = np.round(cls[:, 3:] * 32) / 32   # thousands of exactly tied scores
     want = oracle.proposal_v3(cls, bb, info, 1000, 1000, 0.7, 0, (8,), (0.5, 1, 2), 16, False)
-    out, score = ops.proposal_v3(_t(cls), _t(bb), _t(info), 1000, 1000, 0.7, 0, (8,), (0.5, 1, 2), 16)
+    lib().set_tuning("proposal_topk", topk)
+    try:
+        out, score = ops.proposal_v3(_t(cls), _t(bb), _t(info), 1000, 1000, 0.7, 0, (8,),
+                                     (0.5, 1, 2), 16)
+    finally:
+        lib().set_tuning("proposal_topk", 0)
     np.testing.assert_array_equal(score.cpu().numpy(), want[1])
     np.testing.assert_array_equal(out.cpu().numpy(), want[0])
 
