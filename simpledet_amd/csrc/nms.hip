@@ -451,19 +451,21 @@ __device__ __forceinline__ void proposal_gather_filter(const PropArgs& a, int im
   }
 }
 
-__global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // P2 composite keys
-  __shared__ int hist[260];
-  __shared__ int ncand;
-  const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-  const float* sc = a.score_all + (long)img * a.count;
+// Stable top-`pre` of `count` scores by one workgroup: 8-bit radix select of the pre-th best score
+// key, a second select on the row index when the ties at that key are only partly taken, unordered
+// compaction of the selected rows into composite (key, row) words and an LDS sort of the P2 >= pre
+// words.  keys[0 .. pre) end up in the order of a stable descending sort.
+__device__ __forceinline__ void select_sort_topk(const float* __restrict__ sc, int count, int pre,
+                                                 int P2, unsigned long long* keys, int* hist,
+                                                 int* ncand) {
+  const int tid = threadIdx.x, T = blockDim.x;
   auto skey = [&](int i) { return ordered_desc_bits(sc[i]); };  // ascending key = best score first
   // ---- the pre-th smallest score key ----
   unsigned prefix = 0, mask = 0;
-  int want = a.pre, last_bucket = 0;
+  int want = pre, last_bucket = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     int below;
-    const int d = radix_digit(a.count, shift, mask, prefix, want, hist, &below, &last_bucket, skey);
+    const int d = radix_digit(count, shift, mask, prefix, want, hist, &below, &last_bucket, skey);
     want -= below;
     prefix |= (unsigned)d << shift;
     mask |= 255u << shift;
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
     for (int shift = 24; shift >= 0; shift -= 8) {
       int below, bucket;
       // rows that do not carry Tkey map to 0xffffffff and never match a prefix below 2^24 rows
-      const int d = radix_digit(a.count, shift, imask, ipre, iwant, hist, &below, &bucket, ikey);
+      const int d = radix_digit(count, shift, imask, ipre, iwant, hist, &below, &bucket, ikey);
       iwant -= below;
       ipre |= (unsigned)d << shift;
       imask |= 255u << shift;
@@ -488,29 +490,37 @@ __global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
     Irow = ipre;
   }
   // ---- unordered compaction of the selected rows into composite keys, then sort ----
-  if (tid == 0) ncand = 0;
-  for (int i = tid; i < a.P2; i += T) keys[i] = ~0ull;
+  if (tid == 0) *ncand = 0;
+  for (int i = tid; i < P2; i += T) keys[i] = ~0ull;
   __syncthreads();
-  for (int i0 = 0; i0 < a.count; i0 += 8 * T) {
+  for (int i0 = 0; i0 < count; i0 += 8 * T) {
     unsigned kk[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * T + tid;
-      kk[u] = i < a.count ? skey(i) : 0xffffffffu;
+      kk[u] = i < count ? skey(i) : 0xffffffffu;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * T + tid;
       const unsigned k = kk[u];
-      if (i < a.count && (k < Tkey || (k == Tkey && (unsigned)i <= Irow))) {
-        const int pos = atomicAdd(&ncand, 1);
-        if (pos < a.P2) keys[pos] = ((unsigned long long)k << 32) | (unsigned)i;
+      if (i < count && (k < Tkey || (k == Tkey && (unsigned)i <= Irow))) {
+        const int pos = atomicAdd(ncand, 1);
+        if (pos < P2) keys[pos] = ((unsigned long long)k << 32) | (unsigned)i;
       }
     }
   }
   __syncthreads();
-  bitonic_sort_lds(keys, a.P2, tid, T);
-  proposal_gather_filter(a, img, keys, tid, T);
+  bitonic_sort_lds(keys, P2, tid, T);
+}
+
+__global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // P2 composite keys
+  __shared__ int hist[260];
+  __shared__ int ncand;
+  const int img = blockIdx.x;
+  select_sort_topk(a.score_all + (long)img * a.count, a.count, a.pre, a.P2, keys, hist, &ncand);
+  proposal_gather_filter(a, img, keys, threadIdx.x, blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -874,17 +884,23 @@ struct TopArgs {
   const float* score;
   float4* out_bbox;
   float* out_score;
-  int N, top_n, P2;
+  int N, top_n, P2, select;
 };
 
 __global__ __launch_bounds__(1024) void top_proposal_kernel(TopArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ int hist[260];
+  __shared__ int ncand;
   const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const float* sc = a.score + (long)img * a.N;
-  for (int i = tid; i < a.P2; i += T)
-    keys[i] = i < a.N ? (((unsigned long long)ordered_desc_bits(sc[i]) << 32) | (unsigned)i) : ~0ull;
-  __syncthreads();
-  bitonic_sort_lds(keys, a.P2, tid, T);
+  if (a.select) {  // top_n < N: select first, sort only the P2 >= top_n survivors
+    select_sort_topk(sc, a.N, a.top_n, a.P2, keys, hist, &ncand);
+  } else {
+    for (int i = tid; i < a.P2; i += T)
+      keys[i] = i < a.N ? (((unsigned long long)ordered_desc_bits(sc[i]) << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(keys, a.P2, tid, T);
+  }
   for (int i = tid; i < a.top_n; i += T) {
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     float s = 0.f;
@@ -906,9 +922,17 @@ extern "C" int sd_get_top_proposal(const float* bbox, const float* score, int B,
   SD_REQUIRE((((uintptr_t)bbox | (uintptr_t)out_bbox) & 15) == 0, "bbox must be 16-byte aligned");
   int P2 = 64;
   while (P2 < N) P2 <<= 1;
-  SD_REQUIRE(P2 <= kMaxSortKeys, "get_top_proposal: N=%d exceeds %d", N, kMaxSortKeys);
+  int P2t = 64;
+  while (P2t < top_n) P2t <<= 1;
+  // fewer rows wanted than given: radix select, then sort the survivors only (N is then bounded by
+  // the 2^24 rows of the select, not by the LDS sort capacity)
+  const int select = (top_n < N && P2t < P2 && tuning("top_proposal_select", 1)) ? 1 : 0;
+  if (select) P2 = P2t;
+  SD_REQUIRE(P2 <= kMaxSortKeys, "get_top_proposal: N=%d / top_n=%d exceeds %d", N, top_n,
+             kMaxSortKeys);
+  SD_REQUIRE(N < (1 << 24), "get_top_proposal: N=%d >= 2^24", N);
   TopArgs a{reinterpret_cast<const float4*>(bbox), score, reinterpret_cast<float4*>(out_bbox),
-            out_score, N, top_n, P2};
+            out_score, N, top_n, P2, select};
   const size_t lds = (size_t)P2 * sizeof(unsigned long long);
   if (lds > 64 * 1024)
     SD_HIP_CHECK(hipFuncSetAttribute((const void*)top_proposal_kernel,

@@ -40,6 +40,7 @@ Knob g_knobs[] = {
     {"roi_align_bwd_threads", 0, false}, // 256 or 512 (default)
     {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes (default)
     {"proposal_topk", 0, false},         // 0 by level size (default), 1 single workgroup, 2 multi-workgroup
+    {"top_proposal_select", 0, false},   // 1 radix select before the sort when top_n < N (default)
     {"nms_scan", 0, false},              // 0 single-wave scan, 1 (default) block scan
     {"soft_nms_threads", 0, false},
     {"proposal_target_shuffle", 0, false},
