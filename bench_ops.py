@@ -129,6 +129,25 @@ def run(seed=0, cpu=True, only=None):
             except Exception:
                 pass
 
+    # ---- mask-head RoIAlign: fused FPN extractor, 14x14, 128 fg RoIs / image (BASELINE configs[4]) ----
+    if want("roi_align_14x14"):
+        feats = [torch.randn((2, 256, h, w), device="cuda") for h, w in synth.FPN_SHAPES]
+        r14 = T(synth.random_rois(seed, 2, 128))
+        strides4 = [4, 8, 16, 32]
+        o14, am14 = ops.fpn_roi_align_forward_packed(feats, r14, strides4, (14, 14))
+        dy14 = torch.randn_like(o14)
+        shapes = [f.shape for f in feats]
+        grads = [torch.empty_like(f) for f in feats]
+        ms_f = _time_gpu(lambda: ops.fpn_roi_align_forward_packed(feats, r14, strides4, (14, 14)))
+        ms_b = _time_gpu(lambda: ops.fpn_roi_align_backward_packed(dy14, r14, am14, shapes, strides4,
+                                                                    d_feats=grads))
+        alg = sum(4 * f.numel() for f in feats) + 16 * r14.shape[0] * r14.shape[1] + 3 * 4 * o14.numel()
+        res["roi_align_14x14"] = {"fwd_ms": ms_f, "bwd_ms": ms_b, "algorithmic_bytes": alg,
+                                  "fwd_frac": alg / ms_f / 1e6 / PEAK_HBM_GBS,
+                                  "bwd_frac": alg / ms_b / 1e6 / PEAK_HBM_GBS,
+                                  "config": "P2-P5 256ch 800x1333, N=2, 128 RoIs/img, 14x14, packed arg-max"}
+        del feats, o14, am14, dy14, grads
+
     # ---- ROIPooling_v1: C4 map (2,1024,50,84), 1024 rois, 7x7 ----
     if want("roi_pool_v1"):
         rs = np.random.RandomState(seed)
