@@ -442,7 +442,7 @@ void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restri
   for (int c = c0; c < c1; ++c) {
     const long ch = (long)n * g.C + (long)grp * cpg + c;
     __syncthreads();  // the previous channel's readers are done
-    dcn_stage_plane(xs, x + ch * plane + wstart, wcount, (vec & 1) != 0, tid, T);
+    if (!(nt & 2)) dcn_stage_plane(xs, x + ch * plane + wstart, wcount, (vec & 1) != 0, tid, T);
     __syncthreads();
     float* out = col + ch * K2 * P;  // wave-uniform base + 32-bit lane offset
 #pragma unroll
@@ -453,10 +453,11 @@ void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restri
         const Corners q = dcn_corners(xs, in, g.W);
         float val = (w1[tap] * q.x1 + w2[tap] * q.x2 + w3[tap] * q.x3 + w4[tap] * q.x4);
         if (!(in & kDcnInside)) val = 0.f;
-        if (live) {
-          if (nt) __builtin_nontemporal_store(val, out + (tap * P + p));
+        if (live && !(nt & 4)) {
+          if (nt & 1) __builtin_nontemporal_store(val, out + (tap * P + p));
           else out[tap * P + p] = val;
         }
+        if ((nt & 4) && val == 12345.678f) out[0] = val;  // profiling only: keep the value alive
       }
     }
   }
@@ -827,7 +828,7 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
     constexpr int T = 256;
     const int vec = (((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0) |
                     (tuning("dcn_window", 1) ? 0 : 2);
-    const int nt = tuning("dcn_im2col_nt", 1);
+    const int nt = tuning("dcn_im2col_nt", 1);  // bit 0 non-temporal; bits 1-2 profiling only
     int nsplit = tuning("dcn_im2col_split", 1);
     if (nsplit < 1 || nsplit > C / dgroup) nsplit = 1;
     if (kh * kw == 9)
