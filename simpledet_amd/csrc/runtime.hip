@@ -41,15 +41,12 @@ Knob g_knobs[] = {
     {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes (default)
     {"proposal_topk", 0, false},         // 0 by level size (default), 1 single workgroup, 2 multi-workgroup
     {"top_proposal_select", 0, false},   // 1 radix select before the sort when top_n < N (default)
-    {"nms_scan", 0, false},              // 0 single-wave scan, 1 (default) block scan
-    {"soft_nms_threads", 0, false},
-    {"proposal_target_shuffle", 0, false},
-    {"deform_gemm", 0, false},
+    {"soft_nms_threads", 0, false},      // threads per problem: 64, 128 or 256 (default)
     {"deform_gemm_bk", 0, false},    // K extent of a GEMM tile: 16 (default) or 32
     {"deform_gemm_j", 0, false},     // GEMM tile width 64*J (1..3), 0 = by wave quantisation (default)
     {"dcn_im2col", 0, false},        // 1 LDS-plane im2col (default), 0 per-lane global gathers
     {"dcn_im2col_split", 0, false},  // channel splits per (image, group, pixel tile), default 1
-    {"dcn_im2col_nt", 0, false},     // 1 non-temporal col stores (default)
+    {"dcn_im2col_nt", 0, false},     // bit 0: non-temporal col stores (default 1); bits 1-2 profiling only
     {"dcn_window", 0, false},        // 1 stage only the touched range of each plane (default)
     {"dcn_coord", 0, false},         // 1 LDS-plane offset gradient (default), 0 per-lane gathers
 };
