@@ -171,12 +171,12 @@ def run(seed=0, cpu=True, only=None):
         off = torch.randn((N, 72, H, W), device="cuda") * 2
         wt = torch.randn((F, C, 3, 3), device="cuda") * 0.05
         ms_i = _time_gpu(lambda: ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4), iters=20, warm=2)
-        ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=5, warm=1)
+        ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=10, warm=2)
         y = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)
         dyc = torch.randn_like(y)
         grads = (torch.empty_like(x), torch.empty_like(off), torch.empty_like(wt))
         ms_b = _time_gpu(lambda: ops.deform_conv_backward(dyc, x, off, wt, 1, 1, 1, 4, grads=grads),
-                         iters=3, warm=1)
+                         iters=6, warm=2)
         colm = ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4)
         ms_c2i = _time_gpu(lambda: ops.deform_col2im(colm, off, x.shape, (3, 3), 1, 1, 1, 4), iters=10, warm=2)
         ms_crd = _time_gpu(lambda: ops.deform_col2im_coord(colm, x, off, (3, 3), 1, 1, 1, 4), iters=20, warm=2)
