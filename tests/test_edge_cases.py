@@ -1,0 +1,109 @@
+"""Empty and ragged inputs through every entry point (GPU): nothing may crash, hang or write, and
+the outputs keep the reference's shapes."""
+import numpy as np
+import pytest
+
+from simpledet_amd import synth
+
+STRIDES = [4, 8, 16, 32]
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+def test_empty_inputs(ops):
+    import torch
+    z = lambda *s: torch.zeros(s, device="cuda")  # noqa: E731
+    # RoIAlign_v2: no rois / no channels
+    out, mx, my = ops.roi_align_v2_forward(z(2, 4, 10, 12), z(2, 0, 4), (7, 7), 0.25)
+    assert out.shape == (2, 0, 4, 7, 7) and mx.shape == out.shape
+    dx = ops.roi_align_v2_backward(out, z(2, 0, 4), mx, my, (2, 4, 10, 12), 0.25)[0]
+    assert dx.shape == (2, 4, 10, 12) and float(dx.abs().max()) == 0  # kWriteTo with nothing to add
+    # fused FPN extractor, float and packed arg-max
+    feats = [z(1, 8, h, w) for h, w in [(20, 24), (10, 12), (5, 6), (3, 3)]]
+    o, mx, my = ops.fpn_roi_align_forward(feats, z(1, 0, 4), STRIDES, (7, 7))
+    assert o.shape == (1, 0, 8, 7, 7)
+    g = ops.fpn_roi_align_backward(o, z(1, 0, 4), mx, my, [f.shape for f in feats], STRIDES)
+    assert all(float(t.abs().max()) == 0 for t in g)
+    o, am = ops.fpn_roi_align_forward_packed(feats, z(1, 0, 4), STRIDES, (7, 7))
+    g = ops.fpn_roi_align_backward_packed(o, z(1, 0, 4), am, [f.shape for f in feats], STRIDES)
+    assert all(float(t.abs().max()) == 0 for t in g)
+    # ROIPooling_v1
+    o, ix = ops.roi_pool_v1_forward(z(2, 3, 8, 9), z(0, 5), (7, 7), 0.5)
+    assert o.shape == (0, 3, 7, 7)
+    dx, _ = ops.roi_pool_v1_backward(o, z(0, 5), ix, (2, 3, 8, 9), 0.5)
+    assert float(dx.abs().max()) == 0
+    # NMS / soft-NMS / IoU / top proposals
+    out, score = ops.nms(z(2, 0, 5), 10, 5, 0.7)[:2]
+    assert out.shape[0] == 2
+    od, oi, oc = ops.soft_nms_batched(z(3, 0, 5), None, 0.5, 0.3, 0.001, 1)
+    assert oc.shape == (3,) and int(oc.abs().max()) == 0
+    od, oi, oc = ops.soft_nms_batched(z(0, 10, 5), None, 0.5, 0.3, 0.001, 1)
+    assert oc.numel() == 0
+    assert ops.bbox_overlaps(z(0, 4), z(5, 4)).shape == (0, 5)
+    assert ops.bbox_overlaps(z(5, 4), z(0, 4)).shape == (5, 0)
+    ob, os_ = ops.get_top_proposal(z(2, 0, 4), z(2, 0, 1), 7)
+    assert ob.shape == (2, 7, 4) and float(ob.abs().max()) == 0 and float(os_.abs().max()) == 0
+    # decode / filter
+    b = ops.decode_bbox(z(2, 0, 4), z(2, 0, 8), torch.tensor([[100., 100., 1.]] * 2, device="cuda"),
+                        (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2), class_agnostic=False)
+    assert b.shape[1] == 0
+    # DeformableConvolution with an empty batch
+    y = ops.deform_conv_forward(z(0, 8, 9, 11), z(0, 72, 9, 11), z(6, 8, 3, 3), 1, 1, 1, 4)
+    assert y.shape == (0, 6, 9, 11)
+    # anchors of an empty map
+    assert ops.gen_anchor(0, 5, 16, [8], [0.5, 1, 2]).numel() == 0
+
+
+@pytest.mark.gpu
+def test_proposal_target_without_ground_truth_or_foreground(ops, oracle):
+    """All gt rows padded with -1 (no object in the image): every sampled roi is background."""
+    rois, gt = synth.proposal_target_inputs(3, 2, 300, 20)
+    gt[1, :, :] = -1
+    want = oracle.proposal_target(rois, gt, oracle.make_pt_param(81, 2, 64), rng=oracle.GlibcRand(1))
+    state = ops.glibc_rand_state(1)
+    got = ops.proposal_target(_t(rois), _t(gt), 81, 2, 64, rng_state=state)
+    for g, w in zip(got[:2], want[:2]):  # rois, labels
+        np.testing.assert_array_equal(g.cpu().numpy().reshape(w.shape), w)
+
+
+@pytest.mark.gpu
+def test_fpn_roi_align_many_rois_per_image(ops, oracle):
+    """3000 RoIs per image: long per-band RoI lists in the backward's LDS, many forward workgroups."""
+    feats = synth.feature_maps(9, batch=1, channels=4)
+    rois = synth.random_rois(9, 1, 3000)
+    want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (7, 7))
+    tf = [_t(f) for f in feats]
+    out, am = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, (7, 7))
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+    o2, mx, my = ops.fpn_roi_align_forward(tf, _t(rois), STRIDES, (7, 7))
+    np.testing.assert_array_equal(mx.cpu().numpy(), want[1])
+    np.testing.assert_array_equal(my.cpu().numpy(), want[2])
+    dy = np.random.RandomState(2).standard_normal(want[0].shape).astype(np.float32)
+    wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], [f.shape for f in feats], STRIDES)
+    g1 = ops.fpn_roi_align_backward_packed(_t(dy), _t(rois), am, [f.shape for f in feats], STRIDES)
+    g2 = ops.fpn_roi_align_backward(_t(dy), _t(rois), mx, my, [f.shape for f in feats], STRIDES)
+    for a, b, w in zip(g1, g2, wd):
+        s = max(1.0, float(np.abs(w).max()))
+        assert np.abs(a.cpu().numpy() - w).max() <= 1e-4 * s
+        assert np.abs(b.cpu().numpy() - w).max() <= 1e-4 * s
+
+
+@pytest.mark.gpu
+def test_nms_and_soft_nms_at_capacity(ops, oracle):
+    """The largest sizes the in-LDS kernels accept: 16384 boxes for NMS, 4096 for soft-NMS."""
+    d = synth.nms_dets(4, 16384)[None]
+    want = oracle.nms(d, 6000, 1000, 0.7)
+    got = ops.nms(_t(d), 6000, 1000, 0.7)
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+    np.testing.assert_array_equal(got[1].cpu().numpy(), want[1])
+    s = synth.nms_dets(5, 4096)
+    wk = oracle.soft_nms(s, 0.5, 0.3, 0.01, 1)
+    od, oi, oc = ops.soft_nms_batched(_t(s[None]), None, 0.5, 0.3, 0.01, 1)
+    n = int(oc[0])
+    assert n == len(wk[0])
+    np.testing.assert_array_equal(od[0, :n].cpu().numpy(), wk[0])
+    np.testing.assert_array_equal(oi[0, :n].cpu().numpy(), wk[1])
