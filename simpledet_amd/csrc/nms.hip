@@ -106,8 +106,9 @@ __device__ __forceinline__ float dev_iou(float a0, float a1, float a2, float a3,
   return interS / (Sa + Sb - interS);
 }
 
-// Transposed suppression matrix: T[col][rb] = bit r set  <=>  box (rb*64 + r) suppresses box col
-// (IoU over the threshold, r ranked before col).  Lanes hold the 64 row boxes of block rb, the 64
+// Transposed suppression matrix, word-major: T[rb][col] = bit r set  <=>  box (rb*64 + r) suppresses
+// box col (IoU over the threshold, r ranked before col).  Word-major so that the 64 lanes of the
+// scan (consecutive boxes) read one contiguous 512-byte run per word instead of 64 rows.  Lanes hold the 64 row boxes of block rb, the 64
 // column boxes of block cb are broadcast through SGPRs; the word of one column IS the wave's
 // v_cmp result (ballot).  devIoU is symmetric in its arguments bit for bit (max/min and the float
 // additions commute), so this is the reference's mask read column-wise.
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(MaskArgs a) {
     if (rb == cb) m &= (1ull << c) - 1;  // only rows ranked before the column (start = tid + 1)
     if (lane == c) word = m;
   }
-  if (col < a.pre) a.ws.mask[((long)img * a.pre + col) * a.nb + rb] = word;
+  if (col < a.pre) a.ws.mask[((long)img * a.nb + rb) * a.pre + col] = word;
 }
 
 struct ScanArgs {
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(ScanArgs a) {
       cur |= fre | sup;
       live = ~cur;
     }
-    if (lane == 0) kw[rb] = keepmask;
+    if (a.nb > 32 && lane == 0) kw[rb] = keepmask;  // LDS copy only for the generic path
     // PrepareOutput (nms.cu:207-233) for the boxes kept in this block
     if (keepmask & (1ull << lane)) {
       const int rank = nkeep + __popcll(keepmask & ((1ull << lane) - 1));
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(ScanArgs a) {
       }
     }
     nkeep += __popcll(keepmask);
+    return keepmask;
   };
   // everything a block needs from global memory (its row of T, its diagonal row word, its box)
   // is fetched one block ahead so that no load latency sits on the block-to-block chain
@@ -219,53 +221,81 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(ScanArgs a) {
     }
     return p;
   };
-  constexpr int NBF = 32;  // fast path: the next block's row of T is fetched during this block's resolve
+  constexpr int NBF = 32;  // fast path: the next block's words of T are fetched during this block's resolve
   if (a.nb <= NBF) {
-    unsigned long long cw[NBF + 1];  // words 0..rb of the current block's boxes (word rb = diagonal)
+    // The whole scan is ONE wave's instruction stream, so the per-block instruction count is the
+    // run time: the keep words of the earlier blocks live in SGPRs (no LDS round trip, used as
+    // scalar operands), and every loop over the words is cut off in groups of 8 by a wave-uniform
+    // branch (only words <= rb matter).
+    unsigned long long wa[NBF + 1], wb[NBF + 1];  // words 0..rb of two consecutive blocks (ping-pong)
+    unsigned long long kwr[NBF];                   // keep masks of the resolved blocks (wave-uniform)
 #pragma unroll
-    for (int w = 0; w <= NBF; ++w) cw[w] = 0;
-    if (lane < a.pre) cw[0] = T[(long)lane * a.nb];
-    Pre cp = fetch(lane, lane < a.pre);
-    for (int rb = 0; rb < a.nb; ++rb) {
-      if (nkeep >= a.post) break;  // only the first `post` kept boxes are ever output
+    for (int w = 0; w <= NBF; ++w) wa[w] = wb[w] = 0;
+#pragma unroll
+    for (int w = 0; w < NBF; ++w) kwr[w] = 0;
+    if (lane < a.pre) wa[0] = T[lane];
+    Pre pa = fetch(lane, lane < a.pre), pb = pa;
+    // one block: cw / cp = this block's words and box (fetched during the previous block), nw / np
+    // receive the next block's
+    auto block = [&](int rb, unsigned long long (&cw)[NBF + 1], unsigned long long (&nw)[NBF + 1],
+                     const Pre& cp, Pre& np) {
       const int c = rb * kWave + lane;
       const bool valid = c < a.pre;
       // issue the loads of block rb + 1 now; they complete while this block is resolved
-      unsigned long long nw[NBF + 1];
       const int cn = c + kWave;
       const bool nvalid = rb + 1 < a.nb && cn < a.pre;
-      const unsigned long long* Tn = T + (long)(nvalid ? cn : 0) * a.nb;
+      const unsigned long long* Tn = T + (nvalid ? cn : 0);
 #pragma unroll
-      for (int w = 0; w <= NBF; ++w) nw[w] = (nvalid && w <= rb + 1) ? Tn[w] : 0ull;
-      const Pre np = fetch(cn, nvalid);
+      for (int g = 0; g <= NBF; g += 8) {
+        if (g <= rb + 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int w = g + e;
+            if (w <= NBF) nw[w] = (nvalid && w <= rb + 1) ? Tn[(long)w * a.pre] : 0ull;
+          }
+        }
+      }
+      np = fetch(cn, nvalid);
       unsigned long long acc = 0, diag = 0;
 #pragma unroll
-      for (int w = 0; w <= NBF; ++w) {
-        if (w < rb) acc |= cw[w] & kw[w];
-        if (w == rb) diag = cw[w];
-      }
-      resolve(rb, valid, acc, diag, cp.bx, cp.sc, cp.ord);
+      for (int g = 0; g <= NBF; g += 8) {
+        if (g <= rb) {
 #pragma unroll
-      for (int w = 0; w <= NBF; ++w) cw[w] = nw[w];
-      cp = np;
+          for (int e = 0; e < 8; ++e) {
+            const int w = g + e;
+            if (w < NBF && w < rb) acc |= cw[w] & kwr[w];
+            if (w <= NBF && w == rb) diag = cw[w];
+          }
+        }
+      }
+      const unsigned long long km = resolve(rb, valid, acc, diag, cp.bx, cp.sc, cp.ord);
+#pragma unroll
+      for (int w = 0; w < NBF; ++w)
+        if (w == rb) kwr[w] = km;
+    };
+    for (int rb = 0; rb < a.nb; rb += 2) {
+      if (nkeep >= a.post) break;  // only the first `post` kept boxes are ever output
+      block(rb, wa, wb, pa, pb);
+      if (rb + 1 >= a.nb || nkeep >= a.post) break;
+      block(rb + 1, wb, wa, pb, pa);
     }
   } else {
     for (int rb = 0; rb < a.nb; ++rb) {
       if (nkeep >= a.post) break;
       const int c = rb * kWave + lane;
       const bool valid = c < a.pre;
-      const unsigned long long* Tc = T + (long)(valid ? c : 0) * a.nb;
+      const unsigned long long* Tc = T + (valid ? c : 0);
       unsigned long long acc = 0;
       for (int w0 = 0; w0 < rb; w0 += 16) {
         unsigned long long t[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) t[e] = (w0 + e < rb) ? Tc[w0 + e] : 0ull;
+        for (int e = 0; e < 16; ++e) t[e] = (w0 + e < rb) ? Tc[(long)(w0 + e) * a.pre] : 0ull;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           if (w0 + e < rb) acc |= t[e] & kw[w0 + e];
       }
       const Pre p = fetch(c, valid);
-      resolve(rb, valid, acc, valid ? Tc[rb] : 0ull, p.bx, p.sc, p.ord);
+      (void)resolve(rb, valid, acc, valid ? Tc[(long)rb * a.pre] : 0ull, p.bx, p.sc, p.ord);
     }
   }
   if (nkeep > a.post) nkeep = a.post;
