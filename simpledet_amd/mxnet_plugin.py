@@ -523,12 +523,20 @@ def _build_ops(mx):
 
     ops["_contrib_DeformableConvolution"] = (DeformConvProp, ("contrib", "DeformableConvolution"))
 
+    def _fpn_packed(pooled):
+        return tuple(pooled) in ((7, 7), (14, 14))
+
     # ---- fpn_roi_align: the whole FPNRoiAlign.get_roi_feature subgraph (models/FPN/builder.py:
     #      567-610: assign -> per level ROIAlign_v2 -> add_n) as ONE op: feats..., rois -> output ----
     class FPNRoIAlign(CustomOp):
+        """outputs: output, then the op's private forward -> backward state.  7x7 / 14x14 pooling:
+        one-byte arg-max + the per-RoI coordinate / tap table (sd_fpn_roi_align_fwd_packed);
+        other sizes: the reference's two fp32 arg-max planes."""
+
         def __init__(self, strides, pooled, scale0, lvl0):
             super().__init__()
             self.strides, self.pooled, self.scale0, self.lvl0 = strides, pooled, scale0, lvl0
+            self.packed = _fpn_packed(pooled)
 
         def _levels(self, feats):
             ptrs = (ctypes.c_void_p * len(feats))(*[_ptr(f).value for f in feats])
@@ -541,10 +549,11 @@ def _build_ops(mx):
             ptrs, Hs, Ws = self._levels(feats)
             wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, rois.shape[1])
             ws = _scratch(rois, wsb)
-            lib().call("sd_fpn_roi_align_fwd", ptrs, Hs, Ws, _iarr(self.strides), len(feats),
-                       _ptr(rois), _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), B, C,
-                       rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
-                       float(self.lvl0), _ptr(ws), ctypes.c_size_t(wsb), None)
+            lib().call("sd_fpn_roi_align_fwd_packed" if self.packed else "sd_fpn_roi_align_fwd", ptrs,
+                       Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois), _ptr(out_data[0]),
+                       _ptr(out_data[1]), _ptr(out_data[2]), B, C, rois.shape[1], self.pooled[0],
+                       self.pooled[1], float(self.scale0), float(self.lvl0), _ptr(ws),
+                       ctypes.c_size_t(wsb), None)
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
@@ -555,10 +564,10 @@ def _build_ops(mx):
                 raise RuntimeError("fpn_roi_align: all feature gradients must share one req")
             B, C = feats[0].shape[:2]
             ptrs, Hs, Ws = self._levels(in_grad[:-1])
-            lib().call("sd_fpn_roi_align_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
-                       _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B,
-                       C, rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
-                       float(self.lvl0), None)
+            lib().call("sd_fpn_roi_align_bwd_packed" if self.packed else "sd_fpn_roi_align_bwd",
+                       _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]), _ptr(out_data[2]), ptrs, Hs,
+                       Ws, _iarr(self.strides), len(feats), rq.pop(), B, C, rois.shape[1],
+                       self.pooled[0], self.pooled[1], float(self.scale0), float(self.lvl0), None)
             _sync()
             self.assign(in_grad[-1], req[-1], 0)
 
@@ -569,12 +578,13 @@ def _build_ops(mx):
             self.rcnn_stride = _tuple(rcnn_stride, typ=int)
             self.pooled_size = _tuple(pooled_size, 2, int)
             self.scale0, self.lvl0 = float(roi_canonical_scale), float(roi_canonical_level)
+            self.packed = _fpn_packed(self.pooled_size)
 
         def list_arguments(self):
             return ["data_s{}".format(s) for s in self.rcnn_stride] + ["rois"]
 
         def list_outputs(self):
-            return ["output", "maxidx_x", "maxidx_y"]
+            return ["output", "argmax", "coords"] if self.packed else ["output", "maxidx_x", "maxidx_y"]
 
         num_visible_outputs = 1
 
@@ -583,7 +593,14 @@ def _build_ops(mx):
             if len(b) != 3 or b[2] != 4:
                 raise ValueError("bbox should be a 3D tensor of shape [batch, rois, 4]")
             o = (b[0], b[1], feats[0][1], self.pooled_size[0], self.pooled_size[1])
+            if self.packed:
+                return in_shape, [o, o, (b[0], b[1], 9 * (self.pooled_size[0] + self.pooled_size[1]))]
             return in_shape, [o, o, o]
+
+        def infer_type(self, in_type):
+            import numpy as np
+            f32 = np.float32
+            return in_type, [f32, np.uint8 if self.packed else f32, f32], []
 
         def create_operator(self, ctx, shapes, dtypes):
             return FPNRoIAlign(self.rcnn_stride, self.pooled_size, self.scale0, self.lvl0)

@@ -103,7 +103,13 @@ def test_fused_fpn_roi_align_prop(plugin):
     assert p.list_arguments() == ["data_s4", "data_s8", "data_s16", "data_s32", "rois"]
     assert p.num_visible_outputs == 1
     shapes = [(2, 256, 200, 334), (2, 256, 100, 167), (2, 256, 50, 84), (2, 256, 25, 42), (2, 512, 4)]
-    assert p.infer_shape(shapes)[1] == [(2, 512, 256, 7, 7)] * 3
+    # 7x7: output + the op's private state (one-byte arg-max, per-RoI coordinate / tap table)
+    assert p.list_outputs() == ["output", "argmax", "coords"]
+    assert p.infer_shape(shapes)[1] == [(2, 512, 256, 7, 7), (2, 512, 256, 7, 7), (2, 512, 126)]
+    assert [np.dtype(t) for t in p.infer_type([np.float32] * 5)[1]] == [np.float32, np.uint8, np.float32]
+    q = props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)", pooled_size="(5, 5)")
+    assert q.list_outputs() == ["output", "maxidx_x", "maxidx_y"]
+    assert q.infer_shape(shapes)[1] == [(2, 512, 256, 5, 5)] * 3
 
 
 def test_symbol_alias_builds_custom_node_with_visible_outputs(plugin):
@@ -164,3 +170,33 @@ def test_adapter_forward_backward_on_gpu(plugin, oracle):
     op.forward(False, ["write"] * 2, [w(torch.from_numpy(dets).cuda())], o, [])
     wn = oracle.nms(dets, 500, 100, 0.7)
     np.testing.assert_array_equal(o[0].t.cpu().numpy(), wn[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pooled", [(7, 7), (5, 5)])
+def test_fused_fpn_roi_align_adapter_on_gpu(plugin, oracle, pooled):
+    """The fused CustomOp (packed state for 7x7, float arg-max planes otherwise) against the oracle."""
+    import torch
+    from simpledet_amd import synth
+    _, props, _ = plugin
+    w = mx_stub.wrap
+    strides = [4, 8, 16, 32]
+    feats = synth.feature_maps(3, batch=2, channels=8)
+    rois = synth.random_rois(3, 2, 40)
+    want = oracle.fpn_roi_align_fwd(feats, rois, strides, pooled)
+    prop = props["fpn_roi_align"](rcnn_stride=str(tuple(strides)), pooled_size=str(pooled))
+    _, oshape = prop.infer_shape([f.shape for f in feats] + [rois.shape])
+    _, otype, _ = prop.infer_type([np.float32] * 5)
+    tmap = {np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}
+    op = prop.create_operator(None, None, None)
+    tin = [w(torch.from_numpy(f).cuda()) for f in feats] + [w(torch.from_numpy(rois).cuda())]
+    tout = [w(torch.empty(s, device="cuda", dtype=tmap[np.dtype(t)])) for s, t in zip(oshape, otype)]
+    op.forward(True, ["write"] * 3, tin, tout, [])
+    np.testing.assert_array_equal(tout[0].t.cpu().numpy(), want[0])
+    dy = np.random.RandomState(1).standard_normal(want[0].shape).astype(np.float32)
+    wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], [f.shape for f in feats], strides)
+    gin = [w(torch.empty_like(t.t)) for t in tin]
+    op.backward(["write"] * 5, [w(torch.from_numpy(dy).cuda())], tin, tout, gin, [])
+    for g, wv in zip(gin[:-1], wd):
+        assert np.abs(g.t.cpu().numpy() - wv).max() <= 1e-4 * max(1.0, float(np.abs(wv).max()))
+    assert float(gin[-1].t.abs().max()) == 0
