@@ -214,11 +214,84 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
     have_best = true;
     if (CTRL[1] == i) {
       // ---- replay "swap with the last box, shrink, re-examine" on the flag words (one wave) ----
-      if (wave == 0) {
+      const int nw = (M + 63) / 64;
+      bool keep_best = false;  // uniform over the workgroup (depends on nw only)
+      if (nw <= kWave) {
+        // Fast path (<= 4096 remaining boxes).  The flag words sit in the lanes of wave 0 and are
+        // read with v_readlane, so the hole / last-box walk is scalar code without LDS round
+        // trips; it only RECORDS the moves (hole <- last surviving box), lane k holding move k.
+        // The moves never depend on each other (every source lies behind every hole), so a batch
+        // of up to 64 is then executed by the lanes in parallel.  The arg-max of the remaining
+        // boxes folded during this step stays valid: a moved box changes position only, so the
+        // best position is re-derived from the moved boxes that carry the best score (ties keep
+        // "lowest position wins") instead of rescanning every score.
+        keep_best = true;
+        if (wave == 0) {
+          const unsigned long long fw = lane < nw ? FW[lane] : 0ull;
+          auto word = [&](int w) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)fw, w);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(fw >> 32), w);
+            return ((unsigned long long)hi << 32) | lo;
+          };
+          auto flag = [&](int r) { return (word(r >> 6) >> (r & 63)) & 1ull; };
+          auto next_hole = [&](int from) {  // first flagged rel position >= from, or a huge value
+            int w = from >> 6;
+            if (w >= nw) return 1 << 30;
+            unsigned long long m = word(w) & (~0ull << (from & 63));
+            while (!m) {
+              if (++w >= nw) return 1 << 30;
+              m = word(w);
+            }
+            return (w << 6) + __ffsll((long long)m) - 1;
+          };
+          Cand gb{0.f, -1};  // arg-max of the remaining boxes, positions before the moves
+#pragma unroll
+          for (int w = 0; w < NW; ++w) gb = better(gb, Cand{PS[w], PP[w]});
+          int bpos = gb.pos;
+          int mv_h = 0, mv_s = 0;  // this lane's move: absolute positions hole <- source
+          auto flush = [&](int cnt) {
+            if (cnt == 0) return;
+            int cand = 0x7fffffff;
+            bool is_best = false;
+            if (lane < cnt) {
+              float v[6];
+#pragma unroll
+              for (int f = 0; f < 6; ++f) v[f] = smem[f * Nmax + mv_s];
+#pragma unroll
+              for (int f = 0; f < 6; ++f) smem[f * Nmax + mv_h] = v[f];
+              is_best = mv_s == bpos;
+              if (gb.pos >= 0 && v[4] == gb.s) cand = mv_h;  // carries the best score (never NaN)
+            }
+            if (__any(is_best)) bpos = 0x7fffffff;  // the recorded best itself moved: it is in `cand`
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cand = iminr(cand, __shfl_xor(cand, o));
+            bpos = iminr(bpos, cand);
+          };
+          int Mc = M, nmv = 0;
+          int hole = next_hole(0);
+          while (hole < Mc) {
+            --Mc;  // the last box leaves its place
+            if (Mc == hole) break;       // the hole was the last box
+            if (flag(Mc)) continue;      // moved into the hole, examined, removed as well
+            if (lane == (nmv & (kWave - 1))) {
+              mv_h = i + 1 + hole;
+              mv_s = i + 1 + Mc;
+            }
+            if ((++nmv & (kWave - 1)) == 0) flush(kWave);
+            hole = next_hole(hole + 1);
+          }
+          flush(nmv & (kWave - 1));
+          if (lane == 0) {
+            CTRL[0] = i + 1 + Mc;
+            PS[0] = gb.s;
+            PP[0] = gb.pos >= 0 ? bpos : -1;
+          }
+          if (lane > 0 && lane < NW) PP[lane] = -1;
+        }
+      } else if (wave == 0) {
         int Mc = M;
-        const int nw = (M + 63) / 64;
         auto flag = [&](int r) { return (FW[r >> 6] >> (r & 63)) & 1ull; };
-        auto next_hole = [&](int from) {  // first flagged rel position >= from, or Mc
+        auto next_hole = [&](int from) {  // first flagged rel position >= from, or a huge value
           int w = from >> 6;
           if (w >= nw) return 1 << 30;
           unsigned long long m = FW[w] & (~0ull << (from & 63));
@@ -240,7 +313,7 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
       }
       __syncthreads();
       N = CTRL[0];
-      have_best = false;  // positions moved: recompute the arg-max from scratch
+      have_best = keep_best;  // slow path: positions moved, recompute the arg-max from scratch
     }
   }
 
