@@ -262,10 +262,12 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
               is_best = mv_s == bpos;
               if (gb.pos >= 0 && v[4] == gb.s) cand = mv_h;  // carries the best score (never NaN)
             }
-            if (__any(is_best)) bpos = 0x7fffffff;  // the recorded best itself moved: it is in `cand`
+            if (__any(cand != 0x7fffffff)) {  // rare: a moved box carries the best score
+              if (__any(is_best)) bpos = 0x7fffffff;  // the recorded best itself moved: it is in `cand`
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cand = iminr(cand, __shfl_xor(cand, o));
-            bpos = iminr(bpos, cand);
+              for (int o = 32; o > 0; o >>= 1) cand = iminr(cand, __shfl_xor(cand, o));
+              bpos = iminr(bpos, cand);
+            }
           };
           int Mc = M, nmv = 0;
           int hole = next_hole(0);
