@@ -89,8 +89,9 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
   const int nwords = (Nmax + 63) / 64 + 1;
   float* PS = reinterpret_cast<float*>(FW + nwords);
   int* PP = reinterpret_cast<int*>(PS + NW);
-  int* CTRL = PP + NW;  // [0] = N, [1] = step stamp of the last removal, [2..3] = queue lengths
+  int* CTRL = PP + NW;  // [0] = N, [1] = step stamp of the last removal
   int* LIST = CTRL + 4;
+  const int qcap = (((Nmax + kWave - 1) / kWave + NW - 1) / NW) * kWave;  // queue words per wave
 
   int n = a.counts ? a.counts[p] : Nmax;
   n = n < 0 ? 0 : (n > Nmax ? Nmax : n);
@@ -103,8 +104,6 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
   if (tid == 0) {
     CTRL[0] = n;
     CTRL[1] = -1;
-    CTRL[2] = 0;
-    CTRL[3] = 0;
   }
   __syncthreads();
 
@@ -151,8 +150,11 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
     // of lanes instead of in every 64-box chunk.  Untouched boxes enter the next arg-max here.
     Cand c{0.f, -1};
     const int M = N - (i + 1);
-    int* QL = LIST;                  // queue of overlapping positions
-    int* qn = CTRL + 2 + (i & 1);    // its length (two counters, alternating steps)
+    // every wave queues the overlapping boxes of ITS chunks in its own segment (length in a
+    // register: no LDS atomic, and no barrier between the two passes -- pass 2 of a wave only
+    // touches boxes and flag words of that wave's chunks)
+    int* QL = LIST + wave * qcap;
+    int nq = 0;
     for (int chunk = wave; chunk * kWave < M; chunk += NW) {
       const int rel = chunk * kWave + lane;
       const int pos = i + 1 + rel;
@@ -170,20 +172,13 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
         if (!ovl && s == s) c = better(c, Cand{s, pos});
       }
       const unsigned long long bal = __ballot(ovl);
-      if (bal) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(qn, __popcll(bal));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (ovl) QL[base + __popcll(bal & ((1ull << lane) - 1))] = pos;
-      }
+      if (ovl) QL[nq + __popcll(bal & ((1ull << lane) - 1))] = pos;
+      nq += __popcll(bal);
       if (lane == 0) FW[chunk] = 0ull;
     }
-    if (tid == 0) CTRL[2 + ((i + 1) & 1)] = 0;  // the other counter, for the next step
-    __syncthreads();
     // ---- pass 2 (queued boxes only): IoU, decay, removal flag ----
     bool any_removed = false;
-    const int nq = *qn;
-    for (int e = tid; e < nq; e += THREADS) {
+    for (int e = lane; e < nq; e += kWave) {
       const int pos = QL[e], rel = pos - (i + 1);
       const float x1 = X1[pos], y1 = Y1[pos], x2 = X2[pos], y2 = Y2[pos], s = S[pos];
       const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
@@ -371,7 +366,8 @@ extern "C" int sd_soft_nms_batched(const float* dets, const int32_t* counts, int
   int T = tuning("soft_nms_threads", 256);
   if (T != 64 && T != 128) T = 256;
   const size_t lds = (((size_t)6 * Nmax + 1) & ~(size_t)1) * 4 + ((size_t)(Nmax + 63) / 64 + 1) * 8 +
-                     (size_t)(T / kWave) * 8 + 16 + (size_t)Nmax * 4;
+                     (size_t)(T / kWave) * 8 + 16 +
+                     (size_t)((((Nmax + 63) / 64 + T / kWave - 1) / (T / kWave)) * 64) * (T / kWave) * 4;
   SD_REQUIRE(lds <= 160 * 1024, "soft_nms: Nmax=%d needs %zu B of LDS (limit 160 KB)", Nmax, lds);
   SoftArgs a{dets, counts, out_dets, out_inds, out_counts, P, Nmax, sigma, Nt, threshold, method};
 #define SD_SOFT(TT)                                                                              \
