@@ -189,9 +189,12 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
 //     28 (TYPE_3 keeps front = rear + 3), so the unrolled recurrence reg[s] += reg[(s+28) % 31]
 //     has static register indices: ~3 instructions per draw instead of a chain of LDS round trips;
 // (2) j_i = draw_i % (i+1) for all i in parallel;
-// (3) only the first `take` shuffled entries are ever used, and the origin of output position p
-//     follows from walking the swaps backwards (i = n-1 .. 1: at i == cur the content came from
-//     j_i; at j_i == cur it came from i, which no earlier swap can touch): one thread per output.
+// (3) only the first `take` shuffled entries are ever used.  Output position p is decided by the
+//     LAST swap from above that writes it (last[p] = max i with j_i == p, one LDS atomic-max pass
+//     over the swaps): it holds list[last[p]], untouched by any earlier swap.  Positions no later
+//     swap writes (probability (p+1)/n) keep what step p left: those walk the swaps i <= p
+//     backwards (at i == cur the content came from j_i; at j_i == cur it came from i), i.e. at most
+//     `take` steps instead of n.  One thread per output.
 // The rare multi-round negative padding (proposal_target.cc:116-122 with fewer negatives than
 // missing rows) needs the whole permuted list between rounds and replays the swaps in order.
 struct RingRegs {
@@ -249,12 +252,13 @@ __device__ void shuffle_list(int* list, int n, unsigned* ring, int& f, int& b) {
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pt_sample_kernel(PtArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int lds[];  // [list: Ncand][draws / j: Ncand]
+  extern __shared__ __attribute__((aligned(16))) int lds[];  // [list: Ncand][draws / j: Ncand][last: Ncand]
   __shared__ unsigned ring[31];
   __shared__ int fb[2];
   const int tid = threadIdx.x;
   int* lists = lds;
   int* draws = lds + a.Ncand;
+  int* last = lds + 2 * a.Ncand;  // last[k] = the largest i with j_i == k (0: none)
   if (tid < 31) ring[tid] = (unsigned)a.rng[tid];
   if (tid == 0) {
     fb[0] = a.rng[31];
@@ -265,26 +269,41 @@ __global__ __launch_bounds__(THREADS) void pt_sample_kernel(PtArgs a) {
   // out[0..take) = first `take` entries of random_shuffle(list[0..n)); consumes n-1 draws
   auto shuffled_prefix = [&](const int* list, int n, int take, int* out) {
     draw_many<THREADS>(ring, fb, draws, n - 1);
-    for (int i = 1 + tid; i < n; i += THREADS) draws[i - 1] = draws[i - 1] % (i + 1);  // j_i
+    for (int i = tid; i < n; i += THREADS) last[i] = 0;
+    __syncthreads();
+    for (int i = 1 + tid; i < n; i += THREADS) {
+      const int j = draws[i - 1] % (i + 1);  // j_i
+      draws[i - 1] = j;
+      if (j != i) atomicMax(&last[j], i);    // the last swap that writes position j from above
+    }
     __syncthreads();
     for (int p = tid; p < take; p += THREADS) {
+      // If some later swap (i > p, j_i == p) writes position p, the last of them decides: it
+      // brings list[i], which no earlier swap can have touched.  Otherwise position p holds what
+      // step p left there, and only the swaps i <= p matter: walk those backwards (at i == cur
+      // the content came from j_i; at j_i == cur it came from i, which ends the walk).
+      const int L = last[p];
       int cur = p;
-      // j_i are read eight at a time (independent LDS loads); once cur has moved up to some i no
-      // later (smaller) i can match it, so the walk simply runs to the end without a branch
-      int i = n - 1;
-      for (; i >= 8; i -= 8) {
-        int j[8];
+      if (L > p) {
+        cur = L;
+      } else {
+        // j_i are read eight at a time (independent LDS loads); once cur has moved up to some i
+        // no later (smaller) i can match it, so the walk simply runs on without a branch
+        int i = p;
+        for (; i >= 8; i -= 8) {
+          int j[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) j[e] = draws[i - 1 - e];
+          for (int e = 0; e < 8; ++e) j[e] = draws[i - 1 - e];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int ii = i - e;
-          cur = (cur == ii) ? j[e] : ((cur == j[e]) ? ii : cur);
+          for (int e = 0; e < 8; ++e) {
+            const int ii = i - e;
+            cur = (cur == ii) ? j[e] : ((cur == j[e]) ? ii : cur);
+          }
         }
-      }
-      for (; i >= 1; --i) {
-        const int j = draws[i - 1];
-        cur = (cur == i) ? j : ((cur == j) ? i : cur);
+        for (; i >= 1; --i) {
+          const int j = draws[i - 1];
+          cur = (cur == i) ? j : ((cur == j) ? i : cur);
+        }
       }
       out[p] = list[cur];
     }
@@ -520,7 +539,7 @@ extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int 
   SD_REQUIRE(lds1 <= 64 * 1024, "too many gt boxes per image (M=%d)", M);
   hipLaunchKernelGGL((pt_assign_kernel<1024>), dim3(B), dim3(1024), lds1, st, a);
   SD_LAUNCH_CHECK();
-  const size_t lds2 = (size_t)(a.Ncand > 0 ? a.Ncand : 1) * 2 * sizeof(int);
+  const size_t lds2 = (size_t)(a.Ncand > 0 ? a.Ncand : 1) * 3 * sizeof(int);
   SD_REQUIRE(lds2 <= 150 * 1024, "too many candidate rois per image (%d)", a.Ncand);
   if (lds2 > 64 * 1024)
     SD_HIP_CHECK(hipFuncSetAttribute((const void*)pt_sample_kernel<512>,
