@@ -33,23 +33,60 @@ __device__ __forceinline__ unsigned ordered_desc_bits(float f) {
   return ~u;                                        // descending
 }
 
-// ascending bitonic sort of P2 (power of two) 64-bit keys in LDS by the whole workgroup
+// ascending bitonic sort of P2 (power of two) 64-bit keys in LDS by the whole workgroup.
+// Stages with a pair distance j <= 64 only exchange inside aligned 128-key blocks, so a wave that
+// owns such a block runs them back to back with no workgroup barrier (the LDS accesses of one wave
+// are ordered): 2048 keys need 15 barriers instead of 66.
+// orders the LDS accesses of the lanes of ONE wave against each other for the compiler (the
+// hardware already executes a wave's LDS instructions in order): without it a lane's loads of the
+// next stage may be hoisted above the other lanes' stores of this one
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void bitonic_stage(unsigned long long* keys, int t, int j, int k) {
+  // pair (lo, lo + j) of the bitonic network; direction from bit k of lo
+  const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+  const int hi = lo + j;
+  const unsigned long long x = keys[lo], y = keys[hi];
+  const bool up = (lo & k) == 0;
+  if ((x > y) == up) {
+    keys[lo] = y;
+    keys[hi] = x;
+  }
+}
+
 __device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int P2, int tid, int T) {
-  for (int k = 2; k <= P2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < P2 / 2; t += T) {
-        // pair (lo, lo + j) of the bitonic network; direction from bit k of lo
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int hi = lo + j;
-        const unsigned long long x = keys[lo], y = keys[hi];
-        const bool up = (lo & k) == 0;
-        if ((x > y) == up) {
-          keys[lo] = y;
-          keys[hi] = x;
-        }
+  if (P2 < 128 || (T & (kWave - 1))) {  // tiny inputs: every stage with a barrier
+    for (int k = 2; k <= P2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < P2 / 2; t += T) bitonic_stage(keys, t, j, k);
+        __syncthreads();
       }
+    return;
+  }
+  const int lane = tid & (kWave - 1), wave = tid / kWave, nwaves = T / kWave;
+  // phases 2 .. 128: every aligned 128-key block is sorted by one wave on its own
+  for (int b = wave; b < P2 / 128; b += nwaves)
+    for (int k = 2; k <= 128; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        bitonic_stage(keys, b * kWave + lane, j, k);
+        wave_lds_sync();
+      }
+  __syncthreads();
+  for (int k = 256; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j >= 128; j >>= 1) {  // pairs across blocks: whole workgroup + barrier
+      for (int t = tid; t < P2 / 2; t += T) bitonic_stage(keys, t, j, k);
       __syncthreads();
     }
+    for (int b = wave; b < P2 / 128; b += nwaves)  // j = 64 .. 1 inside the blocks
+      for (int j = 64; j > 0; j >>= 1) {
+        bitonic_stage(keys, b * kWave + lane, j, k);
+        wave_lds_sync();
+      }
+    __syncthreads();
   }
 }
 
