@@ -46,6 +46,17 @@ __host__ __device__ static inline int iminr(int a, int b) { return a < b ? a : b
 
 constexpr int kWave = 64;      // CDNA wavefront
 constexpr int kNumXCD = 8;     // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+
+// Compiler-level ordering of the LDS accesses of the lanes of ONE wave (the hardware already
+// executes a wave's LDS instructions in order): without it a lane's loads may be hoisted above
+// the stores other lanes issue in the same instruction stream.  Emits no instruction.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
 constexpr int kNumCU = 256;
 
 }  // namespace sd

@@ -37,15 +37,6 @@ __device__ __forceinline__ unsigned ordered_desc_bits(float f) {
 // Stages with a pair distance j <= 64 only exchange inside aligned 128-key blocks, so a wave that
 // owns such a block runs them back to back with no workgroup barrier (the LDS accesses of one wave
 // are ordered): 2048 keys need 15 barriers instead of 66.
-// orders the LDS accesses of the lanes of ONE wave against each other for the compiler (the
-// hardware already executes a wave's LDS instructions in order): without it a lane's loads of the
-// next stage may be hoisted above the other lanes' stores of this one
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ __forceinline__ void bitonic_stage(unsigned long long* keys, int t, int j, int k) {
   // pair (lo, lo + j) of the bitonic network; direction from bit k of lo
   const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));

@@ -603,6 +603,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
               issue(pl + d * pstep, d, ch);
               commit(d, ch, dup_tag);
             }
+            wave_lds_sync();  // the tile was written by the fill lanes, read by the bin lanes
 #pragma unroll
             for (int b = 0; b < NI; ++b) {
               const int bin = lane + b * kWave;
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
                 }
               }
             }
+            wave_lds_sync();  // ... and is refilled for the next channel
           }
         }
         pl += D * pstep;

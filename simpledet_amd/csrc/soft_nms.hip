@@ -177,6 +177,7 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
       if (lane == 0) FW[chunk] = 0ull;
     }
     // ---- pass 2 (queued boxes only): IoU, decay, removal flag ----
+    wave_lds_sync();  // the queue and the old box i were written by other lanes of this wave
     bool any_removed = false;
     for (int e = lane; e < nq; e += kWave) {
       const int pos = QL[e], rel = pos - (i + 1);
