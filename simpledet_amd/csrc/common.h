@@ -56,6 +56,19 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// fp32 add into an LDS word by compare-and-swap.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on
+// gfx950 against ~2 for this loop and 4-9 for the integer LDS atomics (tools/lds_atomic_bench.hip,
+// tools/lds_scatter_bench.hip), so every gradient plane kept in LDS is accumulated this way.
+__device__ __forceinline__ void lds_add_cas(float* p, float v) {
+  int* ip = reinterpret_cast<int*>(p);
+  int old = *ip;
+  while (true) {
+    const int assumed = old;
+    old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + v));
+    if (old == assumed) break;
+  }
+}
 #endif
 constexpr int kNumCU = 256;
 

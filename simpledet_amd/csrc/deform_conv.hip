@@ -128,15 +128,6 @@ __device__ __forceinline__ float get_gradient_weight(float argmax_h, float argma
 // (image, channel) plane in LDS, accumulates the 9 taps x Ho*Wo col elements of that channel into
 // it with LDS compare-and-swap adds and writes the band to HBM once: no global atomics, no
 // zero-fill pass.  grid: x = channel, y = band, z = image.
-__device__ __forceinline__ void lds_add_cas_f32(float* p, float v) {
-  int* ip = reinterpret_cast<int*>(p);
-  int old = *ip;
-  while (true) {
-    const int assumed = old;
-    old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + v));
-    if (old == assumed) break;
-  }
-}
 
 __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restrict__ col,
                                                             const float* __restrict__ offset,
@@ -213,7 +204,7 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
         else if (ww == wh_) fwv = (aw + 1 - ww);
         else continue;
         const float w = fhv * fwv;
-        if (w != 0.f) lds_add_cas_f32(plane + (hh - row0) * g.W + ww, w * cur_top_grad);
+        if (w != 0.f) lds_add_cas(plane + (hh - row0) * g.W + ww, w * cur_top_grad);
       }
     }
    }

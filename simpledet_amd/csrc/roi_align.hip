@@ -703,23 +703,14 @@ __global__ __launch_bounds__(256) void roi_align_bwd_atomic(BwdArgs a) {
   }
 }
 
-// ds_add_f32 runs at ~0.33 lane-ops/clk/CU on gfx950 (measured, tools/lds_atomic_bench.hip) while
-// the integer LDS atomics (32 and 64 bit) run at ~4: more than 12x faster.  The gradient planes
-// are therefore accumulated in 64-bit fixed point with a per-workgroup power-of-two scale chosen
-// from max|dY| of the workgroup's own items (no overflow by construction).  Every tap value is
-// still computed in float exactly as the reference does (g*(1-a)*(1-b) ...); only the summation is
-// exact instead of float-in-arbitrary-order, which also makes the backward bit-reproducible.
-// Non-finite dY (inf/nan must propagate) falls back to float accumulation with a CAS loop.
-__device__ __forceinline__ void lds_add_cas(float* p, float v) {
-  int* ip = reinterpret_cast<int*>(p);
-  int old = *ip;
-  while (true) {
-    const int assumed = old;
-    old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + v));
-    if (old == assumed) break;
-  }
-}
-
+// Per-level plane kernel (knob roi_align_bwd = 1; also the fallback when the fused kernel does not
+// apply).  Besides the float compare-and-swap planes (lds_add_cas, common.h) it keeps a 64-bit
+// fixed-point variant (knob roi_align_bwd_accum = 1): a per-workgroup power-of-two scale chosen
+// from max|dY| of the workgroup's own items (no overflow by construction), every tap value still
+// computed in float exactly as the reference does, only the summation exact instead of
+// float-in-arbitrary-order -- a bit-reproducible backward.  It is not faster (ds_add_u64 sustains
+// no more adds than the CAS loop in this access pattern, tools/lds_scatter_bench.hip, and the
+// planes take twice the LDS).  Non-finite dY (inf/nan must propagate) falls back to the CAS loop.
 __device__ __forceinline__ void lds_add_fx(long long* p, float v, double scale) {
   const long long q = __double2ll_rn((double)v * scale);
   __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q,

@@ -110,15 +110,6 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(PoolBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // LDS-plane backward
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pool_lds_add(float* p, float v) {
-  int* ip = reinterpret_cast<int*>(p);
-  int old = *ip;
-  while (true) {
-    const int assumed = old;
-    old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + v));
-    if (old == assumed) break;
-  }
-}
 
 // grid: x = channel, y = row band, z = image
 __global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(PoolBwdArgs a, int band_rows,
@@ -145,7 +136,7 @@ __global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(PoolBwdArgs a, in
     const int n = list[it / a.PP], bin = it % a.PP;
     const long idx = ((long)n * a.C + c) * a.PP + bin;
     const int argmax = (int)a.maxidx[idx];
-    if (argmax >= lo && argmax < hi) pool_lds_add(plane + (argmax - lo), a.dy[idx]);
+    if (argmax >= lo && argmax < hi) lds_add_cas(plane + (argmax - lo), a.dy[idx]);
   }
   __syncthreads();
   float* dst = a.dx + (((long)b * a.C + c) * a.H + row0) * a.W;
