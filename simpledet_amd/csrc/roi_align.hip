@@ -1013,7 +1013,15 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
       px[k] = -1;
       fy[k] = fx[k] = vg[k] = 0.f;
       if (it < nitems) {
-        const int r = list[it / PP], bin = it % PP;
+        const int r = list[it / PP];
+        int bin = it % PP;
+        if (PP == 196 && !(a.ablate & 64)) {
+          // 14x14: most bins are narrower than a pixel, so 64 consecutive bins pile their taps onto
+          // a few pixels (5.5 CAS rounds per instruction, simulated); every third bin spreads a
+          // wave instruction over the whole RoI (3.8 rounds) at the price of 12-byte lane strides
+          bin *= 3;
+          bin -= bin >= 392 ? 392 : (bin >= 196 ? 196 : 0);
+        }
         const int idx = r * roi_stride + bin;
         if (PK) {
           const int code = amb[idx];

@@ -107,3 +107,24 @@ def test_nms_and_soft_nms_at_capacity(ops, oracle):
     assert n == len(wk[0])
     np.testing.assert_array_equal(od[0, :n].cpu().numpy(), wk[0])
     np.testing.assert_array_equal(oi[0, :n].cpu().numpy(), wk[1])
+
+
+@pytest.mark.gpu
+def test_fused_fpn_roi_align_14x14_mask_head(ops, oracle):
+    """The mask-head extractor (14x14, packed arg-max, strided bin order in the backward)."""
+    feats = synth.feature_maps(12, batch=2, channels=6)
+    rois = synth.random_rois(12, 2, 48)
+    want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (14, 14))
+    tf = [_t(f) for f in feats]
+    out, am = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, (14, 14))
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+    np.testing.assert_array_equal(am[0].cpu().numpy() == 255, want[1] == -1)
+    dy = np.random.RandomState(5).standard_normal(want[0].shape).astype(np.float32)
+    wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], [f.shape for f in feats], STRIDES)
+    gd = ops.fpn_roi_align_backward_packed(_t(dy), _t(rois), am, [f.shape for f in feats], STRIDES)
+    o2, mx, my = ops.fpn_roi_align_forward(tf, _t(rois), STRIDES, (14, 14))
+    g2 = ops.fpn_roi_align_backward(_t(dy), _t(rois), mx, my, [f.shape for f in feats], STRIDES)
+    for a, b, w in zip(gd, g2, wd):
+        s = max(1.0, float(np.abs(w).max()))
+        assert np.abs(a.cpu().numpy() - w).max() <= 1e-4 * s
+        assert np.abs(b.cpu().numpy() - w).max() <= 1e-4 * s
