@@ -87,6 +87,15 @@ def _scratch(like, nbytes):
     return mx.nd.empty(((int(nbytes) + 3) // 4,), ctx=like.context, dtype="float32")
 
 
+def _no_add(req):
+    """forward outputs: kWriteTo / kWriteInplace / kNullOp only.  The kernels overwrite their
+    outputs, so honouring kAddTo would need a temporary; no graph of the reference requests it
+    (MXNet uses kAddTo for gradients), hence it is refused loudly instead of silently ignored."""
+    for r in req:
+        if _req(r) == REQ["add"]:
+            raise RuntimeError("forward outputs do not support req='add' (kAddTo)")
+
+
 def _require_write(req, names):
     for r, n in zip(req, names):
         if _req(r) not in (REQ["write"], REQ["null"]):
@@ -106,6 +115,7 @@ def _build_ops(mx):
             self.scale = spatial_scale
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             data, rois = in_data
             _wait(data, rois)
             B, C, H, W = data.shape
@@ -169,6 +179,7 @@ def _build_ops(mx):
             self.scale = spatial_scale
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             data, rois = in_data
             _wait(data, rois)
             B, C, H, W = data.shape
@@ -224,6 +235,7 @@ def _build_ops(mx):
             self.p = p
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             from .ops import ProposalTargetParam
             _require_write(req[:4], ["roi_output", "label", "bbox_target", "bbox_weight"])
             rois, gt = in_data
@@ -308,6 +320,7 @@ def _build_ops(mx):
             self.scales, self.ratios, self.stride = scales, ratios, stride
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             _require_write(req[:1], ["output"])
             H, W = in_data[0].shape[2], in_data[0].shape[3]
             lib().call("sd_gen_anchor", _ptr(out_data[0]), H, W, self.stride, _darr(self.scales),
@@ -351,11 +364,20 @@ def _build_ops(mx):
             self.pre, self.post, self.thr, self.sorted = pre, post, thr, already_sorted
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             rois = in_data[0]
             _wait(rois)
             B, N, _ = rois.shape
             wsb = lib().cdll.sd_nms_workspace_bytes(B, N, self.pre)
             ws = _scratch(rois, wsb)
+            pre = min(self.pre if self.pre > 0 else N, N)
+            if self.post > pre:
+                # NMSProp::InferShape always declares (B, post, .) but the op writes min(post, pre)
+                # rows per image, image i at row offset i*min(post, pre) of the flat buffer
+                # (nms.cu:277,352-354), and never touches the tail.  Same bytes here; the tail
+                # (uninitialised in the reference) is zeroed.
+                self.assign(out_data[0], "write", 0)
+                self.assign(out_data[1], "write", 0)
             lib().call("sd_nms", _ptr(rois), B, N, self.pre, self.post, float(self.thr), 0,
                        int(self.sorted), _ptr(out_data[0]), _ptr(out_data[1]), None, _ptr(ws),
                        ctypes.c_size_t(wsb), None)
@@ -383,11 +405,6 @@ def _build_ops(mx):
             d = in_shape[0]
             if len(d) != 3 or d[2] != 5:
                 raise ValueError("Input:[bbox] must be (batch, rois, 5)")
-            pre = self.pre if self.pre > 0 else d[1]
-            if self.post > min(pre, d[1]):
-                # the reference writes image i at offset i*4*min(post, pre) into a (B, post, 4)
-                # buffer (nms.cu:277,352-354): only post <= pre is a consistent layout
-                raise ValueError("rpn_post_nms_top_n must not exceed the boxes that enter NMS")
             return in_shape, [(d[0], self.post, 4), (d[0], self.post, 1)]
 
         def create_operator(self, ctx, shapes, dtypes):
@@ -405,6 +422,7 @@ def _build_ops(mx):
             self.strides, self.scale0, self.lvl0 = strides, scale0, lvl0
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             rois = in_data[0]
             _wait(rois)
             n = 1
@@ -460,6 +478,7 @@ def _build_ops(mx):
             return _scratch(x, n), n
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             x, off, w = in_data
             _wait(x, off, w)
             g = self.g
@@ -543,6 +562,7 @@ def _build_ops(mx):
             return ptrs, _iarr([f.shape[2] for f in feats]), _iarr([f.shape[3] for f in feats])
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             feats, rois = in_data[:-1], in_data[-1]
             _wait(*in_data)
             B, C = feats[0].shape[:2]
@@ -617,6 +637,7 @@ def _build_ops(mx):
             self.g = g
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             cls_prob, bbox_pred, im_info = in_data
             _wait(cls_prob, bbox_pred, im_info)
             g = self.g
@@ -624,6 +645,13 @@ def _build_ops(mx):
             A = A2 // 2
             wsb = lib().cdll.sd_proposal_v3_workspace_bytes(B, A, H, W, g["pre"])
             ws = _scratch(cls_prob, wsb)
+            count = A * H * W
+            pre = min(g["pre"] if g["pre"] > 0 else count, count)
+            if g["is_train"] and g["post"] > pre:
+                # same quirk as _contrib_NMS (proposal_v3.cu:474-479,626-632): declared
+                # (B, post, .), written min(post, pre) rows per image, packed; tail zeroed here
+                self.assign(out_data[0], "write", 0)
+                self.assign(out_data[1], "write", 0)
             fa = lambda v: (ctypes.c_float * len(v))(*v)
             lib().call("sd_proposal_v3", _ptr(cls_prob), _ptr(bbox_pred), _ptr(im_info),
                        _ptr(out_data[0]), _ptr(out_data[1]), B, A, H, W, g["pre"], g["post"],
@@ -665,8 +693,7 @@ def _build_ops(mx):
             if A != len(g["scales"]) * len(g["ratios"]):
                 raise ValueError("num_anchors != len(ratios) * len(scales)")
             count = A * d[2] * d[3]
-            pre = min(g["pre"] if g["pre"] > 0 else count, count)
-            post = min(g["post"], pre) if g["is_train"] else g["post"]
+            post = g["post"]  # ProposalProp_v3::InferShape (proposal_v3-inl.h:199-218)
             return [d, (d[0], 4 * A, d[2], d[3]), (d[0], 3)], [(d[0], post, 4), (d[0], post, 1)]
 
         def create_operator(self, ctx, shapes, dtypes):
@@ -684,6 +711,7 @@ def _build_ops(mx):
             self.top_n = top_n
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             bbox, score = in_data
             _wait(bbox, score)
             lib().call("sd_get_top_proposal", _ptr(bbox), _ptr(score), bbox.shape[0], bbox.shape[1],
@@ -724,6 +752,7 @@ def _build_ops(mx):
             self.g = g
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
             _require_write(req[:1], ["output"])
             rois, pred, info = in_data
             _wait(rois, pred, info)
@@ -795,8 +824,7 @@ def install(mx=None):
     def make(name, prop):
         def ctor(*args, **kwargs):
             name_kw = kwargs.pop("name", None)
-            params = {k: (v if isinstance(v, str) else repr(v)) for k, v in kwargs.items()
-                      if not _is_symbol(mx, v)}
+            params = {k: _param_str(v) for k, v in kwargs.items() if not _is_symbol(mx, v)}
             inputs = {k: v for k, v in kwargs.items() if _is_symbol(mx, v)}
             sym = mx.sym.Custom(*args, op_type=_PREFIX + name, name=name_kw, **inputs, **params)
             p = prop(**params)
@@ -815,6 +843,18 @@ def install(mx=None):
         target = getattr(mx.sym, ns) if ns else mx.sym
         setattr(target, attr, make(name, props[name]))
     return props
+
+
+def _param_str(v):
+    """keyword argument -> the string MXNet's front end would send (str(value)); numpy scalars
+    are unwrapped first (numpy 2 prints np.float32(0.25) for repr)."""
+    if isinstance(v, str):
+        return v
+    if isinstance(v, (tuple, list)):
+        return "(" + ", ".join(_param_str(x) for x in v) + ("," if len(v) == 1 else "") + ")"
+    if hasattr(v, "item") and not isinstance(v, (bool, int, float)):
+        v = v.item()
+    return repr(v) if isinstance(v, float) else str(v)
 
 
 def _is_symbol(mx, v):

@@ -318,6 +318,20 @@ def glibc_rand_state(seed=1, device=None):
     return torch.tensor(list(host), dtype=torch.int32, device=device)
 
 
+_default_rng = {}
+
+
+def default_rng_state(device=None, reset_seed=None):
+    """The process-wide (per device) glibc rand() state ProposalTarget advances when the caller
+    passes none -- libc's global state in the reference.  reset_seed re-seeds it (srand)."""
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if reset_seed is not None or device not in _default_rng:
+        _default_rng[device] = glibc_rand_state(1 if reset_seed is None else reset_seed, device)
+    return _default_rng[device]
+
+
 def proposal_target(rois, gt_boxes, num_classes, batch_images, image_rois, fg_fraction=0.25,
                     fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0, proposal_without_gt=False,
                     class_agnostic=False, bbox_mean=(0., 0., 0., 0.), bbox_std=(.1, .1, .2, .2),
@@ -341,8 +355,15 @@ def proposal_target(rois, gt_boxes, num_classes, batch_images, image_rois, fg_fr
     for i in range(4):
         p.bbox_mean[i], p.bbox_std[i], p.bbox_weight[i] = bbox_mean[i], bbox_std[i], bbox_weight[i]
     if rng_state is None:
-        rng_state = glibc_rand_state(1, rois.device)
+        # the reference never calls srand: libc's global state starts at seed 1 and ADVANCES from
+        # call to call, so every step draws a fresh stretch of the rand() stream.  Keep one such
+        # state per device for callers that do not manage their own (mx.sym.ProposalTarget has no
+        # rng argument).
+        rng_state = default_rng_state(rois.device)
     _chk(rng_state, "rng_state", dtype=torch.int32, ndim=1)
+    if rng_state.numel() != 33:
+        raise ValueError("rng_state must hold 33 int32 words (glibc_rand_state), got %d"
+                         % rng_state.numel())
     S, K4 = int(image_rois), 4 * int(num_classes)
     dev = rois.device
     ro = torch.empty((B, S, 4), device=dev, dtype=torch.float32)

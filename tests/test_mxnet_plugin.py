@@ -70,8 +70,8 @@ def test_other_props_shapes(plugin):
     p = props["_contrib_NMS"](rpn_pre_nms_top_n="2000", rpn_post_nms_top_n="1000", threshold="0.7")
     assert p.list_outputs() == ["output", "score"] and p.num_visible_outputs == 1
     assert p.infer_shape([(2, 2000, 5)])[1] == [(2, 1000, 4), (2, 1000, 1)]
-    with pytest.raises(ValueError):
-        p.infer_shape([(2, 500, 5)])
+    # NMSProp::InferShape (nms-inl.h:90-103) declares (B, post, .) whatever the input count
+    assert p.infer_shape([(2, 500, 5)])[1] == [(2, 1000, 4), (2, 1000, 1)]
     p = props["assign_layer_fpn"](rcnn_stride="(4, 8, 16, 32)", roi_canonical_scale="224",
                                   roi_canonical_level="4")
     assert p.list_outputs() == ["rois_s4", "rois_s8", "rois_s16", "rois_s32"]
