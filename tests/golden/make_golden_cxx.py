@@ -34,7 +34,7 @@ def main():
         for k, v in res.items():
             assert not np.isnan(v).any(), (name, k, "the reference left part of the output unwritten")
             digests[name][k] = {"sha256": refcases.digest(v), "shape": list(v.shape), "dtype": str(v.dtype)}
-            if case["kind"] != "exact":
+            if case["kind"] != "exact" or k in case["hip_close"]:
                 arrays["%s/%s" % (name, k)] = v
         print("%-34s %s" % (name, " ".join("%s%s" % (k, tuple(v.shape)) for k, v in res.items())))
     with open(os.path.join(HERE, "ref_cxx_digests.json"), "w") as f:

@@ -301,8 +301,10 @@ def case_decode_bbox(class_agnostic, xyxy, seed=5):
 CASES = {}
 
 
-def _add(name, fn, kind="exact", oracle_exact=True):
-    CASES[name] = dict(run=fn, kind=kind, oracle_exact=oracle_exact)
+def _add(name, fn, kind="exact", oracle_exact=True, hip_close=None):
+    """hip_close: {output: tol} -- outputs the HIP kernel reproduces to |err| <= tol * max(1, |ref|)
+    instead of bit for bit (the oracle still matches them exactly)."""
+    CASES[name] = dict(run=fn, kind=kind, oracle_exact=oracle_exact, hip_close=hip_close or {})
 
 
 for _l in range(4):
@@ -321,10 +323,14 @@ _add("roi_pool_v1_bwd_gpu", case_roi_pool_bwd(), kind=("close", 1e-4))
 for _i in range(len(ANCHOR_CFGS)):
     _add("gen_anchor_%d_cpu" % _i, case_gen_anchor(_i, "cpu"))
     _add("gen_anchor_%d_gpu" % _i, case_gen_anchor(_i, "gpu"))
+# bbox_target holds log(gt_w / ex_w): glibc's logf on the host (and which of its ifunc variants runs
+# depends on the CPU) against the device logf -- 1e-6 relative; everything else, including the
+# libc rand() / random_shuffle replay that picks the rows, is bit-exact
+_PT_CLOSE = {"bbox_target": 2e-6}
 for _i in range(len(PT_CFGS)):
-    _add("proposal_target_%d" % _i, case_proposal_target(_i))
-_add("proposal_target_0_agnostic", case_proposal_target(0, class_agnostic=True))
-_add("proposal_target_1_third_call", case_proposal_target(1, calls=3))
+    _add("proposal_target_%d" % _i, case_proposal_target(_i), hip_close=_PT_CLOSE)
+_add("proposal_target_0_agnostic", case_proposal_target(0, class_agnostic=True), hip_close=_PT_CLOSE)
+_add("proposal_target_1_third_call", case_proposal_target(1, calls=3), hip_close=_PT_CLOSE)
 for _i in range(len(NMS_CFGS)):
     _add("nms_%d" % _i, case_nms(_i))
 for _i in range(len(PV3_CFGS)):

@@ -34,13 +34,18 @@ def _have_ref():
                                             "generate_anchor", "nms", "proposal_v3", "decodebbox"))
 
 
-def _check(name, res, exact):
+def _check(name, res, exact, hip=False):
     case = refcases.CASES[name]
     assert set(res) == set(DIGESTS[name]), (set(res), set(DIGESTS[name]))
     for k, v in res.items():
         meta = DIGESTS[name][k]
         assert list(v.shape) == meta["shape"] and str(v.dtype) == meta["dtype"], (name, k, v.shape)
-        if exact:
+        if hip and k in case["hip_close"]:
+            want = ARRAYS["%s/%s" % (name, k)]
+            err = np.abs(v.astype(np.float64) - want) / np.maximum(1.0, np.abs(want))
+            assert err.max() <= case["hip_close"][k], "%s/%s: rel err %g" % (name, k, err.max())
+            assert np.array_equal(v != 0, want != 0), "%s/%s: different rows / class slots" % (name, k)
+        elif exact:
             assert refcases.digest(v) == meta["sha256"], \
                 "%s/%s differs from what the reference's compiled operator produced" % (name, k)
         else:
@@ -53,8 +58,8 @@ def _check(name, res, exact):
 def test_every_case_has_a_fixture():
     assert set(DIGESTS) == set(NAMES)
     for name in NAMES:
-        if refcases.CASES[name]["kind"] != "exact":
-            for k in DIGESTS[name]:
+        for k in DIGESTS[name]:
+            if refcases.CASES[name]["kind"] != "exact" or k in refcases.CASES[name]["hip_close"]:
                 assert "%s/%s" % (name, k) in ARRAYS.files
 
 
@@ -138,7 +143,7 @@ def test_reference_roi_pool_docstring_vector():
 def test_hip_reproduces_reference(ops, name):
     case = refcases.CASES[name]
     res = refcases.run_case(name, "hip")
-    _check(name, res, exact=(case["kind"] == "exact"))
+    _check(name, res, exact=(case["kind"] == "exact"), hip=True)
 
 
 # ------------------------------------------------------------- operator interface (drop-in) ----
