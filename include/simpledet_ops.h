@@ -109,7 +109,12 @@ int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois, const float* 
  * and backward, not part of the reference's graph interface.  The backward looks the pair up, i.e.
  * uses exactly the values the float planes would have produced, without floor / clamp / divide
  * per gradient element.  Cuts the forward's writes from 3 to 1.25 planes and the backward's reads
- * likewise (7x7 and 14x14 pooling).  coords must be 8-byte aligned. */
+ * likewise (7x7 and 14x14 pooling).  coords must be 8-byte aligned.
+ * argmax layout: (B, R, C, sd_fpn_roi_align_argmax_stride(ph, pw)) bytes -- every (RoI, channel)
+ * row of ph*pw codes is padded to whole 4-byte words (7x7: 52, 14x14: 196) so that the backward
+ * fetches four codes with one aligned load; the padding bytes are never read as codes.  argmax
+ * must be 4-byte aligned. */
+int sd_fpn_roi_align_argmax_stride(int pooled_h, int pooled_w);
 int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_host,
                                 const int* Ws_host, const int* strides_host, int nlvl,
                                 const float* rois, float* out, uint8_t* argmax, float* coords, int B,

@@ -57,6 +57,31 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Wave-wide reductions on the VALU only (DPP butterfly inside each row of 16 lanes, then the four
+// row results through v_readlane): no LDS traffic, unlike __shfl_xor (ds_bpermute_b32).  The result
+// is wave-uniform.  Every lane must be active.
+#define SD_DPP_STEP(x, ctrl) __builtin_amdgcn_update_dpp((x), (x), (ctrl), 0xf, 0xf, false)
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = fmaxr(v, __int_as_float(SD_DPP_STEP(__float_as_int(v), 0xB1)));   // quad_perm [1,0,3,2]
+  v = fmaxr(v, __int_as_float(SD_DPP_STEP(__float_as_int(v), 0x4E)));   // quad_perm [2,3,0,1]
+  v = fmaxr(v, __int_as_float(SD_DPP_STEP(__float_as_int(v), 0x141)));  // row_half_mirror
+  v = fmaxr(v, __int_as_float(SD_DPP_STEP(__float_as_int(v), 0x140)));  // row_mirror
+  const int x = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+  return fmaxr(fmaxr(r0, r1), fmaxr(r2, r3));
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += SD_DPP_STEP(v, 0xB1);
+  v += SD_DPP_STEP(v, 0x4E);
+  v += SD_DPP_STEP(v, 0x141);
+  v += SD_DPP_STEP(v, 0x140);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+         __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 // fp32 add into an LDS word by compare-and-swap.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on
 // gfx950 against ~2 for this loop and 4-9 for the integer LDS atomics (tools/lds_atomic_bench.hip,
 // tools/lds_scatter_bench.hip), so every gradient plane kept in LDS is accumulated this way.

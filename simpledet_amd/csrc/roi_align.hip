@@ -113,9 +113,18 @@ __device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ p
   return o;
 }
 
+// Packed arg-max rows: one byte per output, each (RoI, channel) row padded to whole dwords so that
+// the backward fetches four codes with one aligned 4-byte load (7x7: 49 -> 52 bytes)
+__host__ __device__ constexpr int amax_stride(int pp) { return (pp + 3) & ~3; }
+
 // 8-byte load of two adjacent floats that is only 4-byte aligned
 struct __attribute__((packed, aligned(4))) F2u {
   float x, y;
+};
+
+// 16-byte load of four adjacent floats that is only 4-byte aligned
+struct __attribute__((packed, aligned(4))) F4u {
+  float x, y, z, w;
 };
 
 struct FwdArgs {
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
     if (a.L.nlvl > 1) o.val = o.val + 0.0f;  // add_n with the other levels' zeros
     a.out[index] = o.val;
     if (a.amax8) {
-      a.amax8[index] = (unsigned char)o.code;
+      a.amax8[((long)n * a.C + c) * amax_stride(PP) + ph * a.PW + pw] = (unsigned char)o.code;
     } else {
       a.ax[index] = o.ax;
       a.ay[index] = o.ay;
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
   constexpr int D = 1;  // channels in flight per wave (deeper batches measured slower)
   using S = FwdSmem<PH, PW, NROI>;
   constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, PPP = S::PPP, CH = S::CH, NWAVE = S::NWAVE;
+  constexpr int PPS = amax_stride(PP);  // bytes per (RoI, channel) row of the packed arg-max
   constexpr int THREADS = NWAVE * kWave;
   static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
   constexpr int NPAIR = NC / 2;                 // (left,right) column pairs per tile row
@@ -443,11 +453,12 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     const int lvl = t.lvl;
     if (lvl == -2) break;
     const long obase = ((long)n * a.C + cbeg) * PP;
+    const long abase = ((long)n * a.C + cbeg) * PPS;
     if (lvl < 0) {  // every per-level op sees a zero box
       for (int e = tid; e < nch * PP; e += THREADS) {
         a.out[obase + e] = 0.f;
         if (PK) {
-          a.amax8[obase + e] = 255;
+          a.amax8[abase + (e / PP) * PPS + e % PP] = 255;
         } else {
           a.ax[obase + e] = -1.f;
           a.ay[obase + e] = -1.f;
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
         if (a.L.nlvl > 1) o.val = o.val + 0.0f;
         a.out[obase + e] = o.val;
         if (PK) {
-          a.amax8[obase + e] = (unsigned char)o.code;
+          a.amax8[abase + c * PPS + bin] = (unsigned char)o.code;
         } else {
           a.ax[obase + e] = o.ax;
           a.ay[obase + e] = o.ay;
@@ -484,6 +495,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     if (lvl == -2) break;
     if (lvl < 0 || __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col)) continue;
     const long obase = ((long)n * a.C + cbeg) * PP;
+    const long abase = ((long)n * a.C + cbeg) * PPS;
     const int W = a.L.W[lvl];
     const long plane = (long)a.L.H[lvl] * W;
     const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
           if (bin < PP) {
             a.out[ob + bin] = 0.f;
             if (PK) {
-              a.amax8[ob + bin] = 255;
+              a.amax8[abase + (long)c * PPS + bin] = 255;
             } else {
               a.ax[ob + bin] = -1.f;
               a.ay[ob + bin] = -1.f;
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
       float* po = a.out + obase + (long)wave * PP;
       float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
       float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
-      unsigned char* pk = PK ? a.amax8 + obase + (long)wave * PP : nullptr;
+      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
       for (int c0 = wave; c0 < nch; c0 += D * NWAVE) {
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
                 if (a.L.nlvl > 1) maxval = maxval + 0.0f;
                 po[bin + d * NWAVE * PP] = maxval;
                 if (PK) {
-                  pk[bin + d * NWAVE * PP] = (unsigned char)(bk < 0 ? 255 : bk);
+                  pk[bin + d * NWAVE * PPS] = (unsigned char)(bk < 0 ? 255 : bk);
                 } else {
                   px[bin + d * NWAVE * PP] = bx;
                   py[bin + d * NWAVE * PP] = by;
@@ -643,7 +655,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
         pl += D * pstep;
         po += D * NWAVE * PP;
         if (PK) {
-          pk += D * NWAVE * PP;
+          pk += D * NWAVE * PPS;
         } else {
           px += D * NWAVE * PP;
           py += D * NWAVE * PP;
@@ -715,6 +727,11 @@ __device__ __forceinline__ void lds_add_fx(long long* p, float v, double scale) 
   const long long q = __double2ll_rn((double)v * scale);
   __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// fire-and-forget 32-bit fixed-point add (no return value, no dependent LDS round trip)
+__device__ __forceinline__ void lds_add_i32(int* p, float v, float scale) {
+  __hip_atomic_fetch_add(p, __float2int_rn(v * scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // One workgroup owns CPB channel planes (rows [row0,row1) of them) of one image in LDS.
@@ -996,7 +1013,8 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
   const float* dyb = a.dy + img_base;
   const float* axb = PK ? nullptr : a.ax + img_base;
   const float* ayb = PK ? nullptr : a.ay + img_base;
-  const unsigned char* amb = PK ? a.amax8 + img_base : nullptr;
+  const unsigned char* amb =
+      PK ? a.amax8 + ((long)img * a.R * a.C + c) * amax_stride(PP) : nullptr;
   // packed path: the forward's (neighbours, fraction) pairs of this image's RoIs
   const float* tapb =
       PK ? a.coords + (long)img * a.R * kCoordWords * (PH + PW) + 3 * (PH + PW) : nullptr;
@@ -1024,7 +1042,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
         }
         const int idx = r * roi_stride + bin;
         if (PK) {
-          const int code = amb[idx];
+          const int code = amb[r * (a.C * amax_stride(PP)) + bin];
           if (code != 255) {
             const float* tb = tapb + r * (kCoordWords * (PH + PW));
             const float2 ey = *reinterpret_cast<const float2*>(tb + 2 * ((bin / PW) * 3 + code / 3));
@@ -1112,8 +1130,338 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused backward of the packed path, wide-load version
+// ------------------------------------------------------------------------------------------------
+// Same decomposition as roi_align_bwd_fused (workgroup = (level, image, row band, channel), band of
+// the gradient plane in LDS, written to HBM once).  What changed is the item loop, which the SQ
+// counters showed to be bound by the NUMBER of vector-memory instructions (a wave64 load occupies
+// the address unit ~16 clocks whatever its width): the old loop issued four loads per (RoI, bin)
+// item -- arg-max byte, two 8-byte table entries, gradient -- 2.0 M wave instructions per launch.
+// Here
+//   * a lane owns FOUR consecutive bins of one RoI: one aligned 4-byte load brings their four
+//     arg-max codes (rows are padded to whole dwords, amax_stride) and one 16-byte load the four
+//     gradients: 0.5 load per item instead of 2;
+//   * the per-RoI sample-coordinate tables (3*(PH+PW) floats each, written by the forward) of the
+//     RoIs on the band are staged ONCE per workgroup into LDS with 8-byte loads; an item then picks
+//     its row / column coordinate with two ds_read_b32 and derives the neighbours and the
+//     interpolation fraction with the backward's own expressions (floor / ceil / clamp, v - low);
+//   * the band is accumulated in 32-bit FIXED POINT with plain integer LDS atomics (ds_add_u32,
+//     fire and forget: 3.5 adds/clk/CU against 1.9 for the float compare-and-swap loop whose two
+//     dependent LDS round trips per add were the longest chain of the workgroup).  Every tap value
+//     is still computed in fp32 exactly as the reference does; only the SUM is exact integer
+//     arithmetic on values rounded to 2^-S, so the result does not depend on the order of the
+//     adds: the backward is bit-reproducible from run to run.  S is chosen per workgroup from
+//     max|dY| of its own items and a rigorous bound on how much one pixel can receive, so the sum
+//     cannot overflow and one add is off by at most 2^-(S+1):
+//         pixel sum <= max|dY| * sum over the band's RoIs of nx*ny,
+//         nx = min(PW, floor(2 / bin width) + 2) = bins of the RoI whose sample can lie within one
+//         pixel of a given column (a bin adds total weight <= 1), ny likewise;
+//     at the baseline that is ~2e-6 * max|dY| per unit.  Non-finite dY (inf / nan must propagate)
+//     switches the workgroup to the float compare-and-swap adds.
+template <int PH, int PW, int THREADS, int TCH>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: four 512-thread workgroups per CU
+void roi_align_bwd_packed4(BwdFusedArgs a) {
+  constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4, TS = 3 * (PH + PW);
+  constexpr int CW = kCoordWords * (PH + PW);  // words per RoI in the forward's table
+  constexpr bool TAIL = (PP % 4) != 0;         // last lane of a RoI owns fewer than four bins
+  static_assert(TS % 2 == 0, "table rows are copied as float2");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  // ---- block -> (level, image, band, channel) ----
+  int li = 0;
+  while (li + 1 < a.nlaunch && (int)blockIdx.x >= a.block_end[li]) ++li;
+  const int lvl = a.order[li];
+  const int b0 = (int)blockIdx.x - (li ? a.block_end[li - 1] : 0);
+  const int H = a.L.H[lvl], W = a.L.W[lvl];
+  const float scale = a.L.scale[lvl];
+  const int nbands = a.nbands[lvl];
+  int u, c;
+  if (a.C % kNumXCD == 0) {  // an XCD keeps a contiguous channel range: dY/argmax lines stay in one L2
+    const int xcd = b0 % kNumXCD, j = b0 / kNumXCD, per = a.C / kNumXCD;
+    c = xcd * per + (j % per);
+    u = j / per;
+  } else {
+    c = b0 % a.C;
+    u = b0 / a.C;
+  }
+  const int img = u / nbands, band = u % nbands;
+  const int row0 = band * a.band_rows[lvl];
+  const int row1 = iminr(row0 + a.band_rows[lvl], H);
+  const int band_elems = (row1 - row0) * W;
+  const int plane_pad = (band_elems + 3) & ~3;
+  float* plane = smem;
+  float* tab = smem + plane_pad;                      // [TCH][TS] sample coordinates
+  int* list = reinterpret_cast<int*>(tab + TCH * TS);  // RoIs of this image on this band
+  int* nlist = list + a.R;  // [0] count [1] bound [2] max|dY| bits, first chunk [3] non-finite [4] max|dY| bits, all
+  int* plane_i = reinterpret_cast<int*>(smem);
+
+  // the RoI boxes are in flight while the band is zeroed
+  const bool has_r0 = tid < a.R;
+  float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (has_r0) rb0 = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + tid) * 4);
+  {
+    float4* p4 = reinterpret_cast<float4*>(smem);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
+  }
+  if (tid < 8) nlist[tid] = 0;
+  // The list is built in RoI order (ballot + prefix over the waves, no atomic slot counter): the
+  // first chunk, whose gradients set the fixed-point scale below, is then a deterministic set and
+  // the whole backward a deterministic function of its inputs.
+  constexpr int NW = THREADS / kWave;
+  int* wcnt = nlist + 8;  // [NW] RoIs taken per wave in the current sweep
+  const int wave = tid / kWave, lane = tid & (kWave - 1);
+  int base = 0, bound_sum = 0;
+  for (int r0 = 0; r0 < a.R; r0 += THREADS) {
+    const int r = r0 + tid;
+    bool take = r < a.R;
+    int weight = 0;
+    if (take) {
+      const float4 rb = r0 == 0 ? rb0 : *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
+      if (a.filter) take = fpn_level(rb.x, rb.y, rb.z, rb.w, a.L) == lvl;
+      if (take && nbands > 1) {
+        // conservative row range of every tap of this RoI (taps lie within the clipped bins +-1)
+        float s = fminr(fmaxr(rb.y * scale, 0.f), (float)(H - 1));
+        float e = fminr(fmaxr(rb.w * scale, 0.f), (float)(H - 1));
+        float lo = fminr(s, e) - 2.f, hi = fmaxr(s, e) + 2.f;
+        if (hi < (float)row0 || lo > (float)(row1 - 1)) take = false;
+      }
+      if (take) {
+        // bins of this RoI that can put weight on one pixel (see the header comment); a degenerate
+        // or NaN width compares false and counts every bin
+        // (hardware reciprocal, 1 ulp, with a 1e-5 safety factor: the count may only err upwards)
+        const float bwx = (rb.z - rb.x) * scale * (1.f / (float)PW), bwy = (rb.w - rb.y) * scale * (1.f / (float)PH);
+        const float fx = 2.00002f * __builtin_amdgcn_rcpf(bwx), fy = 2.00002f * __builtin_amdgcn_rcpf(bwy);
+        const int nx = (bwx > 0.f && fx < (float)PW) ? iminr((int)fx + 2, PW) : PW;
+        const int ny = (bwy > 0.f && fy < (float)PH) ? iminr((int)fy + 2, PH) : PH;
+        weight = nx * ny;
+      }
+    }
+    const unsigned long long mask = __ballot(take);
+    bound_sum += wave_sum_i32(weight);
+    if (r0 > 0) __syncthreads();  // wcnt of the previous sweep has been read
+    if (lane == 0) wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int off = base, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int n = wcnt[w];
+      if (w < wave) off += n;
+      total += n;
+    }
+    if (take) list[off + __popcll(mask & ((1ull << lane) - 1))] = r;
+    base += total;
+  }
+  if (lane == 0) atomicAdd(nlist + 1, bound_sum);
+  if (tid == 0) nlist[0] = base;
+  __syncthreads();
+  const int nl = *nlist;
+
+  // wave-uniform bases + 32-bit lane offsets (the launcher checks R*C*PP < 2^31)
+  const int roi_stride = a.C * PP;
+  const float* dyb = a.dy + (long)img * a.R * roi_stride + (long)c * PP;
+  const unsigned char* amb = a.amax8 + ((long)img * a.R * a.C + c) * PPS;
+  const int am_stride = a.C * PPS;
+  const float* cob = a.coords + (long)img * a.R * CW;
+
+  bool use_fx = !(a.ablate & 64);  // (ablate 64, profiling build: the float compare-and-swap adds)
+  float fx_scale = 1.f, fx_inv = 1.f;
+  struct Item {
+    float4 g;       // gradients of bins b0 .. b0+3
+    unsigned code;  // their four arg-max codes, one per byte (255: nothing pooled)
+    int j, b0;      // RoI slot (in the list / in the streamed chunk), first bin
+  };
+  auto load_item = [&](int t, int cb, int nli, Item& it) {
+    it.code = 0xffffffffu;
+    it.j = 0;
+    it.b0 = 0;
+    it.g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < nli) {
+      const int j = t / GP, g = t - j * GP;
+      const int r = list[cb + j];
+      it.j = j;
+      it.b0 = 4 * g;
+      unsigned code = *reinterpret_cast<const unsigned*>(amb + r * am_stride + 4 * g);
+      if (TAIL && g == GP - 1) {
+        // bins PP-4 .. PP-1 are fetched, only the last PP % 4 of them belong to this lane
+        constexpr int KEEP = PP % 4;
+        const F4u v = *reinterpret_cast<const F4u*>(dyb + r * roi_stride + (PP - 4));
+        float gg[4] = {v.x, v.y, v.z, v.w};
+        it.g = make_float4(gg[4 - KEEP], KEEP > 1 ? gg[KEEP > 1 ? 5 - KEEP : 0] : 0.f,
+                           KEEP > 2 ? gg[KEEP > 2 ? 6 - KEEP : 0] : 0.f, 0.f);
+        code |= 0xffffffffu << (8 * KEEP);  // the padding bytes of the row are not codes
+      } else {
+        const F4u v = *reinterpret_cast<const F4u*>(dyb + r * roi_stride + 4 * g);
+        it.g = make_float4(v.x, v.y, v.z, v.w);
+      }
+      it.code = code;
+    }
+  };
+  auto scatter_item = [&](const Item& it, int slot) {
+    if (it.code == 0xffffffffu) return;
+    const float* tj = tab + slot * TS;
+    const float gg[4] = {it.g.x, it.g.y, it.g.z, it.g.w};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int code = (it.code >> (8 * s)) & 0xff;
+      if (code == 255) continue;
+      const int bin = it.b0 + s;
+      const int p = bin / PW, q = bin - p * PW;
+      const int k = (code * 11) >> 5, l = code - 3 * k;  // code = 3k + l, k,l in 0..2
+      const float a_y = tj[p * 3 + k];
+      const float a_x = tj[3 * PH + q * 3 + l];
+      const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+      const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+      const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+      const int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+      // (v - low) / (high - low) with high - low == 1
+      const float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow);
+      const float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft);
+      const float g = gg[s];
+      const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
+      const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
+      const int o0 = (hlow - row0) * W, o1 = (hhigh - row0) * W;
+      if (use_fx) {
+        if (hlow >= row0 && hlow < row1) {
+          lds_add_i32(plane_i + o0 + wleft, w00, fx_scale);
+          lds_add_i32(plane_i + o0 + wright, w01, fx_scale);
+        }
+        if (hhigh >= row0 && hhigh < row1) {
+          lds_add_i32(plane_i + o1 + wleft, w10, fx_scale);
+          lds_add_i32(plane_i + o1 + wright, w11, fx_scale);
+        }
+        continue;
+      }
+      if (hlow >= row0 && hlow < row1) {
+        lds_add_cas(plane + o0 + wleft, w00);
+        lds_add_cas(plane + o0 + wright, w01);
+      }
+      if (hhigh >= row0 && hhigh < row1) {
+        lds_add_cas(plane + o1 + wleft, w10);
+        lds_add_cas(plane + o1 + wright, w11);
+      }
+    }
+  };
+
+  auto stage_tables = [&](int cb, int ncur) {
+    for (int i = tid; i < ncur * (TS / 2); i += THREADS) {
+      const int j = i / (TS / 2), e2 = i - j * (TS / 2);
+      const float2 v = *reinterpret_cast<const float2*>(cob + list[cb + j] * CW + 2 * e2);
+      *reinterpret_cast<float2*>(tab + j * TS + 2 * e2) = v;
+    }
+  };
+
+  // Fixed point needs a bound on max|dY| of the workgroup's items before the first add, but a
+  // sweep over all of them up front costs a second pass of loads (measured: +10 us per launch).
+  // So the scale is OPTIMISTIC: it is derived from the first chunk's items, which are in registers
+  // anyway (2^30 of the 2^31 range is used, so the true maximum may be up to twice that without
+  // any risk of overflow); every thread keeps the running maximum of what it actually streams, and
+  // if the workgroup-wide maximum turns out larger (heavy-tailed gradients; never for the
+  // near-Gaussian ones of the baseline), or a later item is non-finite, the band is zeroed and
+  // accumulated again with the exact maximum (or with float adds).  The result is the same
+  // deterministic function of the inputs either way.
+  auto abs4 = [](const float4& g) {
+    return fmaxr(fmaxr(fabsf(g.x), fabsf(g.y)), fmaxr(fabsf(g.z), fabsf(g.w)));
+  };
+  auto wave_max_to = [&](float m, int bad, int slot) {
+    m = wave_max_f32(m);
+    if ((tid & (kWave - 1)) == 0)  // non-negative floats order like their bit patterns
+      atomicMax(reinterpret_cast<unsigned*>(nlist + slot), __float_as_uint(m));
+    if (__any(bad) && (tid & (kWave - 1)) == 0) atomicOr(nlist + 3, 1);
+  };
+  auto set_scale = [&](float gmax) {
+    const float bound = gmax * (float)nlist[1];  // no pixel of the band can exceed this
+    if (!(bound <= FLT_MAX)) { use_fx = false; return; }
+    int e;
+    frexpf(bound, &e);  // bound < 2^e
+    const int S = iminr(30 - e, 126);
+    fx_scale = ldexpf(1.f, S);
+    fx_inv = ldexpf(1.f, -S);
+  };
+  Item cur;
+  load_item(tid, 0, iminr(TCH, nl) * GP, cur);
+  stage_tables(0, iminr(TCH, nl));
+  float m_all = abs4(cur.g);
+  int bad = !(m_all <= FLT_MAX);
+  if (use_fx) wave_max_to(m_all, bad, 2);
+  __syncthreads();
+  float gmax_used = 0.f;
+  if (use_fx) {
+    gmax_used = __uint_as_float((unsigned)nlist[2]);
+    if (nlist[3]) use_fx = false;  // non-finite gradients: float adds (a zeroed band is 0 in both formats)
+    else set_scale(gmax_used > 0.f ? gmax_used : 1.f);
+  }
+  bool synced = false;  // the scatter is already fenced by a barrier
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int cb = 0; cb < nl; cb += TCH) {
+      const int ncur = iminr(TCH, nl - cb);
+      const int nli = ncur * GP;  // lane items of this chunk
+      if (cb > 0 || attempt > 0) {
+        load_item(tid, cb, nli, cur);
+        __syncthreads();  // the previous chunk's tables are no longer read
+        stage_tables(cb, ncur);
+        __syncthreads();
+      }
+      for (int t = tid; t < nli; t += THREADS) {
+        Item nxt;
+        load_item(t + THREADS, cb, nli, nxt);
+        const float ag = abs4(cur.g);
+        bad |= !(ag <= FLT_MAX);
+        m_all = fmaxr(m_all, ag);
+        scatter_item(cur, cur.j);
+        cur = nxt;
+      }
+    }
+    if (!use_fx || attempt > 0) break;
+    // was the optimistic scale enough?  (checked behind the barrier that ends the scatter anyway)
+    wave_max_to(m_all, bad, 4);
+    __syncthreads();
+    const float gmax_true = __uint_as_float((unsigned)nlist[4]);
+    if (!nlist[3] && gmax_true <= 2.f * gmax_used) { synced = true; break; }  // also when all gradients are zero
+    __syncthreads();  // every thread has read the verdict before the band is cleared
+    // rare: accumulate the band again with the exact maximum (or with float adds)
+    {
+      float4* p4 = reinterpret_cast<float4*>(smem);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
+    }
+    if (nlist[3]) use_fx = false;
+    else set_scale(gmax_true);
+  }
+  if (!synced) __syncthreads();
+  const long off = (((long)img * a.C + c) * H + row0) * W;
+  float* dst = a.dx[lvl] + off;
+  if (((off | band_elems) & 3) == 0) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i = tid; i < band_elems / 4; i += THREADS) {
+      float4 v = reinterpret_cast<const float4*>(plane)[i];
+      if (use_fx) {
+        const int4 q = reinterpret_cast<const int4*>(plane_i)[i];
+        v = make_float4((float)q.x * fx_inv, (float)q.y * fx_inv, (float)q.z * fx_inv, (float)q.w * fx_inv);
+      }
+      if (a.req == SD_REQ_ADD) {
+        const float4 o = d4[i];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      d4[i] = v;
+    }
+  } else {
+    for (int i = tid; i < band_elems; i += THREADS) {
+      const float v = use_fx ? (float)plane_i[i] * fx_inv : plane[i];
+      dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + v : v;
+    }
+  }
+}
+
 // levels: dx[l] / H / W / scale from a.L; returns SD_ERR_UNSUPPORTED when a level does not fit
 static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
+  // packed arg-max: the wide-load kernel (roi_align_bwd_packed4); its coordinate tables share the
+  // LDS with the band, so the band budget is a little smaller
+  const bool wide = a.amax8 && tuning("roi_align_bwd_packed", 1) == 1;
+  const int tch = tuning("roi_align_bwd_tch", a.PP == 49 ? 32 : 16);
+  const int ts_words = a.PP == 49 ? 3 * 14 : 3 * 28;
+  const size_t tab_bytes = wide ? (size_t)tch * ts_words * 4 : 0;
   const long budget = (long)tuning("roi_align_bwd_lds_kb", 36) * 1024;
   a.ablate = tuning("roi_align_bwd_ablate", 0);
   size_t lds_max = 0;
@@ -1130,7 +1478,8 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
     nb = (a.L.H[l] + rows - 1) / rows;
     a.band_rows[l] = rows;
     a.nbands[l] = nb;
-    const size_t lds = (size_t)((((long)rows * a.L.W[l] + 3) & ~3L) * 4) + (size_t)(a.R + 4) * 4;
+    const size_t lds =
+        (size_t)((((long)rows * a.L.W[l] + 3) & ~3L) * 4) + tab_bytes + (size_t)(a.R + 8 + 16) * 4;
     if (lds > 150 * 1024) return SD_ERR_UNSUPPORTED;
     if (lds > lds_max) lds_max = lds;
     work[l] = (long)a.B * nb * a.C;
@@ -1162,6 +1511,29 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
   if (total >= (1L << 31)) return SD_ERR_UNSUPPORTED;
   int threads = tuning("roi_align_bwd_threads", 0);
   if (threads != 256 && threads != 512) threads = 512;
+  if (wide) {
+#define SD_BWDW(PHv, T, TCHv)                                                                    \
+  do {                                                                                           \
+    auto k = roi_align_bwd_packed4<PHv, PHv, T, TCHv>;                                           \
+    if (lds_max > 64 * 1024)                                                                     \
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds_max));                                           \
+    hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(T), lds_max, st, a);                       \
+  } while (0)
+#define SD_BWDW_T(PHv, TCHv)                                         \
+  do {                                                               \
+    if (threads == 256) SD_BWDW(PHv, 256, TCHv); else SD_BWDW(PHv, 512, TCHv); \
+  } while (0)
+    if (a.PP == 49) {
+      if (tch == 64) SD_BWDW_T(7, 64); else if (tch == 16) SD_BWDW_T(7, 16); else SD_BWDW_T(7, 32);
+    } else {
+      if (tch == 32) SD_BWDW_T(14, 32); else if (tch == 8) SD_BWDW_T(14, 8); else SD_BWDW_T(14, 16);
+    }
+#undef SD_BWDW_T
+#undef SD_BWDW
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+  }
 #define SD_BWDF2(PPv, T, PKv)                                                                    \
   do {                                                                                           \
     auto k = roi_align_bwd_fused<PPv, T, PKv>;                                                   \
@@ -1538,6 +1910,10 @@ extern "C" int sd_fpn_roi_align_fwd(const float* const* feats_host, const int* H
   return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+extern "C" int sd_fpn_roi_align_argmax_stride(int pooled_h, int pooled_w) {
+  return amax_stride(pooled_h * pooled_w);
+}
+
 extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_host,
                                            const int* Ws_host, const int* strides_host, int nlvl,
                                            const float* rois, float* out, uint8_t* argmax,
@@ -1548,6 +1924,8 @@ extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const
   if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
   SD_REQUIRE(feats_host && Hs_host && Ws_host && strides_host, "null level description");
   SD_REQUIRE((argmax && coords) || (long)B * R * C == 0, "argmax / coords is null");
+  SD_REQUIRE(((uintptr_t)argmax & 3) == 0 && ((uintptr_t)coords & 7) == 0,
+             "argmax must be 4-byte and coords 8-byte aligned");
   FwdArgs a{};
   if (int e = fill_levels(a.L, feats_host, Hs_host, Ws_host, strides_host, nlvl,
                           roi_canonical_scale, roi_canonical_level))
@@ -1596,6 +1974,8 @@ extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* r
     return SD_OK;
   }
   SD_REQUIRE(out_grad && rois && argmax && coords, "null tensor pointer");
+  SD_REQUIRE(((uintptr_t)argmax & 3) == 0 && ((uintptr_t)coords & 7) == 0,
+             "argmax must be 4-byte and coords 8-byte aligned");
   const int e = launch_bwd_fused(f, nlvl, (hipStream_t)stream);
   if (e == SD_ERR_UNSUPPORTED) return fail(e, "packed arg-max backward: a level does not fit LDS");
   return e;

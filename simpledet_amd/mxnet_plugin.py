@@ -614,7 +614,9 @@ def _build_ops(mx):
                 raise ValueError("bbox should be a 3D tensor of shape [batch, rois, 4]")
             o = (b[0], b[1], feats[0][1], self.pooled_size[0], self.pooled_size[1])
             if self.packed:
-                return in_shape, [o, o, (b[0], b[1], 9 * (self.pooled_size[0] + self.pooled_size[1]))]
+                stride = int(lib().cdll.sd_fpn_roi_align_argmax_stride(*self.pooled_size))
+                return in_shape, [o, (b[0], b[1], feats[0][1], stride),
+                                  (b[0], b[1], 9 * (self.pooled_size[0] + self.pooled_size[1]))]
             return in_shape, [o, o, o]
 
         def infer_type(self, in_type):

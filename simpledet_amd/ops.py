@@ -156,10 +156,22 @@ def fpn_roi_align_forward(feats, rois, rcnn_stride, pooled_size, roi_canonical_s
     return out, mx, my
 
 
+def argmax_stride(ph, pw):
+    """bytes per (RoI, channel) row of the packed arg-max (sd_fpn_roi_align_argmax_stride)."""
+    return int(lib().cdll.sd_fpn_roi_align_argmax_stride(int(ph), int(pw)))
+
+
+def argmax_codes(argmax, pooled_size):
+    """(B,R,C,S) packed arg-max -> (B,R,C,ph,pw) codes (drops the row padding)."""
+    ph, pw = _pair(pooled_size)
+    return argmax[..., :ph * pw].reshape(tuple(argmax.shape[:3]) + (ph, pw))
+
+
 def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_canonical_scale=224,
                                  roi_canonical_level=4):
-    """The fused extractor with a one-byte arg-max: -> out (B,R,C,ph,pw) fp32, argmax (B,R,C,ph,pw)
-    uint8 (row sample * 3 + column sample, 255 = nothing pooled), coords (B,R,9*(ph+pw)) 4-byte
+    """The fused extractor with a one-byte arg-max: -> out (B,R,C,ph,pw) fp32, argmax (B,R,C,S)
+    uint8 (S = ph*pw rounded up to a multiple of 4; code = row sample * 3 + column sample, 255 =
+    nothing pooled; unpack with argmax_codes()), coords (B,R,9*(ph+pw)) 4-byte
     words: per RoI 3*(ph+pw) fp32 sample coordinates, then 3*(ph+pw) {neighbours, fraction} pairs.  (argmax, coords) are state between this op's forward and backward
     only; fpn_roi_align_backward_packed decodes them."""
     _chk(rois, "rois", ndim=3)
@@ -176,7 +188,7 @@ def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_cano
     R = rois.shape[1]
     shape = (B, R, C, ph, pw)
     out = torch.empty(shape, device=rois.device, dtype=torch.float32)
-    amax = torch.empty(shape, device=rois.device, dtype=torch.uint8)
+    amax = torch.empty((B, R, C, argmax_stride(ph, pw)), device=rois.device, dtype=torch.uint8)
     coords = torch.empty((B, R, 9 * (ph + pw)), device=rois.device, dtype=torch.float32)
     wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, R)
     ws = torch.empty(wsb, device=rois.device, dtype=torch.uint8)
@@ -193,9 +205,11 @@ def fpn_roi_align_backward_packed(out_grad, rois, argmax, feat_shapes, rcnn_stri
     _chk(out_grad, "out_grad", ndim=5)
     _chk(rois, "rois", ndim=3)
     argmax, coords = argmax
-    _chk(argmax, "argmax", dtype=torch.uint8, ndim=5)
+    _chk(argmax, "argmax", dtype=torch.uint8, ndim=4)
     _chk(coords, "coords", ndim=3)
     B, R, C, ph, pw = out_grad.shape
+    if tuple(argmax.shape) != (B, R, C, argmax_stride(ph, pw)):
+        raise ValueError("argmax must be (B,R,C,%d) uint8" % argmax_stride(ph, pw))
     rd = REQ[req_data] if isinstance(req_data, str) else int(req_data)
     if d_feats is None:
         if rd == REQ["add"]:

@@ -105,7 +105,7 @@ def test_fused_fpn_roi_align_prop(plugin):
     shapes = [(2, 256, 200, 334), (2, 256, 100, 167), (2, 256, 50, 84), (2, 256, 25, 42), (2, 512, 4)]
     # 7x7: output + the op's private state (one-byte arg-max, per-RoI coordinate / tap table)
     assert p.list_outputs() == ["output", "argmax", "coords"]
-    assert p.infer_shape(shapes)[1] == [(2, 512, 256, 7, 7), (2, 512, 256, 7, 7), (2, 512, 126)]
+    assert p.infer_shape(shapes)[1] == [(2, 512, 256, 7, 7), (2, 512, 256, 52), (2, 512, 126)]
     assert [np.dtype(t) for t in p.infer_type([np.float32] * 5)[1]] == [np.float32, np.uint8, np.float32]
     q = props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)", pooled_size="(5, 5)")
     assert q.list_outputs() == ["output", "maxidx_x", "maxidx_y"]
@@ -198,5 +198,5 @@ def test_fused_fpn_roi_align_adapter_on_gpu(plugin, oracle, pooled):
     gin = [w(torch.empty_like(t.t)) for t in tin]
     op.backward(["write"] * 5, [w(torch.from_numpy(dy).cuda())], tin, tout, gin, [])
     for g, wv in zip(gin[:-1], wd):
-        assert np.abs(g.t.cpu().numpy() - wv).max() <= 1e-4 * max(1.0, float(np.abs(wv).max()))
+        assert np.abs(g.t.cpu().numpy() - wv).max() <= 1e-4
     assert float(gin[-1].t.abs().max()) == 0

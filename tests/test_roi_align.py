@@ -125,9 +125,10 @@ def _t(a):
 
 
 def _assert_bwd_close(got, want, tol=1e-4):
-    scale = max(1.0, float(np.abs(want).max()))
+    """north_star bar: |err| <= 1e-4 ELEMENTWISE (absolute; dY ~ N(0,1), gradient sums reach
+    ~30), not relative to the largest gradient."""
     err = float(np.abs(got - want).max())
-    assert err <= tol * scale, "max abs err %g (scale %g)" % (err, scale)
+    assert err <= tol, "max abs err %g" % err
 
 
 @pytest.mark.gpu
@@ -356,7 +357,7 @@ def test_fpn_packed_argmax_forward_backward(ops, oracle, variant):
     finally:
         lib().set_tuning("roi_align_fwd", 1)
     np.testing.assert_array_equal(out.cpu().numpy(), want[0])
-    amn, con = am[0].cpu().numpy(), am[1].cpu().numpy()
+    amn, con = ops.argmax_codes(am[0], (7, 7)).cpu().numpy(), am[1].cpu().numpy()
     np.testing.assert_array_equal(amn == 255, want[1] == -1)
     dax, day = _decode_packed(amn, rois, [f.shape for f in feats], STRIDES, level)
     np.testing.assert_array_equal(dax, want[1])  # decoded coordinates are the forward's floats
@@ -395,13 +396,13 @@ def test_fpn_packed_equals_float_argmax_path_full_size(ops):
     o1, mx, my = ops.fpn_roi_align_forward(feats, rois, STRIDES, (7, 7))
     o2, am = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, (7, 7))
     assert torch.equal(o1, o2)
-    assert torch.equal(am[0] == 255, mx == -1)
+    assert torch.equal(ops.argmax_codes(am[0], (7, 7)) == 255, mx == -1)
     dy = torch.randn_like(o1)
     shapes = [f.shape for f in feats]
     g1 = ops.fpn_roi_align_backward(dy, rois, mx, my, shapes, STRIDES)
     g2 = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
     for a, b in zip(g1, g2):
-        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-4
 
 
 @pytest.mark.gpu
@@ -415,4 +416,55 @@ def test_contrib_fpn_roi_align_autograd(ops):
     o2, mx, my = ops.fpn_roi_align_forward([f.detach() for f in feats], rois, STRIDES, (7, 7))
     g = ops.fpn_roi_align_backward(torch.ones_like(o2), rois, mx, my, [f.shape for f in feats], STRIDES)
     for f, w in zip(feats, g):
-        assert float((f.grad - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max()))
+        assert float((f.grad - w).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pooled,num", [((7, 7), 512), ((14, 14), 128)])
+def test_packed_backward_is_bit_reproducible_and_within_1e4_at_full_size(ops, oracle, pooled, num):
+    """BASELINE configs[1] / [4] shapes at reduced channels: the fixed-point band accumulation makes
+    the backward independent of the order of the LDS adds (two runs agree bit for bit) and stays
+    within 1e-4 of the oracle elementwise; kAddTo and non-finite gradients (float fallback: inf
+    must reach the pixels it touches) behave like the reference scatter."""
+    import torch
+    feats = synth.feature_maps(9, batch=2, channels=8)
+    rois = synth.random_rois(9, 2, num)
+    want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, pooled, nthreads=8)
+    tf = [_t(f) for f in feats]
+    out, am = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, pooled)
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0])
+    dy = np.random.RandomState(10).standard_normal(want[0].shape).astype(np.float32)
+    shapes = [f.shape for f in feats]
+    wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], shapes, STRIDES)
+    g1 = ops.fpn_roi_align_backward_packed(_t(dy), _t(rois), am, shapes, STRIDES)
+    g2 = ops.fpn_roi_align_backward_packed(_t(dy), _t(rois), am, shapes, STRIDES)
+    for a, b, w in zip(g1, g2, wd):
+        assert torch.equal(a, b), "backward differs between two runs"
+        _assert_bwd_close(a.cpu().numpy(), w)
+    # a tiny and a huge gradient scale: the per-workgroup scale follows max|dY|
+    for mul in (1e-6, 1e6):
+        gs = ops.fpn_roi_align_backward_packed(_t(dy * np.float32(mul)), _t(rois), am, shapes, STRIDES)
+        for a, w in zip(gs, wd):
+            assert np.abs(a.cpu().numpy() / np.float32(mul) - w).max() <= 1e-4
+    # heavy tails: gradients 100x larger on every other RoI defeat the optimistic scale taken from
+    # the first RoIs of a band; the band is then accumulated again with the exact maximum
+    dyo = dy.copy()
+    dyo[:, 1::2] *= np.float32(100.0)
+    wo = oracle.fpn_roi_align_bwd(dyo, rois, want[1], want[2], shapes, STRIDES)
+    go1 = ops.fpn_roi_align_backward_packed(_t(dyo), _t(rois), am, shapes, STRIDES)
+    go2 = ops.fpn_roi_align_backward_packed(_t(dyo), _t(rois), am, shapes, STRIDES)
+    for a, b, w in zip(go1, go2, wo):
+        assert torch.equal(a, b)
+        assert np.abs(a.cpu().numpy() - w).max() <= 1e-4 * 100
+    # inf / nan propagate to exactly the pixels the oracle sends them to
+    dyn = dy.copy()
+    valid = np.argwhere(want[1] != -1)
+    b, r, c, p, q = valid[len(valid) // 2]
+    dyn[b, r, c, p, q] = np.inf
+    wn = oracle.fpn_roi_align_bwd(dyn, rois, want[1], want[2], shapes, STRIDES)
+    gn = ops.fpn_roi_align_backward_packed(_t(dyn), _t(rois), am, shapes, STRIDES)
+    for a, w in zip(gn, wn):
+        a = a.cpu().numpy()
+        np.testing.assert_array_equal(np.isfinite(a), np.isfinite(w))
+        m = np.isfinite(w)
+        assert np.abs(a[m] - w[m]).max() <= 1e-4
