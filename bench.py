@@ -6,26 +6,35 @@ One "step" = one pass of the hot path over one per-GPU batch of synthetic input:
   x 4 samples (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a torchrun environment re-launches itself as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+(one rank per GPU, RCCL); started by torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
 
 Prints ONE JSON line on rank 0.  `value` = images/s over all ranks (weak scaling: every rank
 processes its own images; the path has no data-path collective -- RoIs/images are independent,
-SURVEY 8(e)).  `--grad-allreduce MB` additionally overlaps an RCCL all-reduce of an MB-sized fp32
-gradient buffer with every step (the reference's only inter-GPU exchange, detection_train.py:42-43).
+SURVEY 8(e)).  For N > 1 every step also all-reduces an fp32 gradient buffer over RCCL (default
+165 MB = the R50-FPN gradients of the reference's only inter-GPU exchange, detection_train.py:
+42-43,266), started when the step's kernels have been enqueued and joined at the end of the step,
+i.e. overlapped with the RoIAlign work the way a data-parallel backward overlaps it.
 
 roofline: ALGORITHMIC bytes of one forward launch (N*S_F + 16*N*R + 3*N*S_O
 = 335.9 MB at N=2) / the forward kernel's average duration measured with HIP events on the launch
 stream inside the timed region; peak = 8 TB/s HBM3E.  The backward (one fused launch for all levels,
 same algorithmic bytes) is reported next to it.
-cpu_baseline: the CPU oracle (oracle/, a port of operator_cxx's arithmetic) timed on the host
-cores on the same workload, rank 0, N=1 only.  It is a reported baseline, not the product.
+cpu_baseline: the CPU oracle (oracle/, a restatement of operator_cxx's arithmetic that is pinned
+bit for bit to the reference's own compiled operators, tests/test_ref_pins.py) timed on the host
+cores on the same workload: all cores and one core.  Reported baseline, not the product.
+Verification (not timed): the forward output AND the gradients of the last timed step are compared
+with the oracle (forward bit-exact, backward |err| <= 1e-4 elementwise).
 Clock state: before the W warm-up steps the same step runs untimed for ~0.1 s (--preheat-ms) so
-that short K/W settings measure the steady state a training loop sees instead of the clock ramp
-(measured: 20/5 steps 8,076 -> 8,526 images/s, 50/10 steps 8,374 -> 8,572).
+that short K/W settings measure the steady state a training loop sees instead of the clock ramp.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0
+R50_FPN_GRAD_MB = 165.0  # fp32 gradients of faster_r50v1_fpn (reference: KVStore 'nccl' all-reduce)
 
 
 def parse():
@@ -46,11 +56,12 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--preheat-ms", type=float, default=100.0,
                     help="untimed clock pre-heat before the --warmup steps (0 disables)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU oracle (baseline timing AND the verification of the timed step)")
     ap.add_argument("--cpu-passes", type=int, default=3)
-    ap.add_argument("--grad-allreduce", type=float, default=0.0,
-                    help="MB of fp32 gradients all-reduced (RCCL) per step, overlapped; 0 = off")
-    ap.add_argument("--tuning", action="append", default=[], help="key=value kernel knob (A/B)")
+    ap.add_argument("--grad-allreduce", type=float, default=-1.0,
+                    help="MB of fp32 gradients all-reduced (RCCL) per step; -1 = 165 when N > 1, 0 = off")
+    ap.add_argument("--tuning", action="append", default=[], help="key=value kernel-variant knob (A/B)")
     ap.add_argument("--float-argmax", action="store_true",
                     help="keep the arg-max between forward and backward as two fp32 planes (the "
                          "reference op's outputs) instead of one byte per output")
@@ -58,7 +69,7 @@ def parse():
                     help="also run the known-size HBM stream copies (measured peak + PMC calibration)")
     ap.add_argument("--no-ops", action="store_true",
                     help="skip the per-operator secondary measurements (bench_ops.py)")
-    ap.add_argument("--extra", action="store_true", help="also time the un-fused 4-op graph path")
+    ap.add_argument("--no-extra", action="store_true", help="skip the un-fused 4-op graph path")
     return ap.parse_args()
 
 
@@ -68,8 +79,23 @@ def algorithmic_bytes(n_img, n_roi, channels, shapes, pooled=49):
     return n_img * s_f + n_img * n_roi * 16 + 3 * n_img * s_o
 
 
+def self_launch(n):
+    """python bench.py --gpus N, no torchrun environment: become the launcher."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -78,13 +104,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")  # "gloo": launcher-path test on CPU boxes
+    use_cuda = backend == "nccl"
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", local_rank)} if use_cuda else {}
+        dist.init_process_group(backend, **kw)
+    if not use_cuda:
+        return launcher_selftest(args, rank, world)
 
+    from simpledet_amd import dist as sdd
     from simpledet_amd import ops, synth
     from simpledet_amd._lib import lib
 
@@ -102,19 +134,20 @@ def main():
     out_shape = (args.images, args.rois, args.channels, 7, 7)
     dy = torch.randn(out_shape, device="cuda")
     d_feats = [torch.empty_like(f) for f in feats]
-    grad_buf = None
-    comm_stream = None
-    if args.grad_allreduce > 0 and world > 1:
-        grad_buf = torch.randn(int(args.grad_allreduce * 1e6 / 4), device="cuda")
-        comm_stream = torch.cuda.Stream()
+    grad_mb = args.grad_allreduce if args.grad_allreduce >= 0 else (R50_FPN_GRAD_MB if world > 1 else 0.0)
+    reducer = None
+    rccl_ranks = 1
+    if world > 1:
+        # a real collective before anything is timed: every rank contributes 1
+        one = torch.ones(1, device="cuda")
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        if grad_mb > 0:
+            reducer = sdd.OverlappedAllReduce(grad_mb * 1e6, device="cuda")
 
     state = {}
 
     def step(ev=None):
-        if grad_buf is not None:
-            comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm_stream):
-                dist.all_reduce(grad_buf)
         if ev:
             ev[0].record()
         if args.float_argmax:
@@ -123,15 +156,20 @@ def main():
             out, am = ops.fpn_roi_align_forward_packed(feats, rois, strides, (7, 7))
         if ev:
             ev[1].record()
+        if reducer is not None:
+            # the gradients of the layers behind the RoI head exist by now: their all-reduce runs
+            # under the RoIAlign backward, as in a data-parallel training step
+            reducer.start()
         if args.float_argmax:
             ops.fpn_roi_align_backward(dy, rois, ax, ay, None, strides, d_feats=d_feats)
         else:
             ops.fpn_roi_align_backward_packed(dy, rois, am, None, strides, d_feats=d_feats)
         if ev:
             ev[2].record()
-        if grad_buf is not None:
-            torch.cuda.current_stream().wait_stream(comm_stream)
+        if reducer is not None:
+            reducer.finish()  # the optimizer needs the reduced gradients: the step ends here
         state["out"] = out
+        state["arg"] = (ax, ay) if args.float_argmax else am
 
     def barrier():
         if world > 1:
@@ -153,11 +191,15 @@ def main():
     for i in range(args.steps):
         step(events[i])
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank_ms = [elapsed_local * 1e3 / args.steps]
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_local], device="cuda", dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [float(x.item()) * 1e3 / args.steps for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
@@ -166,9 +208,9 @@ def main():
     value = total_images / elapsed
 
     extra = {}
-    if args.extra and rank == 0:
-        # the reference's graph structure through the drop-in per-level ops:
-        # assign -> 4 x ROIAlign_v2 (3 full-size outputs each) -> add_n
+    if not args.no_extra and rank == 0:
+        # what an UNCHANGED reference graph executes through the drop-in per-level operators
+        # (models/FPN/builder.py:588-605): assign -> 4 x ROIAlign_v2 (3 full-size outputs each) -> add_n
         def graph_step():
             per, _ = ops.fpn_roi_assign(rois, strides)
             total = None
@@ -186,6 +228,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         extra["unfused_4op_fwd_ms"] = e0.elapsed_time(e1) / 10
+        extra["fused_vs_unfused_fwd"] = extra["unfused_4op_fwd_ms"] / fwd_ms
 
     if args.calibrate and rank == 0:
         import ctypes
@@ -213,22 +256,27 @@ def main():
 
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     alg = algorithmic_bytes(args.images, args.rois, args.channels, shapes)
-    # HBM-side bytes per forward launch from the committed PMC profile of this same command
-    # (profiles/*_pmc_summary.json, tools/profile_round.sh): 2 x FETCH_SIZE (gfx950 correction,
-    # confirmed on the known-size hbm_stream_copy in the same profile) + WRITE_SIZE
-    traffic = None
+    # HBM-side bytes per forward launch: NOT measured in this run (PMC counters need rocprofv3); the
+    # newest committed PMC profile of this same command is quoted and named.  2 x FETCH_SIZE (gfx950
+    # correction, confirmed on the known-size hbm_stream_copy in the same profile) + WRITE_SIZE
+    traffic, traffic_source, bwd_traffic = None, None, None
     import glob
     for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))[::-1]:
         try:
             ks = json.load(open(pmc_path))["kernels"]
             for name, d in ks.items():
-                if "roi_align_fwd_tiled" in name and "fetch_bytes_x2_gfx950" in d:
+                if "roi_align_fwd" in name and "fetch_bytes_x2_gfx950" in d and traffic is None:
                     traffic = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
+                if "roi_align_bwd" in name and "fetch_bytes_x2_gfx950" in d and bwd_traffic is None:
+                    bwd_traffic = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
             if traffic is not None:
+                traffic_source = ("%s (rocprofv3 --pmc passes of this command at commit time; "
+                                  "not re-measured in this run)" % os.path.relpath(pmc_path, ROOT))
                 break
         except Exception:
             traffic = None
@@ -240,42 +288,60 @@ def main():
         "unit": "GB/s",
         "frac": alg / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
         "traffic": traffic,
+        "traffic_source": traffic_source,
         "algorithmic_bytes": alg,
         "avg_launch_ms": fwd_ms,
         "backward": {
-            "kernel": "sd::roi_align_bwd_fused<49,512> (all FPN levels, 1 launch/step)",
+            "kernel": "sd::roi_align_bwd_packed4<7,7,512,32> (all FPN levels, 1 launch/step)",
             "achieved": alg / (bwd_ms * 1e-3) / 1e9,
             "frac": alg / (bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "avg_ms": bwd_ms,
+            "traffic": bwd_traffic,
         },
         "fwd_bwd_frac": 2 * alg / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS,
     }
 
     cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         from oracle import pyoracle as orc
         cores = os.cpu_count() or 1
         dy_np = dy.cpu().numpy()
+        fshapes = [f.shape for f in feats_np]
         # warm (page in) once, then time a bounded sample: cpu_passes x the same full workload
         o = orc.fpn_roi_align_fwd(feats_np, rois_np, strides, (7, 7), nthreads=cores)
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_passes):
-            o = orc.fpn_roi_align_fwd(feats_np, rois_np, strides, (7, 7), nthreads=cores)
-            orc.fpn_roi_align_bwd(dy_np, rois_np, o[1], o[2], [f.shape for f in feats_np], strides,
-                                  nthreads=cores)
-        cpu_t = time.perf_counter() - t0
-        cpu_baseline = {
-            "value": args.images * args.cpu_passes / cpu_t,
-            "unit": "images/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": "%d passes of the same fwd+bwd workload (N=%d, %d RoIs/img) through "
-                      "oracle/liboracle.so, OpenMP over outputs (fwd) / planes (bwd)"
-                      % (args.cpu_passes, args.images, args.rois),
-            "ms_per_step": cpu_t * 1e3 / args.cpu_passes,
-        }
-        # the GPU result of the last step must still match the oracle (cheap sanity, not timed)
-        extra["matches_oracle"] = bool(np.array_equal(state["out"].cpu().numpy(), o[0]))
+        wd = None
+        if world == 1:
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_passes):
+                o = orc.fpn_roi_align_fwd(feats_np, rois_np, strides, (7, 7), nthreads=cores)
+                wd = orc.fpn_roi_align_bwd(dy_np, rois_np, o[1], o[2], fshapes, strides, nthreads=cores)
+            cpu_t = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            o1 = orc.fpn_roi_align_fwd(feats_np, rois_np, strides, (7, 7), nthreads=1)
+            orc.fpn_roi_align_bwd(dy_np, rois_np, o1[1], o1[2], fshapes, strides, nthreads=1)
+            cpu_t1 = time.perf_counter() - t0
+            cpu_baseline = {
+                "value": args.images * args.cpu_passes / cpu_t,
+                "unit": "images/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "%d passes of the same fwd+bwd workload (N=%d, %d RoIs/img) through "
+                          "oracle/liboracle.so on %d threads (OpenMP over outputs / planes, glue "
+                          "loops included); single_thread: 1 pass on 1 thread"
+                          % (args.cpu_passes, args.images, args.rois, cores),
+                "ms_per_step": cpu_t * 1e3 / args.cpu_passes,
+                "single_thread": {"value": args.images / cpu_t1, "unit": "images/s", "cores": 1,
+                                  "ms_per_step": cpu_t1 * 1e3},
+            }
+        else:
+            wd = orc.fpn_roi_align_bwd(dy_np, rois_np, o[1], o[2], fshapes, strides, nthreads=cores)
+        # the GPU results of the LAST TIMED step against the oracle (not timed): forward values bit
+        # for bit, gradients elementwise within 1e-4
+        fwd_ok = bool(np.array_equal(state["out"].cpu().numpy(), o[0]))
+        bwd_err = max(float(np.abs(g.cpu().numpy() - w).max()) for g, w in zip(d_feats, wd))
+        extra["matches_oracle"] = bool(fwd_ok and bwd_err <= 1e-4)
+        extra["verify"] = {"forward_bit_exact": fwd_ok, "backward_max_abs_err": bwd_err,
+                           "backward_tol": 1e-4, "what": "outputs of the last timed step vs oracle/"}
 
     if world == 1 and not args.no_ops:
         import bench_ops
@@ -307,16 +373,60 @@ def main():
             "images_per_gpu": args.images,
             "rois_per_image": args.rois,
             "argmax_state": "fp32 x,y planes" if args.float_argmax else "packed u8 (decoded in backward)",
-            "sharding": "images across ranks, no data-path collective"
-                        + (", +%.0f MB grad all-reduce/step" % args.grad_allreduce
-                           if grad_buf is not None else ""),
+            "sharding": "images across ranks, no data-path collective",
+            "grad_allreduce_mb_per_step": grad_mb if reducer is not None else 0.0,
         },
+        "rccl_ranks": rccl_ranks,
+        "per_rank_ms_per_step": per_rank_ms,
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }
     line.update(extra)
     print(json.dumps(line))
+    sys.stdout.flush()
     if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launcher_selftest(args, rank, world):
+    """SD_BENCH_BACKEND=gloo: exercise the launcher path (self-spawn, rendezvous, per-step overlapped
+    gradient all-reduce, max-over-ranks timing, one JSON line from rank 0) on a box without GPUs.
+    No kernel runs and the line says so; tests/test_dist.py drives this with --gpus 2."""
+    import torch
+    import torch.distributed as dist
+    from simpledet_amd import dist as sdd
+    grad_mb = args.grad_allreduce if args.grad_allreduce >= 0 else (R50_FPN_GRAD_MB if world > 1 else 0.0)
+    one = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(one)
+    reducer = sdd.OverlappedAllReduce(grad_mb * 1e6) if world > 1 and grad_mb > 0 else None
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if reducer is not None:
+            reducer.buf.fill_(float(rank + 1))
+            reducer.start()
+            reducer.finish()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    allt = [torch.zeros_like(el) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allt, el)
+    else:
+        allt = [el]
+    ok = reducer is None or bool(torch.allclose(reducer.buf, torch.full_like(reducer.buf, (world + 1) / 2.0)))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no GPU kernels)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "rccl_ranks": int(one.item()), "backend": "gloo",
+                          "grad_allreduce_mb_per_step": grad_mb if reducer is not None else 0.0,
+                          "allreduce_correct": ok,
+                          "per_rank_ms_per_step": [float(x.item()) * 1e3 / max(1, args.steps) for x in allt]}))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

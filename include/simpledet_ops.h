@@ -12,7 +12,8 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in _host
  *   - the caller owns every buffer (incl. workspaces: ask sd_*_workspace_bytes first); the library
- *     allocates nothing on the device and keeps no state between calls
+ *     allocates nothing on the device and keeps no state between calls (the only process-wide
+ *     state is the kernel-variant selection of sd_set_tuning, read lock-free at launch)
  *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it; no entry
  *     point synchronises the device
  *   - all tensors are dense row-major ("C contiguous"), fp32 unless stated
@@ -45,7 +46,9 @@ extern "C" {
 const char* sd_last_error(void);
 /* ABI version of this header (bumped on any signature change) */
 int sd_abi_version(void);
-/* kernel-variant knobs for A/B measurements (bench.py); unknown keys are an error */
+/* kernel-variant knobs for A/B measurements (bench.py, tests); every variant computes the same
+ * result.  Unknown keys are an error.  Knobs that disable parts of a kernel for profiling exist
+ * only in the separate -DSD_PROFILING build used by tools/, not in this library. */
 int sd_set_tuning(const char* key, int value);
 int sd_get_tuning(const char* key, int* value);
 

@@ -233,13 +233,22 @@ void orc_fpn_roi_align_fwd(const float* const* feats, const int* Hs, const int* 
   float* t_x = (float*)malloc(sizeof(float) * total);
   float* t_y = (float*)malloc(sizeof(float) * total);
   orc_fpn_roi_assign(rois, n_rois, strides, nlvl, canonical_scale, canonical_level, level, rl);
-  for (size_t i = 0; i < total; ++i) { amax_x[i] = -1.f; amax_y[i] = -1.f; }
+  /* the glue loops (fill, add_n, argmax merge) run on the same threads as the operator itself, so
+   * that the multi-thread cpu_baseline is not dominated by serial memory passes */
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+  for (long i = 0; i < (long)total; ++i) { amax_x[i] = -1.f; amax_y[i] = -1.f; }
   for (int l = 0; l < nlvl; ++l) {
     orc_roi_align_v2_fwd(feats[l], rl + (size_t)l * n_rois * 4, t_o, t_x, t_y, B, C, Hs[l], Ws[l],
                          R, ph, pw, 1.0f / (float)strides[l], nthreads);
     /* add_n = ElementWiseSum in input order */
-    if (l == 0) memcpy(out, t_o, sizeof(float) * total);
-    else for (size_t i = 0; i < total; ++i) out[i] = out[i] + t_o[i];
+    if (l == 0) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+      for (long i = 0; i < (long)total; ++i) out[i] = t_o[i];
+    } else {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+      for (long i = 0; i < (long)total; ++i) out[i] = out[i] + t_o[i];
+    }
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
     for (int r = 0; r < n_rois; ++r)
       if (level[r] == l) {
         memcpy(amax_x + r * per_roi, t_x + r * per_roi, sizeof(float) * per_roi);
@@ -262,6 +271,7 @@ void orc_fpn_roi_align_bwd(const float* dy, const float* rois, const float* amax
   orc_fpn_roi_assign(rois, n_rois, strides, nlvl, canonical_scale, canonical_level, level, NULL);
   for (int l = 0; l < nlvl; ++l) {
     /* the level-l op only holds argmax for its own RoIs; everything else is -1 */
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
     for (int r = 0; r < n_rois; ++r)
       for (size_t i = 0; i < per_roi; ++i) {
         t_x[r * per_roi + i] = level[r] == l ? amax_x[r * per_roi + i] : -1.f;

@@ -10,7 +10,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "simpledet_ops.h")
-LIB_PATH = os.path.join(_HERE, "libsimpledet_ops_hip.so")
+# SIMPLEDET_AMD_LIB: load another build of the same ABI (tools/ use the -DSD_PROFILING build)
+LIB_PATH = os.environ.get("SIMPLEDET_AMD_LIB") or os.path.join(_HERE, "libsimpledet_ops_hip.so")
 
 _SCALARS = {
     "int": ctypes.c_int,

@@ -33,8 +33,18 @@ int fail(int code, const char* fmt, ...);
 
 #define SD_LAUNCH_CHECK() SD_HIP_CHECK(hipGetLastError())
 
-// runtime tuning knobs (A/B of kernel variants from bench.py; defaults are the shipped path)
+// Kernel-VARIANT knobs (A/B of correct implementations from bench.py / the tests; defaults are the
+// shipped path).  Lock-free reads.  Knobs that switch parts of a kernel OFF for profiling (results
+// are wrong) exist only in the -DSD_PROFILING build (tools/libsimpledet_ops_hip_prof.so, `make prof`)
+// and are compiled out of the product library.
 int tuning(const char* key, int dflt);
+#ifdef SD_PROFILING
+#define SD_PROF_TUNING(key, dflt) ::sd::tuning(key, dflt)
+#define SD_ABLATE(args, bits) ((args).ablate & (bits))
+#else
+#define SD_PROF_TUNING(key, dflt) (dflt)
+#define SD_ABLATE(args, bits) 0  // the ablated branches are not in the product code at all
+#endif
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -819,7 +819,10 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
     constexpr int T = 256;
     const int vec = (((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0) |
                     (tuning("dcn_window", 1) ? 0 : 2);
-    const int nt = tuning("dcn_im2col_nt", 1);  // bit 0 non-temporal; bits 1-2 profiling only
+    int nt = tuning("dcn_im2col_nt", 1);  // bit 0 non-temporal; bits 1-2: profiling build only
+#ifndef SD_PROFILING
+    nt &= 1;
+#endif
     int nsplit = tuning("dcn_im2col_split", 1);
     if (nsplit < 1 || nsplit > C / dgroup) nsplit = 1;
     if (kh * kw == 9)

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     if (__any(valid) && valid) t.any_valid = 1;  // benign same-value race
   }
   __syncthreads();
-  if (a.ablate & 1) return;
+  if (SD_ABLATE(a, 1)) return;
   if (PK && slice == 0) {  // the sample coordinates the packed arg-max indexes, once per RoI
     for (int e = tid; e < NROI * 3 * (PH + PW); e += THREADS) {
       const int i = e / (3 * (PH + PW)), j = e % (3 * (PH + PW));
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   __syncthreads();
 
   // ---- RoIs of this image that can touch this band (and belong to this level) ----
-  for (int r = tid; r < ((a.ablate & 4) ? 0 : a.R); r += THREADS) {
+  for (int r = tid; r < (SD_ABLATE(a, 4) ? 0 : a.R); r += THREADS) {
     const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
     bool take = true;
     if (a.filter_lvl >= 0) take = fpn_level(rb.x, rb.y, rb.z, rb.w, a.L) == a.filter_lvl;
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   }
   __syncthreads();
   int nitems = *nlist * (CPB * PP);
-  if (a.ablate & 1) nitems = 0;
+  if (SD_ABLATE(a, 1)) nitems = 0;
 
   const long roi_stride = (long)a.C * PP;
   const long img_base = (long)img * a.R * roi_stride + (long)c0 * PP;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
 
   // ---- write the band out once.  With one band the CPB planes are contiguous in HBM; with
   // several bands CPB == 1 and rows [row0,row1) of one plane are contiguous ----
-  if (a.ablate & 2) return;
+  if (SD_ABLATE(a, 2)) return;
   const long off = (((long)img * a.C + c0) * H + row0) * W;
   float* dst = a.dx + off;
   auto get = [&](int i) -> float {
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
   if (tid == 0) *nlist = 0;
   __syncthreads();
   // ---- RoIs of this image that belong to this level and can touch this band ----
-  for (int r = tid; r < ((a.ablate & 4) ? 0 : a.R); r += THREADS) {
+  for (int r = tid; r < (SD_ABLATE(a, 4) ? 0 : a.R); r += THREADS) {
     const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
     bool take = true;
     if (a.filter) take = fpn_level(rb.x, rb.y, rb.z, rb.w, a.L) == lvl;
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
   }
   __syncthreads();
   int nitems = *nlist * PP;
-  if (a.ablate & 1) nitems = 0;
+  if (SD_ABLATE(a, 1)) nitems = 0;
   // wave-uniform bases + 32-bit lane offsets (the launcher checks R*C*PP < 2^31)
   const int roi_stride = a.C * PP;
   const long img_base = (long)img * a.R * roi_stride + (long)c * PP;
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
       if (it < nitems) {
         const int r = list[it / PP];
         int bin = it % PP;
-        if (PP == 196 && !(a.ablate & 64)) {
+        if (PP == 196 && !(SD_ABLATE(a, 64))) {
           // 14x14: most bins are narrower than a pixel, so 64 consecutive bins pile their taps onto
           // a few pixels (5.5 CAS rounds per instruction, simulated); every third bin spreads a
           // wave instruction over the whole RoI (3.8 rounds) at the price of 12-byte lane strides
@@ -1084,8 +1084,8 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
         const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
         const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
         const int o0 = (hlow - row0) * W, o1 = (hhigh - row0) * W;
-        if (a.ablate & 24) {  // profiling only: plain read-modify-write (8) / one store per item (16)
-          if (a.ablate & 8) {
+        if (SD_ABLATE(a, 24)) {  // profiling only: plain read-modify-write (8) / one store per item (16)
+          if (SD_ABLATE(a, 8)) {
             if (hlow >= row0 && hlow < row1) {
               plane[o0 + wleft] += w00;
               plane[o0 + wright] += w01;
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
     }
   }
   __syncthreads();
-  if (a.ablate & 2) return;
+  if (SD_ABLATE(a, 2)) return;
   const long off = (((long)img * a.C + c) * H + row0) * W;
   float* dst = a.dx[lvl] + off;
   if (((off | band_elems) & 3) == 0) {
@@ -1265,7 +1265,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   const int am_stride = a.C * PPS;
   const float* cob = a.coords + (long)img * a.R * CW;
 
-  bool use_fx = !(a.ablate & 64);  // (ablate 64, profiling build: the float compare-and-swap adds)
+  bool use_fx = !(SD_ABLATE(a, 64));  // (ablate 64, profiling build: the float compare-and-swap adds)
   float fx_scale = 1.f, fx_inv = 1.f;
   struct Item {
     float4 g;       // gradients of bins b0 .. b0+3
@@ -1285,7 +1285,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
       unsigned code = *reinterpret_cast<const unsigned*>(amb + r * am_stride + 4 * g);
       if (TAIL && g == GP - 1) {
         // bins PP-4 .. PP-1 are fetched, only the last PP % 4 of them belong to this lane
-        constexpr int KEEP = PP % 4;
+        constexpr int KEEP = TAIL ? PP % 4 : 1;
         const F4u v = *reinterpret_cast<const F4u*>(dyb + r * roi_stride + (PP - 4));
         float gg[4] = {v.x, v.y, v.z, v.w};
         it.g = make_float4(gg[4 - KEEP], KEEP > 1 ? gg[KEEP > 1 ? 5 - KEEP : 0] : 0.f,
@@ -1463,7 +1463,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
   const int ts_words = a.PP == 49 ? 3 * 14 : 3 * 28;
   const size_t tab_bytes = wide ? (size_t)tch * ts_words * 4 : 0;
   const long budget = (long)tuning("roi_align_bwd_lds_kb", 36) * 1024;
-  a.ablate = tuning("roi_align_bwd_ablate", 0);
+  a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
   size_t lds_max = 0;
   long work[SD_MAX_FPN_LEVELS];
   int nl = 0;
@@ -1676,7 +1676,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
   const int variant = tuning("roi_align_fwd", 1);  // 0 naive, 1 tiled
-  a.ablate = tuning("roi_align_fwd_ablate", 0);
+  a.ablate = SD_PROF_TUNING("roi_align_fwd_ablate", 0);
   const int nroi = a.B * a.R;
   a.order = nullptr;
   const int nbuckets = (a.L.nlvl + 1) * a.B * kOrderCells * kOrderCells;
@@ -1798,7 +1798,7 @@ static int launch_bwd(BwdArgs& a, hipStream_t st) {
   const size_t dx_bytes = (size_t)a.B * a.C * a.H * a.W * 4;
   if (dx_bytes == 0) return SD_OK;
   const int variant = tuning("roi_align_bwd", 1);  // 0 global atomics, 1 LDS planes
-  a.ablate = tuning("roi_align_bwd_ablate", 0);
+  a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
   const size_t list_bytes = (size_t)(a.R + 8) * 4;
   if (variant >= 1 && (a.PP == 49 || a.PP == 196) && list_bytes < 20 * 1024 && count > 0) {
     return a.PP == 49 ? launch_bwd_plane<49>(a, st) : launch_bwd_plane<196>(a, st);

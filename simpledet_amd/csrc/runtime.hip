@@ -1,7 +1,7 @@
 // Error reporting, ABI version and tuning knobs of libsimpledet_ops_hip.so.
 #include "common.h"
 #include "../../include/simpledet_ops.h"
-#include <mutex>
+#include <atomic>
 #include <string.h>
 
 namespace sd {
@@ -22,13 +22,17 @@ int fail(int code, const char* fmt, ...) {
 namespace {
 struct Knob {
   const char* key;
-  int value;
-  bool set;
+  std::atomic<int> value;
+  std::atomic<bool> set;
+  Knob(const char* k, int v, bool s) : key(k), value(v), set(s) {}
 };
 // every knob a kernel launcher reads must be listed here (sd_set_tuning rejects unknown keys)
 Knob g_knobs[] = {
     {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default)
-    {"roi_align_fwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
+#ifdef SD_PROFILING
+    {"roi_align_fwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
+    {"roi_align_bwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
+#endif
     {"roi_align_fwd_order", 0, false},   // 1: locality order of the RoIs (-25% L2-miss reads, same time; default 0)
     {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)
     {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
@@ -36,7 +40,6 @@ Knob g_knobs[] = {
     {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 36
     {"roi_align_bwd_accum", 0, false},   // per-level plane path only: 1 int64 fixed point, 0 float CAS
     {"roi_align_bwd_order", 0, false},   // 0 longest workgroups first (default), 1 most workgroups first
-    {"roi_align_bwd_ablate", 0, false},  // profiling only (results are wrong when != 0)
     {"roi_align_bwd_threads", 0, false}, // 256 or 512 (default)
     {"roi_align_bwd_packed", 0, false},  // packed arg-max backward: 1 wide-load kernel (default), 0 per-item loads
     {"roi_align_bwd_tch", 0, false},     // RoIs per staged coordinate-table chunk (7x7: 16/32/64, 14x14: 8/16/32)
@@ -48,17 +51,16 @@ Knob g_knobs[] = {
     {"deform_gemm_j", 0, false},     // GEMM tile width 64*J (1..3), 0 = by wave quantisation (default)
     {"dcn_im2col", 0, false},        // 1 LDS-plane im2col (default), 0 per-lane global gathers
     {"dcn_im2col_split", 0, false},  // channel splits per (image, group, pixel tile), default 1
-    {"dcn_im2col_nt", 0, false},     // bit 0: non-temporal col stores (default 1); bits 1-2 profiling only
+    {"dcn_im2col_nt", 0, false},     // bit 0: non-temporal col stores (default 1); bits 1-2 exist in the profiling build only
     {"dcn_window", 0, false},        // 1 stage only the touched range of each plane (default)
     {"dcn_coord", 0, false},         // 1 LDS-plane offset gradient (default), 0 per-lane gathers
 };
-std::mutex g_mu;
 }  // namespace
 
 int tuning(const char* key, int dflt) {
-  std::lock_guard<std::mutex> lk(g_mu);
   for (auto& k : g_knobs)
-    if (!strcmp(k.key, key)) return k.set ? k.value : dflt;
+    if (!strcmp(k.key, key))
+      return k.set.load(std::memory_order_acquire) ? k.value.load(std::memory_order_relaxed) : dflt;
   return dflt;
 }
 
@@ -104,11 +106,10 @@ extern "C" int sd_abi_version(void) { return 1; }
 
 extern "C" int sd_set_tuning(const char* key, int value) {
   if (!key) return sd::fail(SD_ERR_INVALID_ARG, "null tuning key");
-  std::lock_guard<std::mutex> lk(sd::g_mu);
   for (auto& k : sd::g_knobs)
     if (!strcmp(k.key, key)) {
-      k.value = value;
-      k.set = true;
+      k.value.store(value, std::memory_order_relaxed);
+      k.set.store(true, std::memory_order_release);
       return SD_OK;
     }
   return sd::fail(SD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
@@ -116,10 +117,9 @@ extern "C" int sd_set_tuning(const char* key, int value) {
 
 extern "C" int sd_get_tuning(const char* key, int* value) {
   if (!key || !value) return sd::fail(SD_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::mutex> lk(sd::g_mu);
   for (auto& k : sd::g_knobs)
     if (!strcmp(k.key, key)) {
-      *value = k.set ? k.value : -1;
+      *value = k.set.load() ? k.value.load() : -1;
       return SD_OK;
     }
   return sd::fail(SD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);

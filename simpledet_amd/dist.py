@@ -7,7 +7,7 @@ gradient all-reduce, which the reference does with KVStore 'nccl' (detection_tra
 gradients pre-scaled by 1/num_device :266).  Here: torch.distributed, backend "nccl" (= RCCL over
 xGMI on MI355X) or "gloo" (CPU tests), gradients coalesced into a few large flat buckets (xGMI is
 point to point: ring all-reduce is per-link bound, so few large messages beat many small ones) and
-reduced on a side stream so the reduction overlaps the rest of the backward.
+reduced on a side stream, each bucket as soon as the backward has produced its last gradient.
 """
 import os
 
@@ -47,56 +47,156 @@ def shard_round_robin(n_items, rank, world):
 
 
 class GradBucketReducer:
-    """Flat-bucket gradient all-reduce (sum, then scale by 1/world as detection_train.py:266).
+    """Gradient all-reduce (sum, then 1/world as detection_train.py:266) in a few large flat buckets,
+    overlapped with the backward pass.
 
-    bucket_mb: target bucket size.  With 7 xGMI links x ~153 GB/s per GPU a ring all-reduce of the
-    ~165 MB of R50-FPN fp32 gradients is bandwidth bound only for buckets of tens of MB.
+    * every bucket is ONE persistent flat tensor; each parameter's .grad is a view into it, so
+      nothing is concatenated or copied per step and autograd accumulates straight into the bucket;
+    * a post-accumulate hook on every parameter counts the bucket down; when the last gradient of a
+      bucket has been written, its all-reduce is launched at once (async, on a side stream ordered
+      after the producing stream) while autograd keeps computing the earlier layers -- buckets are
+      filled in reverse parameter order, the order the backward produces them;
+    * finish() (call it after loss.backward()) joins the side stream and re-arms the counters.
+    reduce() is the manual form for gradients that were written without autograd (it launches every
+    bucket, then finish()).  A parameter that receives no gradient in a step takes part with zeros
+    (its slot of the bucket), like an unused parameter under DistributedDataParallel.
+
+    bucket_mb: target bucket size.  xGMI is point to point (7 links x ~153 GB/s per GPU): a ring
+    all-reduce of the ~165 MB of R50-FPN fp32 gradients is bandwidth bound only for messages of
+    tens of MB, so the default is few, large buckets.
     """
 
-    def __init__(self, params, bucket_mb=64.0, average=True):
+    def __init__(self, params, bucket_mb=64.0, average=True, hooks=True):
         self.params = [p for p in params]
         self.average = average
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.buckets = []
-        cur, cur_bytes = [], 0
         limit = int(bucket_mb * 1e6)
-        for p in self.params:
+        groups, cur, cur_bytes = [], [], 0
+        for p in reversed(self.params):  # the backward produces the last layers' gradients first
             nb = p.numel() * p.element_size()
-            if cur and (cur_bytes + nb > limit or cur[0].dtype != p.dtype):
-                self.buckets.append(cur)
+            if cur and (cur_bytes + nb > limit or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nb
         if cur:
-            self.buckets.append(cur)
-        self.stream = torch.cuda.Stream() if (self.params and self.params[0].is_cuda) else None
+            groups.append(cur)
+        self.buckets = []
+        self._bucket_of = {}
+        for g in groups:
+            flat = torch.zeros(sum(p.numel() for p in g), dtype=g[0].dtype, device=g[0].device)
+            off = 0
+            for p in g:
+                n = p.numel()
+                view = flat[off:off + n].view_as(p)
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view
+                off += n
+                self._bucket_of[id(p)] = len(self.buckets)
+            self.buckets.append({"flat": flat, "params": g, "pending": len(g), "handle": None})
+        cuda = bool(self.params) and self.params[0].is_cuda
+        self.stream = torch.cuda.Stream() if cuda else None
+        self._hooks = []
+        if hooks and self.world > 1:
+            for p in self.params:
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def reduce(self):
-        """All-reduce .grad of every parameter in place; returns after the reduction is ordered
-        after the current stream's work and before anything issued later on it."""
-        if self.world == 1:
-            return
-        handles = []
+    def zero_grad(self):
+        """Zero every bucket in place (keeps the .grad views)."""
+        for b in self.buckets:
+            b["flat"].zero_()
+
+    def _launch(self, b):
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
         with ctx:
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        b = self.buckets[self._bucket_of[id(p)]]
+        if p.grad is not None and p.grad.data_ptr() != b["flat"].data_ptr() + self._offset(b, p):
+            # autograd replaced the view (first accumulation into a None grad): fold it back
+            self._view(b, p).copy_(p.grad)
+            p.grad = self._view(b, p)
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _offset(self, b, p):
+        off = 0
+        for q in b["params"]:
+            if q is p:
+                return off * p.element_size()
+            off += q.numel()
+        raise KeyError("parameter not in bucket")
+
+    def _view(self, b, p):
+        off = self._offset(b, p) // p.element_size()
+        return b["flat"][off:off + p.numel()].view_as(p)
+
+    def finish(self):
+        """Wait for every launched bucket, scale by 1/world, order the result before later work on
+        the current stream, re-arm the per-bucket counters."""
+        if self.world == 1:
+            return
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        with ctx:
             for b in self.buckets:
-                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
-                flat = torch.cat([g.reshape(-1) for g in grads])
-                h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-                handles.append((h, flat, b))
-            for h, flat, b in handles:
-                h.wait()
+                if b["handle"] is None:   # a bucket some gradient never arrived for
+                    self._launch(b)
+            for b in self.buckets:
+                b["handle"].wait()
                 if self.average:
-                    flat.div_(self.world)
-                off = 0
-                for p in b:
-                    n = p.numel()
-                    if p.grad is None:
-                        p.grad = torch.empty_like(p)
-                    p.grad.copy_(flat[off:off + n].view_as(p))
-                    off += n
+                    b["flat"].div_(self.world)
+                b["handle"] = None
+                b["pending"] = len(b["params"])
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    def reduce(self):
+        """All-reduce gradients that were written into .grad without autograd."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if b["handle"] is None:
+                self._launch(b)
+        self.finish()
+
+
+class OverlappedAllReduce:
+    """One persistent flat buffer all-reduced per step on a side stream: start() after the step's
+    producer work has been enqueued, finish() before the consumer (the optimizer).  bench.py uses it
+    to put the reference's only inter-GPU exchange (165 MB of fp32 gradients for R50-FPN) next to
+    the RoIAlign step."""
+
+    def __init__(self, nbytes, device=None, average=True):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.buf = torch.ones(max(1, int(nbytes) // 4), dtype=torch.float32, device=device)
+        self.stream = torch.cuda.Stream() if self.buf.is_cuda else None
+        self.average = average
+        self.handle = None
+
+    def start(self):
+        if self.world == 1:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        with ctx:
+            self.handle = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        if self.world == 1 or self.handle is None:
+            return
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        with ctx:
+            self.handle.wait()
+            if self.average:
+                self.buf.div_(self.world)
+        self.handle = None
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 

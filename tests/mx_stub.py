@@ -84,7 +84,9 @@ def make_stub():
         array=lambda v, ctx=None, dtype="float32": _NDArray(
             torch.tensor(v, device=dev, dtype=getattr(torch, dtype))))
     sym = types.SimpleNamespace(Symbol=Symbol, Custom=Custom, Variable=Variable,
-                                Group=lambda syms: list(syms), contrib=types.SimpleNamespace())
+                                Group=lambda syms: list(syms), contrib=types.SimpleNamespace(),
+                                reshape=lambda data, shape, name=None: ("reshape", data, tuple(shape)),
+                                Cast=lambda data, dtype, name=None: ("cast", data, dtype))
     mx = types.SimpleNamespace(operator=types.SimpleNamespace(CustomOp=CustomOp,
                                                               CustomOpProp=CustomOpProp,
                                                               register=register),

@@ -38,9 +38,35 @@ def _worker(rank, world, port, q):
     for i, p in enumerate(params):
         p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
     red = sdd.GradBucketReducer(params, bucket_mb=0.004)  # forces several buckets
+    ptrs = [p.grad.data_ptr() for p in params]
     red.reduce()
     ok = all(torch.allclose(p.grad, torch.full_like(p, (i + 1) * (world + 1) / 2.0))
              for i, p in enumerate(params))
+    ok = ok and ptrs == [p.grad.data_ptr() for p in params]  # persistent views, nothing re-allocated
+    # 2b. autograd path: hooks launch a bucket as soon as its last gradient exists
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    red2 = sdd.GradBucketReducer(net.parameters(), bucket_mb=0.0002)
+    for step in range(2):
+        red2.zero_grad()
+        x = torch.full((3, 8), float(rank + 1 + step))
+        net(x).sum().backward()
+        red2.finish()
+        # reference: the mean over ranks of the single-process gradients
+        ref = [torch.zeros_like(p) for p in net.parameters()]
+        for rr in range(world):
+            net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+            net2.load_state_dict(net.state_dict())
+            net2(torch.full((3, 8), float(rr + 1 + step))).sum().backward()
+            for a, p2 in zip(ref, net2.parameters()):
+                a += p2.grad / world
+        ok = ok and all(torch.allclose(p.grad, a, atol=1e-5) for p, a in zip(net.parameters(), ref))
+    ok = ok and len(red2.buckets) >= 2
+    ar = sdd.OverlappedAllReduce(4 * 100)
+    ar.buf.fill_(float(rank + 1))
+    ar.start()
+    ar.finish()
+    ok = ok and bool(torch.allclose(ar.buf, torch.full_like(ar.buf, (world + 1) / 2.0)))
     # 3. (image, class) soft-NMS problems round robin; results gathered ragged
     probs = sdd.shard_round_robin(7, rank, world)
     res = sdd.gather_ragged([(p, p * p) for p in probs])
@@ -78,3 +104,23 @@ def test_shard_helpers_cover_everything_once():
             assert got == list(range(n))
             rr = sorted(sum([sdd.shard_round_robin(n, r, w) for r in range(w)], []))
             assert rr == list(range(n))
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no torchrun environment re-launches itself through
+    torch.distributed.run (127.0.0.1 rendezvous), all-reduces the gradient buffer every step and
+    prints ONE JSON line from rank 0.  SD_BENCH_BACKEND=gloo runs that launcher path without GPUs."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SD_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1", "--grad-allreduce", "2"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["allreduce_correct"] is True
+    assert d["grad_allreduce_mb_per_step"] == 2 and len(d["per_rank_ms_per_step"]) == 2

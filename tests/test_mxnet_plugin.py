@@ -121,6 +121,53 @@ def test_symbol_alias_builds_custom_node_with_visible_outputs(plugin):
     assert s[1].params == {"pooled_size": "(7, 7)", "spatial_scale": "0.25"}
 
 
+def test_install_routes_fpn_extractor_to_the_fused_op_without_editing_the_reference(plugin):
+    """models/FPN/builder.py:567-610 builds assign + 4 x roi_align + add_n; install() rebinds
+    FPNRoiAlign.get_roi_feature so the same call emits one sd_fpn_roi_align node."""
+    import sys
+    import types
+    mx, _, plug = plugin
+
+    class FPNRoiAlign:  # stand-in with the reference class's name, attribute and method
+        def __init__(self, p):
+            self.p = p
+
+        def get_roi_feature(self, conv_fpn_feat, proposal):
+            return "reference subgraph"
+
+    fake = types.ModuleType("models.FPN.builder")
+    fake.FPNRoiAlign = FPNRoiAlign
+    pkgs = {"models": types.ModuleType("models"), "models.FPN": types.ModuleType("models.FPN"),
+            "models.FPN.builder": fake}
+    old = {k: sys.modules.get(k) for k in pkgs}
+    sys.modules.update(pkgs)
+    try:
+        assert plug.patch_fpn_roi_align(mx=mx) is True
+        p = types.SimpleNamespace(stride=(4, 8, 16, 32), roi_canonical_scale=224, roi_canonical_level=4,
+                                  out_size=7, fp16=False)
+        feats = {"stride%d" % s: mx.sym.Variable("P%d" % s) for s in p.stride}
+        rois = mx.sym.Variable("proposal")
+        node = FPNRoiAlign(p).get_roi_feature(feats, rois)
+        assert node[0] == "reshape" and node[2] == (-3, -2)
+        _, custom, idx = node[1]
+        assert idx == 0 and custom.op_type == "sd_fpn_roi_align"
+        assert custom.inputs == [feats["stride4"], feats["stride8"], feats["stride16"], feats["stride32"], rois]
+        assert custom.params == {"rcnn_stride": "(4, 8, 16, 32)", "pooled_size": "(7, 7)",
+                                 "roi_canonical_scale": "224", "roi_canonical_level": "4"}
+        assert FPNRoiAlign(p)._sd_reference_get_roi_feature(feats, rois) == "reference subgraph"
+        # fp16 graphs: fp32 around the op, as the reference does (builder.py:581-586, 607-608)
+        p.fp16 = True
+        node = FPNRoiAlign(p).get_roi_feature(feats, rois)
+        assert node[0] == "cast" and node[2] == "float16" and node[1][0] == "reshape"
+        assert node[1][1][1].inputs[0] == ("cast", feats["stride4"], "float32")
+    finally:
+        for k, v in old.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 @pytest.mark.gpu
 def test_adapter_forward_backward_on_gpu(plugin, oracle):
     import torch
