@@ -191,6 +191,20 @@ int sd_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
                        float* roi_output, float* label, float* bbox_target, float* bbox_weight,
                        float* match_gt_iou, int32_t* kept_index, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* ProposalTarget_v2 (mx.sym.ProposalTarget_v2, call site models/tridentnet/builder.py:281-299)
+ *   replaces ProposalTargetOp_v2::Forward  operator_cxx/proposal_target_v2-inl.h:128-296 and
+ *   proposal_target_v2::SampleROI  operator_cxx/proposal_target_v2.cc:21-177
+ *   = ProposalTarget plus valid_ranges (B,2) DEVICE [min, max] object scale per image: with
+ *   filter_scales a gt box is appended to the candidate rois only if min^2 <= w*h <= max^2; an
+ *   image without candidates / without valid gt gets one all-zero roi / gt row.  image_rois = -1
+ *   is rejected (the reference allocates (B,-1,.) tensors for it).  The `ohem` parameter of the
+ *   reference is LOG(FATAL) "not implemented" there and has no counterpart here. */
+int sd_proposal_target_v2(const float* rois, const float* gt_boxes, const float* valid_ranges,
+                          int filter_scales, int N, int M,
+                          const sd_proposal_target_param* param_host, int32_t* rng_state,
+                          float* roi_output, float* label, float* bbox_target, float* bbox_weight,
+                          float* match_gt_iou, int32_t* kept_index, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * _contrib_NMS  (mx.sym.contrib.NMS; the same kernel is embedded in Proposal_v3)

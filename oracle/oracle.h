@@ -82,6 +82,11 @@ int orc_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
                         float* roi_out, float* label, float* bbox_target, float* bbox_weight,
                         float* match_gt_iou, int* kept_index /* B*S, may be NULL; -1 = unfilled */);
 /* same, but driving libc rand() itself (what the reference binary calls) */
+/* ProposalTarget_v2 (proposal_target_v2-inl.h / .cc): valid_ranges (B,2), filter_scales */
+int orc_proposal_target_v2(const float* rois, const float* gt_boxes, const float* valid_ranges,
+                           int filter_scales, int N, int M, const orc_proposal_target_param* p,
+                           orc_glibc_rand* rng, float* roi_out, float* label, float* bbox_target,
+                           float* bbox_weight, float* match_gt_iou, int* kept_index);
 int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, int M,
                              const orc_proposal_target_param* p, float* roi_out, float* label,
                              float* bbox_target, float* bbox_weight, float* match_gt_iou,

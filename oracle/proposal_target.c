@@ -186,7 +186,17 @@ static int sample_roi(const float* all_rois, unsigned n_rois, const float* gt_bo
   return ub;
 }
 
-static int proposal_target_impl(const float* rois, const float* gt_boxes, int N, int M,
+/* valid_ranges != NULL selects ProposalTarget_v2 (operator_cxx/proposal_target_v2-inl.h:128-266):
+ *   - with filter_scales a gt box is appended to the candidate rois only if its area w*h lies in
+ *     [valid_min^2, valid_max^2] (:188-203); the IoU / label side still sees every valid gt box
+ *   - an image without candidate rois gets one all-zero roi, an image without valid gt one
+ *     all-zero gt row (:244-249).  (The reference builds that row 4 wide and then reads column 4
+ *     as the class: undefined; defined here as class 0.)
+ *   image_rois == -1 ("keep every roi") makes the reference allocate (B, -1, .) host tensors
+ *   (:209-213) and is rejected.  SampleROI itself (proposal_target_v2.cc:21-177) equals v1's for
+ *   image_rois != -1. */
+static int proposal_target_impl(const float* rois, const float* gt_boxes, const float* valid_ranges,
+                                int filter_scales, int N, int M,
                                 const orc_proposal_target_param* p, rand_fn rf, void* rs,
                                 float* roi_out, float* label, float* bbox_target,
                                 float* bbox_weight, float* match_gt_iou, int* kept_index) {
@@ -213,8 +223,25 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, int N,
       const float* r = rois + ((size_t)i * N + j) * 4;
       if (r[3] > 0) memcpy(kept_rois + 4 * n_rois++, r, 4 * sizeof(float));
     }
-    if (!p->proposal_without_gt) /* :177-185 */
-      for (unsigned j = 0; j < n_gt; ++j) memcpy(kept_rois + 4 * n_rois++, kept_gt + 5 * j, 4 * sizeof(float));
+    if (!p->proposal_without_gt) { /* :177-185 */
+      float vmin = 0.f, vmax = 0.f;
+      if (valid_ranges) {
+        vmin = valid_ranges[2 * i] * valid_ranges[2 * i];
+        vmax = valid_ranges[2 * i + 1] * valid_ranges[2 * i + 1];
+      }
+      for (unsigned j = 0; j < n_gt; ++j) {
+        const float* g = kept_gt + 5 * j;
+        if (valid_ranges && filter_scales) { /* DType w = x2 - x1 + 1.0 (double add, narrowed) */
+          float w = (float)((double)(g[2] - g[0]) + 1.0), h = (float)((double)(g[3] - g[1]) + 1.0);
+          if (w * h < vmin || w * h > vmax) continue;
+        }
+        memcpy(kept_rois + 4 * n_rois++, g, 4 * sizeof(float));
+      }
+    }
+    if (valid_ranges) { /* v2 :244-249 */
+      if (n_rois == 0) { memset(kept_rois, 0, 4 * sizeof(float)); n_rois = 1; }
+      if (n_gt == 0) { memset(kept_gt, 0, 5 * sizeof(float)); n_gt = 1; }
+    }
     int e = sample_roi(kept_rois, n_rois, kept_gt, n_gt, p, fg_rois_per_image, (unsigned)S, rf, rs,
                        roi_out + (size_t)i * S * 4, label + (size_t)i * S,
                        bbox_target + (size_t)i * S * K4, bbox_weight + (size_t)i * S * K4,
@@ -229,14 +256,23 @@ int orc_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
                         const orc_proposal_target_param* p, orc_glibc_rand* rng, float* roi_out,
                         float* label, float* bbox_target, float* bbox_weight, float* match_gt_iou,
                         int* kept_index) {
-  return proposal_target_impl(rois, gt_boxes, N, M, p, rand_state, rng, roi_out, label,
+  return proposal_target_impl(rois, gt_boxes, NULL, 0, N, M, p, rand_state, rng, roi_out, label,
                               bbox_target, bbox_weight, match_gt_iou, kept_index);
+}
+
+int orc_proposal_target_v2(const float* rois, const float* gt_boxes, const float* valid_ranges,
+                           int filter_scales, int N, int M, const orc_proposal_target_param* p,
+                           orc_glibc_rand* rng, float* roi_out, float* label, float* bbox_target,
+                           float* bbox_weight, float* match_gt_iou, int* kept_index) {
+  if (p->image_rois < 0 || !valid_ranges) return -2;
+  return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, N, M, p, rand_state, rng,
+                              roi_out, label, bbox_target, bbox_weight, match_gt_iou, kept_index);
 }
 
 int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, int M,
                              const orc_proposal_target_param* p, float* roi_out, float* label,
                              float* bbox_target, float* bbox_weight, float* match_gt_iou,
                              int* kept_index) {
-  return proposal_target_impl(rois, gt_boxes, N, M, p, rand_libc, NULL, roi_out, label,
+  return proposal_target_impl(rois, gt_boxes, NULL, 0, N, M, p, rand_libc, NULL, roi_out, label,
                               bbox_target, bbox_weight, match_gt_iou, kept_index);
 }

@@ -218,8 +218,10 @@ def make_pt_param(num_classes, batch_images, image_rois, fg_fraction=0.25, fg_th
     return p
 
 
-def proposal_target(rois, gt_boxes, param, rng=None, use_libc=False):
-    """Returns (rois_out, label, bbox_target, bbox_weight, match_gt_iou, kept_index, rc)."""
+def proposal_target(rois, gt_boxes, param, rng=None, use_libc=False, valid_ranges=None,
+                    filter_scales=False):
+    """Returns (rois_out, label, bbox_target, bbox_weight, match_gt_iou, kept_index, rc).
+    valid_ranges (B,2) selects ProposalTarget_v2."""
     rois, pr = _f(rois)
     gt, pg = _f(gt_boxes)
     B, N, _ = rois.shape
@@ -231,7 +233,14 @@ def proposal_target(rois, gt_boxes, param, rng=None, use_libc=False):
     bw = np.empty((B, S, K4), np.float32)
     iou = np.empty((B, S), np.float32)
     kept = np.empty((B, S), np.int32)
-    if use_libc:
+    if valid_ranges is not None:
+        vr, pv = _f(valid_ranges)
+        if rng is None:
+            rng = GlibcRand(1)
+        rc = cdll().orc_proposal_target_v2(pr, pg, pv, int(filter_scales), N, M, ctypes.byref(param),
+                                           ctypes.byref(rng), ro.ctypes, lb.ctypes, bt.ctypes,
+                                           bw.ctypes, iou.ctypes, kept.ctypes)
+    elif use_libc:
         rc = cdll().orc_proposal_target_libc(pr, pg, N, M, ctypes.byref(param), ro.ctypes,
                                              lb.ctypes, bt.ctypes, bw.ctypes, iou.ctypes,
                                              kept.ctypes)

@@ -41,9 +41,11 @@ struct PtWs {
 struct PtArgs {
   const float* rois;
   const float* gt;
+  const float* valid_ranges;  // ProposalTarget_v2: (B,2) [min, max] object scale; null = v1
+  int filter_scales;          // v2: append only the gt boxes inside the valid range
   PtWs ws;
   sd_proposal_target_param p;
-  int B, N, M, Ncand, S, fg_per_image;
+  int B, N, M, Mws, Ncand, S, fg_per_image;  // Mws = max(M, 1): row stride of the gt workspace
   int* rng;
   float* roi_out;
   float* label;
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
   float* garea = smem + 4 * a.M;                   // M areas
   PtWs ws = a.ws;
   float4* cand = ws.cand + (long)img * a.Ncand;
-  float4* gtbox = ws.gtbox + (long)img * a.M;
-  float* gtcls = ws.gtcls + (long)img * a.M;
+  float4* gtbox = ws.gtbox + (long)img * a.Mws;
+  float* gtcls = ws.gtcls + (long)img * a.Mws;
 
   // ---- valid gt boxes (cls != -1), order preserved (proposal_target-inl.h:155-162) ----
   int n_gt = 0;
@@ -118,8 +120,46 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
   }
   __syncthreads();
   if (!a.p.proposal_without_gt) {
-    for (int j = tid; j < n_gt; j += THREADS) cand[n_cand + j] = gbox[j];
-    n_cand += n_gt;
+    if (a.valid_ranges && a.filter_scales) {
+      // ProposalTarget_v2 (proposal_target_v2-inl.h:188-203): a gt box joins the candidates only if
+      // its area lies in [valid_min^2, valid_max^2]; order preserved
+      const float v0 = a.valid_ranges[2 * img], v1 = a.valid_ranges[2 * img + 1];
+      const float vmin = v0 * v0, vmax = v1 * v1;
+      for (int base = 0; base < n_gt; base += THREADS) {
+        const int j = base + tid;
+        bool ok = false;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < n_gt) {
+          b = gbox[j];
+          const float w = (float)((double)(b.z - b.x) + 1.0), h = (float)((double)(b.w - b.y) + 1.0);
+          ok = !(w * h < vmin || w * h > vmax);
+        }
+        int tot;
+        const int off = block_scan_flag<THREADS>(ok, wave_sums, &tot);
+        if (ok) cand[n_cand + off] = b;
+        n_cand += tot;
+      }
+    } else {
+      for (int j = tid; j < n_gt; j += THREADS) cand[n_cand + j] = gbox[j];
+      n_cand += n_gt;
+    }
+  }
+  if (a.valid_ranges) {
+    // v2 (:244-249): no candidate -> one all-zero roi; no valid gt -> one all-zero gt row (its
+    // class column is read out of bounds by the reference; defined as 0 here)
+    if (n_cand == 0) {
+      if (tid == 0) cand[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      n_cand = 1;
+    }
+    if (n_gt == 0) {
+      if (tid == 0) {
+        gbox[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        garea[0] = 1.f;
+        gtbox[0] = gbox[0];
+        gtcls[0] = 0.f;
+      }
+      n_gt = 1;
+    }
   }
   __syncthreads();  // cand[] written by other threads is read below (same workgroup: L1/L2 coherent)
   __threadfence_block();
@@ -393,8 +433,8 @@ __global__ __launch_bounds__(128) void pt_encode_kernel(PtArgs a) {
     iou = ws.ov[(long)img * a.Ncand + kidx];
     if (n_gt > 0) {
       const int g = ws.gta[(long)img * a.Ncand + kidx];
-      if (slot < fg_this) lab = ws.gtcls[(long)img * a.M + g];   // proposal_target.cc:129-131
-      const float4 gt = ws.gtbox[(long)img * a.M + g];
+      if (slot < fg_this) lab = ws.gtcls[(long)img * a.Mws + g];   // proposal_target.cc:129-131
+      const float4 gt = ws.gtbox[(long)img * a.Mws + g];
       // NonLinearTransformAndNormalization :204-227 ("0.5 *" is a double expression)
       const float ex_width = roi.z - roi.x + 1.f;
       const float ex_height = roi.w - roi.y + 1.f;
@@ -438,6 +478,7 @@ __global__ __launch_bounds__(128) void pt_encode_kernel(PtArgs a) {
 static inline size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
 
 static size_t pt_layout(int B, int N, int M, int S, PtWs* ws, char* base) {
+  if (M < 1) M = 1;  // ProposalTarget_v2 substitutes one zero gt / roi for an empty list
   const size_t Ncand = (size_t)N + M;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -502,11 +543,12 @@ extern "C" size_t sd_proposal_target_workspace_bytes(int B, int N, int M) {
   return pt_layout(B, N, M, kPtMaxRois, nullptr, nullptr) + 256;
 }
 
-extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
-                                  const sd_proposal_target_param* param_host, int32_t* rng_state,
-                                  float* roi_output, float* label, float* bbox_target,
-                                  float* bbox_weight, float* match_gt_iou, int32_t* kept_index,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+static int proposal_target_impl(const float* rois, const float* gt_boxes, const float* valid_ranges,
+                                int filter_scales, int N, int M,
+                                const sd_proposal_target_param* param_host, int32_t* rng_state,
+                                float* roi_output, float* label, float* bbox_target,
+                                float* bbox_weight, float* match_gt_iou, int32_t* kept_index,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   SD_REQUIRE(param_host, "param is null");
   const sd_proposal_target_param& p = *param_host;
   const int B = p.batch_images, S = p.image_rois;
@@ -528,14 +570,15 @@ extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int 
     return fail(SD_ERR_WORKSPACE, "ProposalTarget workspace too small: %zu < %zu bytes",
                 workspace_bytes, need);
   a.rois = rois; a.gt = gt_boxes; a.p = p;
-  a.B = B; a.N = N; a.M = M; a.Ncand = N + M; a.S = S;
+  a.valid_ranges = valid_ranges; a.filter_scales = filter_scales;
+  a.B = B; a.N = N; a.M = M; a.Mws = M > 0 ? M : 1; a.Ncand = N + a.Mws; a.S = S;
   a.fg_per_image = (int)((float)S * p.fg_fraction);  // static_cast<index_t>(image_rois * fg_fraction)
   a.rng = rng_state;
   a.roi_out = roi_output; a.label = label; a.bbox_target = bbox_target;
   a.bbox_weight = bbox_weight; a.iou_out = match_gt_iou; a.kept_index = kept_index;
   hipStream_t st = (hipStream_t)stream;
 
-  const size_t lds1 = (size_t)(M > 0 ? M : 1) * 5 * sizeof(float);
+  const size_t lds1 = (size_t)(M > 0 ? M : 1) * 5 * sizeof(float) + 32;
   SD_REQUIRE(lds1 <= 64 * 1024, "too many gt boxes per image (M=%d)", M);
   hipLaunchKernelGGL((pt_assign_kernel<1024>), dim3(B), dim3(1024), lds1, st, a);
   SD_LAUNCH_CHECK();
@@ -549,4 +592,32 @@ extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int 
   hipLaunchKernelGGL(pt_encode_kernel, dim3(B * S), dim3(128), 0, st, a);
   SD_LAUNCH_CHECK();
   return SD_OK;
+}
+
+extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
+                                  const sd_proposal_target_param* param_host, int32_t* rng_state,
+                                  float* roi_output, float* label, float* bbox_target,
+                                  float* bbox_weight, float* match_gt_iou, int32_t* kept_index,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return proposal_target_impl(rois, gt_boxes, nullptr, 0, N, M, param_host, rng_state, roi_output,
+                              label, bbox_target, bbox_weight, match_gt_iou, kept_index, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int sd_proposal_target_v2(const float* rois, const float* gt_boxes,
+                                     const float* valid_ranges, int filter_scales, int N, int M,
+                                     const sd_proposal_target_param* param_host,
+                                     int32_t* rng_state, float* roi_output, float* label,
+                                     float* bbox_target, float* bbox_weight, float* match_gt_iou,
+                                     int32_t* kept_index, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  SD_REQUIRE(param_host, "param is null");
+  SD_REQUIRE(valid_ranges || param_host->batch_images == 0, "valid_ranges is null");
+  // image_rois == -1 ("keep every roi") makes the reference allocate (B, -1, .) host tensors
+  // (proposal_target_v2-inl.h:209-213): undefined there, rejected here
+  SD_REQUIRE(param_host->image_rois >= 0,
+             "ProposalTarget_v2: image_rois=-1 is undefined in the reference (negative tensor shape)");
+  return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, N, M, param_host,
+                              rng_state, roi_output, label, bbox_target, bbox_weight, match_gt_iou,
+                              kept_index, workspace, workspace_bytes, stream);
 }

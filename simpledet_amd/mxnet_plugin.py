@@ -238,8 +238,9 @@ def _build_ops(mx):
             _no_add(req)
             from .ops import ProposalTargetParam
             _require_write(req[:4], ["roi_output", "label", "bbox_target", "bbox_weight"])
-            rois, gt = in_data
-            _wait(rois, gt)
+            rois, gt = in_data[0], in_data[1]
+            vr = in_data[2] if len(in_data) > 2 else None  # ProposalTarget_v2: valid_ranges
+            _wait(*in_data)
             p = self.p
             B = p["batch_images"]
             N = int(_numel(rois.shape) // (B * 4))
@@ -262,15 +263,21 @@ def _build_ops(mx):
             rng = _state["rng"][key]
             wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
             ws = _scratch(rois, wsb)
-            lib().call("sd_proposal_target", _ptr(rois), _ptr(gt), N, M, ctypes.byref(cp), _ptr(rng),
-                       _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
-                       _ptr(out_data[4]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
+            if vr is not None:
+                lib().call("sd_proposal_target_v2", _ptr(rois), _ptr(gt), _ptr(vr),
+                           int(p.get("filter_scales", False)), N, M, ctypes.byref(cp), _ptr(rng),
+                           _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
+                           _ptr(out_data[4]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
+            else:
+                lib().call("sd_proposal_target", _ptr(rois), _ptr(gt), N, M, ctypes.byref(cp), _ptr(rng),
+                           _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
+                           _ptr(out_data[4]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-            # proposal_target-inl.h:272-276: both input gradients are zero
-            self.assign(in_grad[0], req[0], 0)
-            self.assign(in_grad[1], req[1], 0)
+            # proposal_target-inl.h:272-276 / proposal_target_v2-inl.h:298-311: input gradients are zero
+            for i in range(len(in_grad)):
+                self.assign(in_grad[i], req[i], 0)
 
     def _numel(shape):
         n = 1
@@ -312,6 +319,26 @@ def _build_ops(mx):
             return []
 
     ops["ProposalTarget"] = (ProposalTargetProp, (None, "ProposalTarget"))
+
+    # ---- ProposalTarget_v2 (proposal_target_v2-inl.h): + valid_ranges input, filter_scales ----
+    class ProposalTargetV2Prop(ProposalTargetProp):
+        def __init__(self, num_classes, batch_images, image_rois, fg_thresh, bg_thresh_hi,
+                     bg_thresh_lo, proposal_without_gt, fg_fraction="0.25", class_agnostic="False",
+                     ohem="False", output_iou="False", bbox_mean="(0,0,0,0)",
+                     bbox_std="(0.1,0.1,0.2,0.2)", bbox_weight="(1,1,1,1)", filter_scales="False"):
+            super().__init__(num_classes, batch_images, image_rois, fg_thresh, bg_thresh_hi,
+                             bg_thresh_lo, fg_fraction, proposal_without_gt, class_agnostic,
+                             output_iou, bbox_mean, bbox_std, bbox_weight)
+            if _bool(ohem):
+                raise ValueError("ProposalTarget_v2: OHEM not Implemented.")  # as the reference (:216-217)
+            if self.p["image_rois"] < 0:
+                raise ValueError("ProposalTarget_v2: image_rois=-1 is undefined in the reference")
+            self.p["filter_scales"] = _bool(filter_scales)
+
+        def list_arguments(self):
+            return ["rois", "gt_boxes", "valid_ranges"]
+
+    ops["ProposalTarget_v2"] = (ProposalTargetV2Prop, (None, "ProposalTarget_v2"))
 
     # ---- _contrib_GenAnchor: 1 input (shape only), 1 output ----
     class GenAnchor(CustomOp):

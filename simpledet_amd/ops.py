@@ -349,10 +349,12 @@ def default_rng_state(device=None, reset_seed=None):
 def proposal_target(rois, gt_boxes, num_classes, batch_images, image_rois, fg_fraction=0.25,
                     fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0, proposal_without_gt=False,
                     class_agnostic=False, bbox_mean=(0., 0., 0., 0.), bbox_std=(.1, .1, .2, .2),
-                    bbox_weight=(1., 1., 1., 1.), rng_state=None, return_index=False):
+                    bbox_weight=(1., 1., 1., 1.), rng_state=None, return_index=False,
+                    valid_ranges=None, filter_scales=False):
     """ProposalTarget: rois (B,N,4), gt_boxes (B,M,5) -> roi_output (B,S,4), label (B,S),
     bbox_target (B,S,4K), bbox_weight (B,S,4K), match_gt_iou (B,S)  (proposal_target-inl.h:297-330).
-    rng_state: int32[33] device tensor from glibc_rand_state(); advanced in place."""
+    rng_state: int32[33] device tensor from glibc_rand_state(); advanced in place.
+    valid_ranges (B,2) selects ProposalTarget_v2 (proposal_target_v2-inl.h), with filter_scales."""
     _chk(rois, "rois", ndim=3)
     _chk(gt_boxes, "gt_boxes", ndim=3)
     B, N, _ = rois.shape
@@ -388,9 +390,17 @@ def proposal_target(rois, gt_boxes, num_classes, batch_images, image_rois, fg_fr
     kept = torch.empty((B, S), device=dev, dtype=torch.int32) if return_index else None
     wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-    lib().call("sd_proposal_target", _p(rois), _p(gt_boxes), N, M, ctypes.byref(p), _p(rng_state),
-               _p(ro), _p(lb), _p(bt), _p(bw), _p(iou), _p(kept), _p(ws), ctypes.c_size_t(wsb),
-               _stream())
+    if valid_ranges is not None:
+        _chk(valid_ranges, "valid_ranges", ndim=2)
+        if tuple(valid_ranges.shape) != (B, 2):
+            raise ValueError("valid_ranges must be (B,2)")
+        lib().call("sd_proposal_target_v2", _p(rois), _p(gt_boxes), _p(valid_ranges),
+                   int(bool(filter_scales)), N, M, ctypes.byref(p), _p(rng_state), _p(ro), _p(lb),
+                   _p(bt), _p(bw), _p(iou), _p(kept), _p(ws), ctypes.c_size_t(wsb), _stream())
+    else:
+        lib().call("sd_proposal_target", _p(rois), _p(gt_boxes), N, M, ctypes.byref(p), _p(rng_state),
+                   _p(ro), _p(lb), _p(bt), _p(bw), _p(iou), _p(kept), _p(ws), ctypes.c_size_t(wsb),
+                   _stream())
     res = (ro, lb, bt, bw, iou)
     return res + (kept,) if return_index else res
 

@@ -228,6 +228,41 @@ def case_proposal_target(i, class_agnostic=False, calls=1):
     return run
 
 
+PT2_CFGS = [dict(seed=5, B=2, N=1000, M=60, S=128, ranges=[[0, 90], [60, 400]], filter=True),
+            dict(seed=6, B=2, N=600, M=40, S=128, ranges=[[0, 90], [60, 400]], filter=False),
+            dict(seed=7, B=2, N=400, M=20, S=64, ranges=[[0, 1e5], [200, 300]], filter=True, without_gt=False,
+                 fg_fraction=0.5)]
+
+
+def case_proposal_target_v2(i):
+    """ProposalTarget_v2 (tridentnet): gt boxes outside the image's valid scale range are not
+    appended to the candidate rois."""
+    c = PT2_CFGS[i]
+
+    def run(runner):
+        kw = dict(num_classes=81, batch_images=c["B"], image_rois=c["S"], fg_fraction=c.get("fg_fraction", 0.25),
+                  fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0, proposal_without_gt=c.get("without_gt", False),
+                  class_agnostic=False)
+        rois, gt = synth.proposal_target_inputs(c["seed"], c["B"], c["N"], c["M"])
+        vr = np.array(c["ranges"], np.float32)
+        if runner == "ref":
+            from oracle import refmx
+            op = _ref("proposal_target_v2", "ProposalTarget_v2", output_iou=True, filter_scales=c["filter"], **kw)
+            refmx.srand(1)
+            res = op.forward([rois, gt, vr])
+        elif runner == "oracle":
+            orc = _orc()
+            p = orc.make_pt_param(81, c["B"], c["S"], kw["fg_fraction"], 0.5, 0.5, 0.0, kw["proposal_without_gt"])
+            res = orc.proposal_target(rois, gt, p, rng=orc.GlibcRand(1), valid_ranges=vr,
+                                      filter_scales=c["filter"])[:5]
+        else:
+            ops = _ops()
+            res = [_n(t) for t in ops.proposal_target(_t(rois), _t(gt), rng_state=ops.glibc_rand_state(1),
+                                                      valid_ranges=_t(vr), filter_scales=c["filter"], **kw)]
+        return dict(zip(PT_NAMES, res))
+    return run
+
+
 # ----------------------------------------------------------------------------------------- NMS --
 NMS_CFGS = [dict(seed=0, N=2000, pre=-1, post=1000, thr=0.7), dict(seed=2, N=1000, pre=600, post=300, thr=0.5),
             dict(seed=4, N=2500, pre=2000, post=2000, thr=0.7, mode="all_overlap")]
@@ -331,6 +366,8 @@ for _i in range(len(PT_CFGS)):
     _add("proposal_target_%d" % _i, case_proposal_target(_i), hip_close=_PT_CLOSE)
 _add("proposal_target_0_agnostic", case_proposal_target(0, class_agnostic=True), hip_close=_PT_CLOSE)
 _add("proposal_target_1_third_call", case_proposal_target(1, calls=3), hip_close=_PT_CLOSE)
+for _i in range(len(PT2_CFGS)):
+    _add("proposal_target_v2_%d" % _i, case_proposal_target_v2(_i), hip_close=_PT_CLOSE)
 for _i in range(len(NMS_CFGS)):
     _add("nms_%d" % _i, case_nms(_i))
 for _i in range(len(PV3_CFGS)):
