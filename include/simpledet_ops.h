@@ -199,6 +199,23 @@ int sd_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
  *   image without candidates / without valid gt gets one all-zero roi / gt row.  image_rois = -1
  *   is rejected (the reference allocates (B,-1,.) tensors for it).  The `ohem` parameter of the
  *   reference is LOG(FATAL) "not implemented" there and has no counterpart here. */
+/* ProposalMaskTarget (mx.sym.ProposalMaskTarget, call sites models/maskrcnn/builder.py:115,184,
+ * models/tridentnet/builder.py:377,437)
+ *   replaces ProposalMaskTargetOp::Forward  operator_cxx/proposal_mask_target-inl.h:141-330,
+ *   SampleROIMask proposal_mask_target.cc:218-378 and convertPoly2Mask :148-216 (over rleFrPoly /
+ *   rleDecode of the un-vendored COCO mask API)
+ *   = the ProposalTarget_v2 sampling (valid_ranges may be NULL: num_args = 3) plus
+ *   gt_polys (B,M,L) DEVICE, per gt box [category, n_seg, len_1..len_n, x,y,x,y,...] padded with -1
+ *   mask_target (B, FG, mask_size, mask_size), FG = (int)(image_rois * fg_fraction): rows of the
+ *   sampled foreground RoIs hold the 0/1 mask of their gt polygon in the RoI's frame, the rest -1.
+ *   output_ratio (mask-scoring R-CNN only) is not provided. */
+int sd_proposal_mask_target(const float* rois, const float* gt_boxes, const float* gt_polys,
+                            const float* valid_ranges, int filter_scales, int N, int M, int L,
+                            int mask_size, const sd_proposal_target_param* param_host,
+                            int32_t* rng_state, float* roi_output, float* label, float* bbox_target,
+                            float* bbox_weight, float* match_gt_iou, float* mask_target,
+                            int32_t* kept_index, void* workspace, size_t workspace_bytes,
+                            void* stream);
 int sd_proposal_target_v2(const float* rois, const float* gt_boxes, const float* valid_ranges,
                           int filter_scales, int N, int M,
                           const sd_proposal_target_param* param_host, int32_t* rng_state,

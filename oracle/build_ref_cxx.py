@@ -41,7 +41,13 @@ LIBS = {
     "generate_anchor": ["contrib/generate_anchor.cc", "contrib/generate_anchor.cu"],
     "nms": ["contrib/nms.cc", "contrib/nms.cu"],
     "proposal_v3": ["contrib/proposal_v3.cc", "contrib/proposal_v3.cu"],
+    # includes "../coco_api/common/maskApi.h" (github.com/RogerChern/cocoapi, NOT vendored): resolved
+    # to mxshim/coco_api/common/maskApi.h + oracle/mask_api.c, a restatement of pycocotools'
+    # rleFrPoly / rleDecode.  The op around it (sampling, polygon -> RoI frame) is reference code.
+    "proposal_mask_target": ["proposal_mask_target.cc"],
 }
+# sources of THIS repository linked into a reference library (stand-ins for un-vendored third party)
+EXTRA = {"proposal_mask_target": [os.path.join(HERE, "mask_api.c")]}
 
 CXXFLAGS = ["-std=c++11", "-O2", "-fPIC", "-w", "-pthread", "-ffp-contract=off", "-fno-fast-math",
             "-fvisibility=default"]
@@ -115,7 +121,7 @@ def up_to_date(lib, srcs):
     if not os.path.exists(so):
         return False
     t = os.path.getmtime(so)
-    deps = [os.path.join(CXX_ROOT, s) for s in srcs] + [__file__]
+    deps = [os.path.join(CXX_ROOT, s) for s in srcs] + [__file__] + EXTRA.get(lib, [])
     for root, _, files in os.walk(SHIM):
         deps += [os.path.join(root, f) for f in files]
     for s in srcs:  # the -inl.h next to each source
@@ -148,6 +154,10 @@ def build_lib(lib, srcs, tmp):
         else:
             cmd = ["g++"] + CXXFLAGS + incs + rel + ["-c", src, "-o", obj]
         subprocess.check_call(cmd)
+        objs.append(obj)
+    for extra in EXTRA.get(lib, []):
+        obj = os.path.join(tmp, lib + "_" + os.path.basename(extra).replace(".", "_") + ".o")
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-w", "-ffp-contract=off", "-I" + HERE, "-c", extra, "-o", obj])
         objs.append(obj)
     rt = os.path.join(tmp, lib + "_runtime.o")
     subprocess.check_call(["g++"] + CXXFLAGS + incs + ["-c", os.path.join(SHIM, "runtime.cc"), "-o", rt])

@@ -935,6 +935,7 @@ struct PropEntry {
   PropEntry &add_arguments(const std::vector<dmlc::ParamFieldInfo> &) { return *this; }
   PropEntry &set_return_type(const std::string &) { return *this; }
   PropEntry &add_alias(const std::string &) { return *this; }
+  PropEntry &set_key_var_num_args(const std::string &) { return *this; }
 };
 PropEntry &RegisterProp(const char *name, std::function<mxnet::OperatorProperty *()> body);
 nnvm::Op &RegisterOp(const char *name);

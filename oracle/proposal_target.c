@@ -68,7 +68,7 @@ static int sample_roi(const float* all_rois, unsigned n_rois, const float* gt_bo
                       const orc_proposal_target_param* p, unsigned fg_rois_per_image,
                       unsigned rois_per_image, rand_fn rf, void* rs, float* rois, float* labels,
                       float* bbox_targets, float* bbox_weights, float* match_gt_ious,
-                      int* kept_out) {
+                      int* kept_out, unsigned* fg_this_out, unsigned* gt_of_row_out) {
   int ub = 0;
   float* max_overlaps = (float*)calloc(n_rois + 1, sizeof(float));
   float* all_labels = (float*)calloc(n_rois + 1, sizeof(float));
@@ -147,7 +147,9 @@ static int sample_roi(const float* all_rois, unsigned n_rois, const float* gt_bo
     memcpy(rois + i * 4, all_rois + (size_t)kept[i] * 4, 4 * sizeof(float));
     match_gt_ious[i] = max_overlaps[kept[i]];
     if (kept_out) kept_out[i] = (int)kept[i];
+    if (gt_of_row_out) gt_of_row_out[i] = gt_assignment[kept[i]];
   }
+  if (fg_this_out) *fg_this_out = fg_this;
   /* :138-161: targets for every output row; rows >= nkept read garbage in the reference and end up
    * zero because their label is 0, so they are skipped here */
   const unsigned K4 = 4 * (unsigned)p->num_classes;
@@ -195,11 +197,54 @@ static int sample_roi(const float* all_rois, unsigned n_rois, const float* gt_bo
  *   image_rois == -1 ("keep every roi") makes the reference allocate (B, -1, .) host tensors
  *   (:209-213) and is rejected.  SampleROI itself (proposal_target_v2.cc:21-177) equals v1's for
  *   image_rois != -1. */
+/* convertPoly2Mask, operator_cxx/proposal_mask_target.cc:148-216.  poly = [category, n_seg,
+ * len_1..len_n, x,y,x,y,...]; the polygon is mapped into the RoI's mask_size x mask_size frame (in
+ * DType = float arithmetic), x and y are swapped on the way into rleFrPoly so that its
+ * column-major decode comes out row-major, and the segments are OR-ed. */
+#include "mxshim/coco_api/common/maskApi.h"
+static void convert_poly2mask(const float* roi, const float* poly, int mask_size, float* mask) {
+  float w = roi[2] - roi[0], h = roi[3] - roi[1];
+  w = fmax2(1.f, w);
+  h = fmax2(1.f, h);
+  int n_seg = (int)poly[1];
+  if (n_seg < 0) n_seg = 0; /* the -1 filled row of an image without gt (:...-inl.h) */
+  int offset = 2 + n_seg;
+  RLE* rles;
+  rlesInit(&rles, (siz)n_seg);
+  for (int i = 0; i < n_seg; i++) {
+    int cur_len = (int)poly[i + 2];
+    double* xys = (double*)malloc(sizeof(double) * (cur_len > 0 ? cur_len : 1));
+    for (int j = 0; j < cur_len; j++) {
+      if (j % 2 == 0) xys[j] = (poly[offset + j + 1] - roi[1]) * mask_size / h;
+      else xys[j] = (poly[offset + j - 1] - roi[0]) * mask_size / w;
+    }
+    rleFrPoly(rles + i, xys, (siz)(cur_len / 2), (siz)mask_size, (siz)mask_size);
+    free(xys);
+    offset += cur_len;
+  }
+  const int area = mask_size * mask_size;
+  byte* bm = (byte*)malloc((size_t)area * (n_seg > 0 ? n_seg : 1));
+  rleDecode(rles, bm, (siz)n_seg);
+  for (int j = 0; j < area; j++) {
+    float cur = 0;
+    for (int i = 0; i < n_seg; i++)
+      if (bm[(size_t)i * area + j] == 1) { cur = 1; break; }
+    mask[j] = cur;
+  }
+  rlesFree(&rles, (siz)n_seg);
+  free(bm);
+}
+
+/* valid_ranges selects the v2 / mask-target front end; gt_polys != NULL adds ProposalMaskTarget's
+ * mask output (proposal_mask_target-inl.h:141-330, proposal_mask_target.cc:218-378):
+ * mask_target (B, FG, ms, ms) with FG = (index_t)(image_rois * fg_fraction), -1 filled, rows
+ * [0, fg_rois_this_image) rasterised from the polygon of the RoI's assigned gt box. */
 static int proposal_target_impl(const float* rois, const float* gt_boxes, const float* valid_ranges,
                                 int filter_scales, int N, int M,
                                 const orc_proposal_target_param* p, rand_fn rf, void* rs,
                                 float* roi_out, float* label, float* bbox_target,
-                                float* bbox_weight, float* match_gt_iou, int* kept_index) {
+                                float* bbox_weight, float* match_gt_iou, int* kept_index,
+                                const float* gt_polys, int L, int mask_size, float* mask_target) {
   const int B = p->batch_images, S = p->image_rois, K4 = 4 * p->num_classes;
   int rc = 0;
   /* outputs are zero-initialised containers (proposal_target-inl.h:189-193) */
@@ -213,11 +258,17 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
   unsigned fg_rois_per_image = (unsigned)(S * p->fg_fraction); /* :194 static_cast truncation */
   float* kept_rois = (float*)malloc(sizeof(float) * 4 * (size_t)(N + M + 1));
   float* kept_gt = (float*)malloc(sizeof(float) * 5 * (size_t)(M + 1));
+  const int v2 = valid_ranges != NULL || gt_polys != NULL;
+  const int FG = (int)(S * p->fg_fraction);
+  int* gt_src = (int*)malloc(sizeof(int) * (size_t)(M + 1));       /* kept gt -> input row */
+  unsigned* gt_of_row = (unsigned*)malloc(sizeof(unsigned) * (size_t)(S + 1));
+  if (mask_target)
+    for (size_t t = 0; t < (size_t)B * FG * mask_size * mask_size; ++t) mask_target[t] = -1.f;
   for (int i = 0; i < B; ++i) {
     unsigned n_gt = 0, n_rois = 0;
     for (int j = 0; j < M; ++j) { /* :155-162 */
       const float* g = gt_boxes + ((size_t)i * M + j) * 5;
-      if (g[4] != -1) memcpy(kept_gt + 5 * n_gt++, g, 5 * sizeof(float));
+      if (g[4] != -1) { gt_src[n_gt] = j; memcpy(kept_gt + 5 * n_gt++, g, 5 * sizeof(float)); }
     }
     for (int j = 0; j < N; ++j) { /* :171-175, y2 == 0 indicates padding */
       const float* r = rois + ((size_t)i * N + j) * 4;
@@ -238,17 +289,33 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
         memcpy(kept_rois + 4 * n_rois++, g, 4 * sizeof(float));
       }
     }
-    if (valid_ranges) { /* v2 :244-249 */
+    int no_gt = 0;
+    if (v2) { /* v2 :244-249, mask target -inl.h:268-276 */
       if (n_rois == 0) { memset(kept_rois, 0, 4 * sizeof(float)); n_rois = 1; }
-      if (n_gt == 0) { memset(kept_gt, 0, 5 * sizeof(float)); n_gt = 1; }
+      if (n_gt == 0) { memset(kept_gt, 0, 5 * sizeof(float)); n_gt = 1; no_gt = 1; }
     }
+    unsigned fg_this = 0;
     int e = sample_roi(kept_rois, n_rois, kept_gt, n_gt, p, fg_rois_per_image, (unsigned)S, rf, rs,
                        roi_out + (size_t)i * S * 4, label + (size_t)i * S,
                        bbox_target + (size_t)i * S * K4, bbox_weight + (size_t)i * S * K4,
-                       match_gt_iou + (size_t)i * S, kept_index ? kept_index + (size_t)i * S : NULL);
+                       match_gt_iou + (size_t)i * S, kept_index ? kept_index + (size_t)i * S : NULL,
+                       &fg_this, gt_of_row);
     if (e) rc = e;
+    if (mask_target && !no_gt) /* an image without gt has one all -1 polygon row: nothing to draw
+                                  (and no roi reaches fg_thresh against the 1-pixel zero box ... if one
+                                  does, n_seg = -1 draws an all-zero mask; restated in the else branch) */
+      for (unsigned r = 0; r < fg_this && r < (unsigned)FG; ++r)
+        convert_poly2mask(roi_out + ((size_t)i * S + r) * 4,
+                          gt_polys + ((size_t)i * M + gt_src[gt_of_row[r]]) * L, mask_size,
+                          mask_target + ((size_t)i * FG + r) * mask_size * mask_size);
+    else if (mask_target) {
+      float neg1[4] = {-1.f, -1.f, -1.f, -1.f};
+      for (unsigned r = 0; r < fg_this && r < (unsigned)FG; ++r)
+        convert_poly2mask(roi_out + ((size_t)i * S + r) * 4, neg1, mask_size,
+                          mask_target + ((size_t)i * FG + r) * mask_size * mask_size);
+    }
   }
-  free(kept_rois); free(kept_gt);
+  free(kept_rois); free(kept_gt); free(gt_src); free(gt_of_row);
   return rc;
 }
 
@@ -257,7 +324,24 @@ int orc_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
                         float* label, float* bbox_target, float* bbox_weight, float* match_gt_iou,
                         int* kept_index) {
   return proposal_target_impl(rois, gt_boxes, NULL, 0, N, M, p, rand_state, rng, roi_out, label,
-                              bbox_target, bbox_weight, match_gt_iou, kept_index);
+                              bbox_target, bbox_weight, match_gt_iou, kept_index, NULL, 0, 0, NULL);
+}
+
+/* ProposalMaskTarget without output_ratio.  valid_ranges may be NULL (num_args = 3). */
+int orc_proposal_mask_target(const float* rois, const float* gt_boxes, const float* gt_polys,
+                             const float* valid_ranges, int filter_scales, int N, int M, int L,
+                             int mask_size, const orc_proposal_target_param* p, orc_glibc_rand* rng,
+                             float* roi_out, float* label, float* bbox_target, float* bbox_weight,
+                             float* match_gt_iou, int* kept_index, float* mask_target) {
+  if (p->image_rois < 0 || !gt_polys || !mask_target) return -2;
+  return proposal_target_impl(rois, gt_boxes, valid_ranges, valid_ranges ? filter_scales : 0, N, M, p,
+                              rand_state, rng, roi_out, label, bbox_target, bbox_weight,
+                              match_gt_iou, kept_index, gt_polys, L, mask_size, mask_target);
+}
+
+int orc_poly2mask(const float* roi, const float* poly, int mask_size, float* mask) {
+  convert_poly2mask(roi, poly, mask_size, mask);
+  return 0;
 }
 
 int orc_proposal_target_v2(const float* rois, const float* gt_boxes, const float* valid_ranges,
@@ -266,7 +350,8 @@ int orc_proposal_target_v2(const float* rois, const float* gt_boxes, const float
                            float* bbox_weight, float* match_gt_iou, int* kept_index) {
   if (p->image_rois < 0 || !valid_ranges) return -2;
   return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, N, M, p, rand_state, rng,
-                              roi_out, label, bbox_target, bbox_weight, match_gt_iou, kept_index);
+                              roi_out, label, bbox_target, bbox_weight, match_gt_iou, kept_index,
+                              NULL, 0, 0, NULL);
 }
 
 int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, int M,
@@ -274,5 +359,5 @@ int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, in
                              float* bbox_target, float* bbox_weight, float* match_gt_iou,
                              int* kept_index) {
   return proposal_target_impl(rois, gt_boxes, NULL, 0, N, M, p, rand_libc, NULL, roi_out, label,
-                              bbox_target, bbox_weight, match_gt_iou, kept_index);
+                              bbox_target, bbox_weight, match_gt_iou, kept_index, NULL, 0, 0, NULL);
 }

@@ -253,6 +253,42 @@ def proposal_target(rois, gt_boxes, param, rng=None, use_libc=False, valid_range
     return ro, lb, bt, bw, iou, kept, rc
 
 
+def proposal_mask_target(rois, gt_boxes, gt_polys, param, mask_size=28, rng=None, valid_ranges=None,
+                         filter_scales=False):
+    """ProposalMaskTarget (output_ratio=False): the six outputs + kept_index."""
+    rois, pr = _f(rois)
+    gt, pg = _f(gt_boxes)
+    polys, pp = _f(gt_polys)
+    B, N, _ = rois.shape
+    M, L = gt.shape[1], polys.shape[2]
+    S, K4 = param.image_rois, 4 * param.num_classes
+    FG = int(np.float32(S) * np.float32(param.fg_fraction))
+    ro = np.empty((B, S, 4), np.float32)
+    lb = np.empty((B, S), np.float32)
+    bt = np.empty((B, S, K4), np.float32)
+    bw = np.empty((B, S, K4), np.float32)
+    iou = np.empty((B, S), np.float32)
+    kept = np.empty((B, S), np.int32)
+    mask = np.empty((B, FG, mask_size, mask_size), np.float32)
+    pv = None
+    if valid_ranges is not None:
+        vr, pv = _f(valid_ranges)
+    if rng is None:
+        rng = GlibcRand(1)
+    cdll().orc_proposal_mask_target(pr, pg, pp, pv, int(filter_scales), N, M, L, int(mask_size),
+                                    ctypes.byref(param), ctypes.byref(rng), ro.ctypes, lb.ctypes,
+                                    bt.ctypes, bw.ctypes, iou.ctypes, kept.ctypes, mask.ctypes)
+    return ro, lb, bt, bw, iou, mask, kept
+
+
+def poly2mask(roi, poly, mask_size=28):
+    roi, pr = _f(roi)
+    poly, pp = _f(poly)
+    m = np.empty((mask_size, mask_size), np.float32)
+    cdll().orc_poly2mask(pr, pp, int(mask_size), m.ctypes)
+    return m
+
+
 def std_random_shuffle(a):
     a = np.ascontiguousarray(a, np.uint32).copy()
     cdll().orc_std_random_shuffle(a.ctypes, len(a))

@@ -34,15 +34,20 @@ struct PtWs {
   int* fg;          // (B, Ncand)
   int* neg;         // (B, Ncand)
   int* bg;          // (B, Ncand)
-  int* counts;      // (B, 8): n_cand, n_gt, n_fg, n_neg, n_bg, fg_this, n_kept
+  int* counts;      // (B, 8): n_cand, n_gt, n_fg, n_neg, n_bg, fg_this, n_kept, no_gt
   int* kept;        // (B, S)
+  int* gtsrc;       // (B, M) input row of every valid gt box (ProposalMaskTarget: its polygon)
 };
 
 struct PtArgs {
   const float* rois;
   const float* gt;
-  const float* valid_ranges;  // ProposalTarget_v2: (B,2) [min, max] object scale; null = v1
-  int filter_scales;          // v2: append only the gt boxes inside the valid range
+  const float* valid_ranges;  // ProposalTarget_v2 / MaskTarget: (B,2) [min, max] object scale, or null
+  int filter_scales;          // append only the gt boxes inside the valid range
+  int v2;                     // v2 / MaskTarget: an empty roi / gt list is replaced by one zero row
+  const float* polys;         // ProposalMaskTarget: (B, M, L) gt polygons, or null
+  float* mask_out;            // (B, FG, ms, ms)
+  int L, mask_size, FG;
   PtWs ws;
   sd_proposal_target_param p;
   int B, N, M, Mws, Ncand, S, fg_per_image;  // Mws = max(M, 1): row stride of the gt workspace
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
   float4* cand = ws.cand + (long)img * a.Ncand;
   float4* gtbox = ws.gtbox + (long)img * a.Mws;
   float* gtcls = ws.gtcls + (long)img * a.Mws;
+  int* gtsrc = ws.gtsrc + (long)img * a.Mws;
 
   // ---- valid gt boxes (cls != -1), order preserved (proposal_target-inl.h:155-162) ----
   int n_gt = 0;
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
       garea[n_gt + off] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
       gtbox[n_gt + off] = b;
       gtcls[n_gt + off] = g[4];
+      gtsrc[n_gt + off] = j;
     }
     n_gt += tot;
   }
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
       n_cand += n_gt;
     }
   }
-  if (a.valid_ranges) {
+  if (a.v2) {
     // v2 (:244-249): no candidate -> one all-zero roi; no valid gt -> one all-zero gt row (its
     // class column is read out of bounds by the reference; defined as 0 here)
     if (n_cand == 0) {
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(THREADS) void pt_assign_kernel(PtArgs a) {
         garea[0] = 1.f;
         gtbox[0] = gbox[0];
         gtcls[0] = 0.f;
+        gtsrc[0] = -1;  // no polygon: ProposalMaskTarget draws an empty mask
       }
       n_gt = 1;
     }
@@ -475,6 +483,162 @@ __global__ __launch_bounds__(128) void pt_encode_kernel(PtArgs a) {
   }
 }
 
+
+// ---- ProposalMaskTarget: polygon of the assigned gt box -> mask_size x mask_size target -----------
+// reference: convertPoly2Mask, operator_cxx/proposal_mask_target.cc:148-216, over the COCO mask API
+// (rleFrPoly + rleDecode of github.com/RogerChern/cocoapi, un-vendored: the published pycocotools
+// algorithm is followed -- parity unpinned, see oracle/mask_api.c).
+// One workgroup per (image, foreground slot).  rleFrPoly is a sequential walk; its result, though,
+// is "pixel t (column-major) is set iff an odd number of boundary crossings has position <= t", so
+//   * every vertex is scaled x5 and rounded, every edge owns max(|dx|,|dy|)+1 dense points (block
+//     prefix sum over the edges),
+//   * every dense point is handled by its own thread: it recomputes itself and its predecessor
+//     with the reference's double expressions, and where the up-sampled column changes it toggles
+//     one bit of an LDS bitmap at x*h + ceil(y) (two crossings at one place cancel, exactly like
+//     the zero-length runs rleFrPoly merges),
+//   * one wave turns the bitmap into the mask with a ballot/popcount prefix parity,
+//   * the segments of a polygon are OR-ed (:196-206).
+// The reference swaps x and y on the way in, which makes the column-major decode row-major.
+constexpr int kMaskThreads = 256;
+constexpr int kMaskMaxVerts = 2048;  // vertices per segment held in LDS
+
+__device__ __forceinline__ void poly_point(const int* vx, const int* vy, int e, int d, int* u, int* v) {
+  int xs = vx[e], xe = vx[e + 1], ys = vy[e], ye = vy[e + 1];
+  const int dx = abs(xe - xs), dy = abs(ys - ye);
+  const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+  if (flip) { int t = xs; xs = xe; xe = t; t = ys; ys = ye; ye = t; }
+  const double s = dx >= dy ? (double)(ye - ys) / (double)dx : (double)(xe - xs) / (double)dy;
+  if (dx >= dy) {
+    const int t = flip ? dx - d : d;
+    *u = t + xs;
+    *v = (int)((double)ys + s * (double)t + .5);
+  } else {
+    const int t = flip ? dy - d : d;
+    *v = t + ys;
+    *u = (int)((double)xs + s * (double)t + .5);
+  }
+}
+
+__global__ __launch_bounds__(kMaskThreads) void pt_mask_kernel(PtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int msm[];
+  __shared__ int wave_sums[kMaskThreads / kWave];
+  __shared__ int s_total;
+  const int row = blockIdx.x, img = row / a.FG, slot = row % a.FG, tid = threadIdx.x;
+  const int ms = a.mask_size, area = ms * ms;
+  float* out = a.mask_out + (long)row * area;
+  const int* c = a.ws.counts + img * 8;
+  const int fg_this = c[5];
+  if (slot >= fg_this) {  // rows past the sampled foreground keep the -1 fill (-inl.h:211-212)
+    for (int j = tid; j < area; j += kMaskThreads) out[j] = -1.f;
+    return;
+  }
+  int* vx = msm;                      // [kMaskMaxVerts + 1]
+  int* vy = vx + kMaskMaxVerts + 1;   // [kMaskMaxVerts + 1]
+  int* start = vy + kMaskMaxVerts + 1;  // [kMaskMaxVerts + 1] first dense point of every edge
+  int* tog = start + kMaskMaxVerts + 1;  // [area] crossing parity per position
+  int* acc = tog + area;                 // [area] OR over the segments
+  for (int j = tid; j < area; j += kMaskThreads) { tog[j] = 0; acc[j] = 0; }
+  const int kidx = a.ws.kept[(long)img * a.S + slot];
+  const int g = a.ws.gta[(long)img * a.Ncand + kidx];
+  const int src = a.ws.gtsrc[(long)img * a.Mws + g];
+  const float4 roi = reinterpret_cast<const float4*>(a.roi_out)[(long)img * a.S + slot];
+  float w = roi.z - roi.x, h = roi.w - roi.y;
+  w = 1.f < w ? w : 1.f;  // std::max((DType)1., w)
+  h = 1.f < h ? h : 1.f;
+  const float* poly = src >= 0 ? a.polys + ((long)img * a.M + src) * a.L : nullptr;
+  int n_seg = poly ? (int)poly[1] : 0;
+  if (n_seg < 0) n_seg = 0;
+  int offset = 2 + n_seg;
+  __syncthreads();
+  for (int sgi = 0; sgi < n_seg; ++sgi) {
+    const int cur_len = (int)poly[sgi + 2];
+    int k = cur_len / 2;
+    if (k > kMaskMaxVerts) k = kMaskMaxVerts;  // (the reference has no limit; L bounds it in practice)
+    // vertices in the RoI's mask frame, x5, rounded: "x" of the mask API = row coordinate
+    for (int t = tid; t < k; t += kMaskThreads) {
+      const float px = poly[offset + 2 * t], py = poly[offset + 2 * t + 1];
+      const float fy = (py - roi.y) * (float)ms / h;  // xys[2t]
+      const float fx = (px - roi.x) * (float)ms / w;  // xys[2t+1]
+      vx[t] = (int)(5.0 * (double)fy + .5);
+      vy[t] = (int)(5.0 * (double)fx + .5);
+    }
+    __syncthreads();
+    if (tid == 0 && k > 0) { vx[k] = vx[0]; vy[k] = vy[0]; }
+    __syncthreads();
+    // dense points per edge, exclusive prefix sum
+    int run = 0;
+    for (int base = 0; base < k; base += kMaskThreads) {
+      const int e = base + tid;
+      int cnt = 0;
+      if (e < k) {
+        const int dx = abs(vx[e] - vx[e + 1]), dy = abs(vy[e] - vy[e + 1]);
+        cnt = (dx > dy ? dx : dy) + 1;
+      }
+      // inclusive scan inside the wave, then across the waves
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if ((tid & (kWave - 1)) >= o) incl += t;
+      }
+      __syncthreads();
+      if ((tid & (kWave - 1)) == kWave - 1) wave_sums[tid / kWave] = incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+      for (int wv = 0; wv < kMaskThreads / kWave; ++wv) {
+        if (wv < tid / kWave) woff += wave_sums[wv];
+        tot += wave_sums[wv];
+      }
+      if (e < k) start[e] = run + woff + incl - cnt;
+      run += tot;
+    }
+    if (tid == 0) { start[k] = run; s_total = run; }
+    __syncthreads();
+    const int m = s_total;
+    for (int gidx = 1 + tid; gidx < m; gidx += kMaskThreads) {
+      // edge of this dense point: last e with start[e] <= gidx
+      int lo = 0, hi = k - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= gidx) lo = mid; else hi = mid - 1;
+      }
+      int u1, v1, u0, v0;
+      poly_point(vx, vy, lo, gidx - start[lo], &u1, &v1);
+      if (gidx - 1 >= start[lo]) poly_point(vx, vy, lo, gidx - 1 - start[lo], &u0, &v0);
+      else poly_point(vx, vy, lo - 1, gidx - 1 - start[lo - 1], &u0, &v0);
+      if (u1 != u0) {
+        double xd = (double)(u1 < u0 ? u1 : u1 - 1);
+        xd = (xd + .5) / 5.0 - .5;
+        if (floor(xd) != xd || xd < 0 || xd > (double)(ms - 1)) continue;
+        double yd = (double)(v1 < v0 ? v1 : v0);
+        yd = (yd + .5) / 5.0 - .5;
+        if (yd < 0) yd = 0; else if (yd > (double)ms) yd = (double)ms;
+        yd = ceil(yd);
+        const int pos = (int)xd * ms + (int)yd;
+        if (pos < area) atomicXor(&tog[pos], 1);
+      }
+    }
+    __syncthreads();
+    if (tid < kWave) {  // prefix parity -> mask of this segment, OR-ed into acc
+      int carry = 0;
+      for (int base = 0; base < area; base += kWave) {
+        const int pos = base + tid;
+        const int bit = pos < area ? tog[pos] : 0;
+        const unsigned long long bits = __ballot(bit);
+        const int par = (__popcll(bits & ((2ull << tid) - 1ull)) + carry) & 1;
+        if (pos < area) {
+          if (par) acc[pos] = 1;
+          tog[pos] = 0;
+        }
+        carry ^= __popcll(bits) & 1;
+      }
+    }
+    __syncthreads();
+    offset += cur_len;
+  }
+  for (int j = tid; j < area; j += kMaskThreads) out[j] = acc[j] ? 1.f : 0.f;
+}
+
 static inline size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
 
 static size_t pt_layout(int B, int N, int M, int S, PtWs* ws, char* base) {
@@ -490,6 +654,7 @@ static size_t pt_layout(int B, int N, int M, int S, PtWs* ws, char* base) {
   const size_t o_gtbox = take((size_t)B * M * 16), o_gtcls = take((size_t)B * M * 4);
   const size_t o_fg = take(B * Ncand * 4), o_neg = take(B * Ncand * 4), o_bg = take(B * Ncand * 4);
   const size_t o_cnt = take((size_t)B * 8 * 4), o_kept = take((size_t)B * (S > 0 ? S : 1) * 4);
+  const size_t o_gtsrc = take((size_t)B * M * 4);
   if (ws) {
     ws->cand = reinterpret_cast<float4*>(base + o_cand);
     ws->ov = reinterpret_cast<float*>(base + o_ov);
@@ -501,6 +666,7 @@ static size_t pt_layout(int B, int N, int M, int S, PtWs* ws, char* base) {
     ws->bg = reinterpret_cast<int*>(base + o_bg);
     ws->counts = reinterpret_cast<int*>(base + o_cnt);
     ws->kept = reinterpret_cast<int*>(base + o_kept);
+    ws->gtsrc = reinterpret_cast<int*>(base + o_gtsrc);
   }
   return off;
 }
@@ -544,11 +710,13 @@ extern "C" size_t sd_proposal_target_workspace_bytes(int B, int N, int M) {
 }
 
 static int proposal_target_impl(const float* rois, const float* gt_boxes, const float* valid_ranges,
-                                int filter_scales, int N, int M,
+                                int filter_scales, int v2, int N, int M,
                                 const sd_proposal_target_param* param_host, int32_t* rng_state,
                                 float* roi_output, float* label, float* bbox_target,
                                 float* bbox_weight, float* match_gt_iou, int32_t* kept_index,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                void* workspace, size_t workspace_bytes, void* stream,
+                                const float* gt_polys = nullptr, int L = 0, int mask_size = 0,
+                                float* mask_target = nullptr) {
   SD_REQUIRE(param_host, "param is null");
   const sd_proposal_target_param& p = *param_host;
   const int B = p.batch_images, S = p.image_rois;
@@ -570,7 +738,9 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
     return fail(SD_ERR_WORKSPACE, "ProposalTarget workspace too small: %zu < %zu bytes",
                 workspace_bytes, need);
   a.rois = rois; a.gt = gt_boxes; a.p = p;
-  a.valid_ranges = valid_ranges; a.filter_scales = filter_scales;
+  a.valid_ranges = valid_ranges; a.filter_scales = valid_ranges ? filter_scales : 0; a.v2 = v2;
+  a.polys = gt_polys; a.mask_out = mask_target; a.L = L; a.mask_size = mask_size;
+  a.FG = (int)((float)S * p.fg_fraction);
   a.B = B; a.N = N; a.M = M; a.Mws = M > 0 ? M : 1; a.Ncand = N + a.Mws; a.S = S;
   a.fg_per_image = (int)((float)S * p.fg_fraction);  // static_cast<index_t>(image_rois * fg_fraction)
   a.rng = rng_state;
@@ -591,6 +761,12 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
   SD_LAUNCH_CHECK();
   hipLaunchKernelGGL(pt_encode_kernel, dim3(B * S), dim3(128), 0, st, a);
   SD_LAUNCH_CHECK();
+  if (mask_target && a.FG > 0) {
+    const size_t lds3 = (size_t)(3 * (kMaskMaxVerts + 1) + 2 * mask_size * mask_size) * sizeof(int);
+    SD_REQUIRE(lds3 <= 64 * 1024, "mask_size=%d too large", mask_size);
+    hipLaunchKernelGGL(pt_mask_kernel, dim3(B * a.FG), dim3(kMaskThreads), lds3, st, a);
+    SD_LAUNCH_CHECK();
+  }
   return SD_OK;
 }
 
@@ -599,7 +775,7 @@ extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int 
                                   float* roi_output, float* label, float* bbox_target,
                                   float* bbox_weight, float* match_gt_iou, int32_t* kept_index,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-  return proposal_target_impl(rois, gt_boxes, nullptr, 0, N, M, param_host, rng_state, roi_output,
+  return proposal_target_impl(rois, gt_boxes, nullptr, 0, 0, N, M, param_host, rng_state, roi_output,
                               label, bbox_target, bbox_weight, match_gt_iou, kept_index, workspace,
                               workspace_bytes, stream);
 }
@@ -617,7 +793,27 @@ extern "C" int sd_proposal_target_v2(const float* rois, const float* gt_boxes,
   // (proposal_target_v2-inl.h:209-213): undefined there, rejected here
   SD_REQUIRE(param_host->image_rois >= 0,
              "ProposalTarget_v2: image_rois=-1 is undefined in the reference (negative tensor shape)");
-  return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, N, M, param_host,
+  return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, 1, N, M, param_host,
                               rng_state, roi_output, label, bbox_target, bbox_weight, match_gt_iou,
                               kept_index, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sd_proposal_mask_target(const float* rois, const float* gt_boxes,
+                                       const float* gt_polys, const float* valid_ranges,
+                                       int filter_scales, int N, int M, int L, int mask_size,
+                                       const sd_proposal_target_param* param_host,
+                                       int32_t* rng_state, float* roi_output, float* label,
+                                       float* bbox_target, float* bbox_weight, float* match_gt_iou,
+                                       float* mask_target, int32_t* kept_index, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  SD_REQUIRE(param_host, "param is null");
+  SD_REQUIRE(param_host->image_rois >= 0,
+             "ProposalMaskTarget: image_rois=-1 is undefined in the reference (negative tensor shape)");
+  SD_REQUIRE(mask_size > 0 && L >= 2, "bad mask_size / polygon length");
+  SD_REQUIRE((gt_polys && mask_target) || param_host->batch_images == 0, "gt_polys / mask_target is null");
+  SD_REQUIRE(!filter_scales || valid_ranges, "filter_scales needs valid_ranges (num_args = 4)");
+  return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, 1, N, M, param_host,
+                              rng_state, roi_output, label, bbox_target, bbox_weight, match_gt_iou,
+                              kept_index, workspace, workspace_bytes, stream, gt_polys, L, mask_size,
+                              mask_target);
 }

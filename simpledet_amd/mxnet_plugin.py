@@ -340,6 +340,94 @@ def _build_ops(mx):
 
     ops["ProposalTarget_v2"] = (ProposalTargetV2Prop, (None, "ProposalTarget_v2"))
 
+    # ---- ProposalMaskTarget (proposal_mask_target-inl.h): rois, gt_boxes, gt_polys [, valid_ranges]
+    #      -> the five ProposalTarget outputs + mask_target (6 visible; mask_ratio not provided) ----
+    class ProposalMaskTarget(CustomOp):
+        def __init__(self, p):
+            super().__init__()
+            self.p = p
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            _no_add(req)
+            from .ops import ProposalTargetParam
+            _require_write(req[:6], ["roi_output", "label", "bbox_target", "bbox_weight", "match_gt_iou",
+                                     "mask_target"])
+            rois, gt, polys = in_data[0], in_data[1], in_data[2]
+            vr = in_data[3] if len(in_data) > 3 else None
+            _wait(*in_data)
+            p = self.p
+            B = p["batch_images"]
+            N = int(_numel(rois.shape) // (B * 4))
+            M = int(_numel(gt.shape) // (B * 5))
+            L = int(polys.shape[2])
+            cp = ProposalTargetParam()
+            cp.num_classes, cp.batch_images, cp.image_rois = p["num_classes"], B, p["image_rois"]
+            cp.fg_fraction, cp.fg_thresh = p["fg_fraction"], p["fg_thresh"]
+            cp.bg_thresh_hi, cp.bg_thresh_lo = p["bg_thresh_hi"], p["bg_thresh_lo"]
+            cp.proposal_without_gt, cp.class_agnostic = int(p["proposal_without_gt"]), int(p["class_agnostic"])
+            for i in range(4):
+                cp.bbox_mean[i], cp.bbox_std[i], cp.bbox_weight[i] = (p["bbox_mean"][i], p["bbox_std"][i],
+                                                                       p["bbox_weight"][i])
+            key = str(rois.context)
+            if key not in _state["rng"]:
+                host = (ctypes.c_int32 * 33)()
+                lib().call("sd_glibc_srand_host", ctypes.c_uint32(1), host)
+                _state["rng"][key] = _state["mx"].nd.array(list(host), ctx=rois.context, dtype="int32")
+            rng = _state["rng"][key]
+            wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
+            ws = _scratch(rois, wsb)
+            lib().call("sd_proposal_mask_target", _ptr(rois), _ptr(gt), _ptr(polys), _ptr(vr),
+                       int(p["filter_scales"]), N, M, L, p["mask_size"], ctypes.byref(cp), _ptr(rng),
+                       _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
+                       _ptr(out_data[4]), _ptr(out_data[5]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
+            _sync()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            for i in range(len(in_grad)):
+                self.assign(in_grad[i], req[i], 0)
+
+    class ProposalMaskTargetProp(ProposalTargetProp):
+        def __init__(self, num_args, num_classes, batch_images, image_rois, mask_size, fg_thresh,
+                     bg_thresh_hi, bg_thresh_lo, proposal_without_gt, fg_fraction="0.25",
+                     class_agnostic="False", ohem="False", output_ratio="False", output_iou="False",
+                     filter_scales="False", bbox_mean="(0,0,0,0)", bbox_std="(0.1,0.1,0.2,0.2)",
+                     bbox_weight="(1,1,1,1)"):
+            super().__init__(num_classes, batch_images, image_rois, fg_thresh, bg_thresh_hi,
+                             bg_thresh_lo, fg_fraction, proposal_without_gt, class_agnostic,
+                             output_iou, bbox_mean, bbox_std, bbox_weight)
+            if _bool(ohem):
+                raise ValueError("ProposalMaskTarget: OHEM not Implemented.")
+            if _bool(output_ratio):
+                raise ValueError("ProposalMaskTarget: output_ratio (mask scoring) is not provided")
+            if self.p["image_rois"] < 0:
+                raise ValueError("ProposalMaskTarget: image_rois=-1 is undefined in the reference")
+            self.p["filter_scales"] = _bool(filter_scales)
+            self.p["mask_size"] = int(mask_size)
+            self.num_args = int(num_args)
+            if self.num_args not in (3, 4):
+                raise ValueError("num_args must be 3 or 4")
+            self.num_visible_outputs = 6  # proposal_mask_target-inl.h:387-395 without output_ratio
+
+        def list_arguments(self):
+            base = ["rois", "gt_boxes", "gt_polys"]
+            return base + ["valid_ranges"] if self.p["filter_scales"] else base
+
+        def list_outputs(self):
+            return ["roi_output", "label", "bbox_target", "bbox_weight", "match_gt_iou", "mask_target"]
+
+        def infer_shape(self, in_shape):
+            p = self.p
+            B, S, K = p["batch_images"], p["image_rois"], p["num_classes"]
+            import numpy as np
+            FG = int(np.float32(S) * np.float32(p["fg_fraction"]))
+            return in_shape, [(B, S, 4), (B, S), (B, S, K * 4), (B, S, K * 4), (B, S),
+                              (B, FG, p["mask_size"], p["mask_size"])]
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return ProposalMaskTarget(self.p)
+
+    ops["ProposalMaskTarget"] = (ProposalMaskTargetProp, (None, "ProposalMaskTarget"))
+
     # ---- _contrib_GenAnchor: 1 input (shape only), 1 output ----
     class GenAnchor(CustomOp):
         def __init__(self, scales, ratios, stride):

@@ -405,6 +405,55 @@ def proposal_target(rois, gt_boxes, num_classes, batch_images, image_rois, fg_fr
     return res + (kept,) if return_index else res
 
 
+def proposal_mask_target(rois, gt_boxes, gt_polys, num_classes, batch_images, image_rois, mask_size=28,
+                         fg_fraction=0.25, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0,
+                         proposal_without_gt=False, class_agnostic=False, bbox_mean=(0., 0., 0., 0.),
+                         bbox_std=(.1, .1, .2, .2), bbox_weight=(1., 1., 1., 1.), rng_state=None,
+                         valid_ranges=None, filter_scales=False, return_index=False):
+    """ProposalMaskTarget (proposal_mask_target-inl.h): ProposalTarget_v2's five outputs plus
+    mask_target (B, int(image_rois*fg_fraction), mask_size, mask_size): the 0/1 mask of each sampled
+    foreground RoI's gt polygon in the RoI's frame, -1 rows past the sampled foreground.
+    gt_polys (B,M,L): [category, n_seg, len_1..len_n, x,y,...] padded with -1."""
+    _chk(rois, "rois", ndim=3)
+    _chk(gt_boxes, "gt_boxes", ndim=3)
+    _chk(gt_polys, "gt_polys", ndim=3)
+    B, N, _ = rois.shape
+    M, L = gt_boxes.shape[1], gt_polys.shape[2]
+    if gt_polys.shape[:2] != gt_boxes.shape[:2] or B != int(batch_images):
+        raise ValueError("gt_polys must be (B,M,L) like gt_boxes (B,M,5), B = batch_images")
+    p = ProposalTargetParam()
+    p.num_classes, p.batch_images, p.image_rois = int(num_classes), int(batch_images), int(image_rois)
+    p.fg_fraction, p.fg_thresh = float(fg_fraction), float(fg_thresh)
+    p.bg_thresh_hi, p.bg_thresh_lo = float(bg_thresh_hi), float(bg_thresh_lo)
+    p.proposal_without_gt, p.class_agnostic = int(bool(proposal_without_gt)), int(bool(class_agnostic))
+    for i in range(4):
+        p.bbox_mean[i], p.bbox_std[i], p.bbox_weight[i] = bbox_mean[i], bbox_std[i], bbox_weight[i]
+    if rng_state is None:
+        rng_state = default_rng_state(rois.device)
+    _chk(rng_state, "rng_state", dtype=torch.int32, ndim=1)
+    if rng_state.numel() != 33:
+        raise ValueError("rng_state must hold 33 int32 words")
+    if valid_ranges is not None:
+        _chk(valid_ranges, "valid_ranges", ndim=2)
+    S, K4 = int(image_rois), 4 * int(num_classes)
+    FG = int(torch.tensor(S, dtype=torch.float32) * torch.tensor(fg_fraction, dtype=torch.float32))
+    dev = rois.device
+    ro = torch.empty((B, S, 4), device=dev, dtype=torch.float32)
+    lb = torch.empty((B, S), device=dev, dtype=torch.float32)
+    bt = torch.empty((B, S, K4), device=dev, dtype=torch.float32)
+    bw = torch.empty((B, S, K4), device=dev, dtype=torch.float32)
+    iou = torch.empty((B, S), device=dev, dtype=torch.float32)
+    mask = torch.empty((B, FG, int(mask_size), int(mask_size)), device=dev, dtype=torch.float32)
+    kept = torch.empty((B, S), device=dev, dtype=torch.int32) if return_index else None
+    wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    lib().call("sd_proposal_mask_target", _p(rois), _p(gt_boxes), _p(gt_polys), _p(valid_ranges),
+               int(bool(filter_scales)), N, M, L, int(mask_size), ctypes.byref(p), _p(rng_state), _p(ro),
+               _p(lb), _p(bt), _p(bw), _p(iou), _p(mask), _p(kept), _p(ws), ctypes.c_size_t(wsb), _stream())
+    res = (ro, lb, bt, bw, iou, mask)
+    return res + (kept,) if return_index else res
+
+
 # --------------------------------------------------------------------------------------------------
 # _contrib_NMS  (operator_cxx/contrib/nms{-inl.h,.cu}) and the Cython soft-NMS family
 # --------------------------------------------------------------------------------------------------

@@ -185,3 +185,36 @@ def rpn_outputs(seed, batch=2, num_anchors=3, height=50, width=84, stride=16, im
     if batch > 1:
         im_info[1] = [img_h - 64, img_w - 100, 1.5]
     return cls_prob, bbox_pred, im_info
+
+
+def gt_polys(seed, gt, max_len=400):
+    """gt_poly rows for ProposalMaskTarget (models/maskrcnn/input.py:100-127 layout): per gt box
+    [category, n_seg, len_1..len_n, x0, y0, x1, y1, ...] padded with -1.  Every valid gt box gets 1-3
+    closed polygons (jittered ellipses with 5-24 vertices, some concave) inside its box."""
+    rs = np.random.RandomState(seed)
+    B, M = gt.shape[:2]
+    out = np.full((B, M, max_len), -1.0, np.float32)
+    for b in range(B):
+        for m in range(M):
+            x1, y1, x2, y2, cls = gt[b, m]
+            if cls == -1:
+                continue
+            nseg = int(rs.choice([1, 1, 1, 2, 3]))
+            segs = []
+            for _ in range(nseg):
+                k = int(rs.randint(5, 25))
+                cx = rs.uniform(x1 + 0.3 * (x2 - x1), x2 - 0.3 * (x2 - x1))
+                cy = rs.uniform(y1 + 0.3 * (y2 - y1), y2 - 0.3 * (y2 - y1))
+                rx = rs.uniform(0.15, 0.5) * (x2 - x1)
+                ry = rs.uniform(0.15, 0.5) * (y2 - y1)
+                ang = np.sort(rs.uniform(0, 2 * np.pi, k))
+                rad = rs.uniform(0.5, 1.0, k)
+                px = np.clip(cx + rx * rad * np.cos(ang), x1, x2)
+                py = np.clip(cy + ry * rad * np.sin(ang), y1, y2)
+                segs.append(np.stack([px, py], 1).reshape(-1))
+            row = [float(cls), float(nseg)] + [float(len(sg)) for sg in segs]
+            for sg in segs:
+                row += [float(v) for v in sg]
+            assert len(row) <= max_len
+            out[b, m, :len(row)] = np.asarray(row, np.float32)
+    return out

@@ -263,6 +263,43 @@ def case_proposal_target_v2(i):
     return run
 
 
+PMT_CFGS = [dict(seed=8, B=2, N=1000, M=40, S=128), dict(seed=9, B=2, N=600, M=20, S=64, fg_fraction=0.5),
+            dict(seed=10, B=2, N=500, M=30, S=128, ranges=[[0, 120], [80, 500]])]
+PMT_NAMES = PT_NAMES + ("mask_target",)
+
+
+def case_proposal_mask_target(i):
+    """ProposalMaskTarget (Mask R-CNN / TridentNet): sampling + 28x28 masks of the gt polygons.  The
+    "ref" runner is the reference's proposal_mask_target.cc compiled against the RESTATED COCO mask
+    API (oracle/mask_api.c; the real one is not vendored): op logic pinned, rasterisation not."""
+    c = PMT_CFGS[i]
+
+    def run(runner):
+        kw = dict(num_classes=81, batch_images=c["B"], image_rois=c["S"], fg_fraction=c.get("fg_fraction", 0.25),
+                  fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0, proposal_without_gt=False)
+        rois, gt = synth.proposal_target_inputs(c["seed"], c["B"], c["N"], c["M"])
+        polys = synth.gt_polys(c["seed"], gt)
+        vr = np.array(c["ranges"], np.float32) if "ranges" in c else None
+        if runner == "ref":
+            from oracle import refmx
+            op = _ref("proposal_mask_target", "ProposalMaskTarget", num_args=4 if vr is not None else 3,
+                      mask_size=28, output_iou=True, filter_scales=vr is not None, **kw)
+            refmx.srand(1)
+            res = op.forward([rois, gt, polys] + ([vr] if vr is not None else []))
+        elif runner == "oracle":
+            orc = _orc()
+            p = orc.make_pt_param(81, c["B"], c["S"], kw["fg_fraction"], 0.5, 0.5, 0.0, False)
+            res = orc.proposal_mask_target(rois, gt, polys, p, 28, rng=orc.GlibcRand(1), valid_ranges=vr,
+                                           filter_scales=vr is not None)[:6]
+        else:
+            ops = _ops()
+            res = [_n(t) for t in ops.proposal_mask_target(
+                _t(rois), _t(gt), _t(polys), mask_size=28, rng_state=ops.glibc_rand_state(1),
+                valid_ranges=None if vr is None else _t(vr), filter_scales=vr is not None, **kw)]
+        return dict(zip(PMT_NAMES, res))
+    return run
+
+
 # ----------------------------------------------------------------------------------------- NMS --
 NMS_CFGS = [dict(seed=0, N=2000, pre=-1, post=1000, thr=0.7), dict(seed=2, N=1000, pre=600, post=300, thr=0.5),
             dict(seed=4, N=2500, pre=2000, post=2000, thr=0.7, mode="all_overlap")]
@@ -368,6 +405,8 @@ _add("proposal_target_0_agnostic", case_proposal_target(0, class_agnostic=True),
 _add("proposal_target_1_third_call", case_proposal_target(1, calls=3), hip_close=_PT_CLOSE)
 for _i in range(len(PT2_CFGS)):
     _add("proposal_target_v2_%d" % _i, case_proposal_target_v2(_i), hip_close=_PT_CLOSE)
+for _i in range(len(PMT_CFGS)):
+    _add("proposal_mask_target_%d" % _i, case_proposal_mask_target(_i), hip_close=_PT_CLOSE)
 for _i in range(len(NMS_CFGS)):
     _add("nms_%d" % _i, case_nms(_i))
 for _i in range(len(PV3_CFGS)):

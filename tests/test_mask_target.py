@@ -1,0 +1,105 @@
+"""ProposalMaskTarget's polygon rasteriser (convertPoly2Mask over the COCO mask API).
+
+The COCO mask API is a third-party library the reference does not vendor (github.com/RogerChern/
+cocoapi, doc/INSTALL.md:90-93), so no output of the real library exists here: PARITY UNPINNED.
+oracle/mask_api.c restates the published pycocotools algorithm; these tests pin it by properties
+that do not depend on the restatement, and the GPU tests compare the HIP rasteriser with the oracle
+bit for bit on many polygons (the op-level cases are in tests/refcases.py)."""
+import numpy as np
+import pytest
+
+from simpledet_amd import synth
+
+
+def _poly_row(segs, L=200, cls=3):
+    row = [float(cls), float(len(segs))] + [float(len(s)) for s in segs]
+    for s in segs:
+        row += [float(v) for v in s]
+    out = np.full(L, -1.0, np.float32)
+    out[:len(row)] = row
+    return out
+
+
+def test_axis_aligned_rectangle_fills_its_pixels(oracle):
+    # RoI (0,0,28,28): w = h = 28 -> one mask pixel per image pixel.  Rectangle [4.5, 20.5) x [6.5, 10.5)
+    roi = np.array([0, 0, 28, 28], np.float32)
+    rect = [4.5, 6.5, 20.5, 6.5, 20.5, 10.5, 4.5, 10.5]  # x,y pairs
+    m = oracle.poly2mask(roi, _poly_row([rect]), 28)
+    want = np.zeros((28, 28), np.float32)
+    want[7:11, 5:21] = 1  # pixel centres inside: rows 7..10, cols 5..20
+    np.testing.assert_array_equal(m, want)
+    # two disjoint rectangles are OR-ed; the same rectangle twice is still itself
+    rect2 = [22.5, 20.5, 26.5, 20.5, 26.5, 25.5, 22.5, 25.5]
+    m2 = oracle.poly2mask(roi, _poly_row([rect, rect2]), 28)
+    want[21:26, 23:27] = 1
+    np.testing.assert_array_equal(m2, want)
+    np.testing.assert_array_equal(oracle.poly2mask(roi, _poly_row([rect, rect]), 28), m)
+
+
+def test_mask_follows_the_roi_frame(oracle):
+    # the same shape in a RoI twice as large occupies a quarter of the mask
+    sq = [10, 10, 38, 10, 38, 38, 10, 38]
+    a = oracle.poly2mask(np.array([10, 10, 38, 38], np.float32), _poly_row([sq]), 28)
+    assert a.mean() > 0.9
+    b = oracle.poly2mask(np.array([10, 10, 66, 66], np.float32), _poly_row([sq]), 28)
+    assert abs(b.mean() - 0.25) < 0.05 and b[:13, :13].mean() > 0.9 and b[15:, 15:].sum() == 0
+    # a polygon entirely outside the RoI leaves the mask empty
+    c = oracle.poly2mask(np.array([100, 100, 128, 128], np.float32), _poly_row([sq]), 28)
+    assert c.sum() == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_area_and_mirror_symmetry(oracle, seed):
+    rs = np.random.RandomState(seed)
+    k = rs.randint(5, 20)
+    ang = np.sort(rs.uniform(0, 2 * np.pi, k))
+    px, py = 14 + 10 * np.cos(ang), 14 + 9 * np.sin(ang)  # convex, inside a (0,0,28,28) RoI
+    roi = np.array([0, 0, 28, 28], np.float32)
+    m = oracle.poly2mask(roi, _poly_row([np.stack([px, py], 1).reshape(-1)]), 28)
+    area = 0.5 * abs(np.dot(px, np.roll(py, -1)) - np.dot(py, np.roll(px, -1)))
+    per = np.hypot(np.diff(np.r_[px, px[0]]), np.diff(np.r_[py, py[0]])).sum()
+    assert abs(m.sum() - area) <= 0.75 * per          # pixelisation error is bounded by the boundary
+    assert set(np.unique(m)) <= {0.0, 1.0}
+    # every row of a convex shape is one run
+    for r in m:
+        idx = np.flatnonzero(r)
+        assert len(idx) == 0 or idx[-1] - idx[0] + 1 == len(idx)
+
+
+# ------------------------------------------------------------------------------------------ GPU --
+@pytest.mark.gpu
+def test_hip_rasteriser_equals_oracle_on_many_polygons(ops, oracle):
+    """One RoI per gt box (the box itself, jittered), fg_fraction 1: every row is rasterised."""
+    import torch
+    B, M = 2, 48
+    gt = synth.gt_boxes(21, B, M, min_n=M)
+    polys = synth.gt_polys(21, gt, max_len=400)
+    rs = np.random.RandomState(3)
+    rois = gt[:, :, :4] + rs.uniform(-3, 3, (B, M, 4)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = ops.proposal_mask_target(t(rois), t(gt), t(polys), 81, B, 64, mask_size=28, fg_fraction=1.0,
+                                   proposal_without_gt=True, rng_state=ops.glibc_rand_state(1),
+                                   return_index=True)
+    p = oracle.make_pt_param(81, B, 64, fg_fraction=1.0, proposal_without_gt=True)
+    want = oracle.proposal_mask_target(rois, gt, polys, p, 28, rng=oracle.GlibcRand(1))
+    np.testing.assert_array_equal(got[6].cpu().numpy(), want[6])
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+    np.testing.assert_array_equal(got[5].cpu().numpy(), want[5])
+    m = got[5].cpu().numpy()
+    assert (m == 1).any() and (m == -1).any()  # 48 < 64 rows: the tail keeps the -1 fill
+    # mask sizes other than 28, long many-vertex polygons
+    big = np.full((B, M, 3000), -1.0, np.float32)
+    for b in range(B):
+        for j in range(M):
+            k = 700
+            ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+            x1, y1, x2, y2 = gt[b, j, :4]
+            px = (x1 + x2) / 2 + (x2 - x1) * 0.45 * np.cos(ang) * (1 + 0.2 * np.sin(7 * ang))
+            py = (y1 + y2) / 2 + (y2 - y1) * 0.45 * np.sin(ang) * (1 + 0.2 * np.cos(5 * ang))
+            row = [gt[b, j, 4], 1.0, 2.0 * k] + list(np.stack([px, py], 1).reshape(-1))
+            big[b, j, :len(row)] = row
+    for ms in (14, 56):
+        got = ops.proposal_mask_target(t(rois), t(gt), t(big), 81, B, 64, mask_size=ms, fg_fraction=1.0,
+                                       proposal_without_gt=True, rng_state=ops.glibc_rand_state(1))
+        want = oracle.proposal_mask_target(rois, gt, big, p, ms, rng=oracle.GlibcRand(1))
+        np.testing.assert_array_equal(got[5].cpu().numpy(), want[5])

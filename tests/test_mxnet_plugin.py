@@ -21,7 +21,7 @@ def test_registers_reference_operator_names(plugin):
     assert set(props) == {"_contrib_ROIAlign_v2", "ROIPooling_v1", "ProposalTarget",
                           "_contrib_GenAnchor", "_contrib_NMS", "assign_layer_fpn",
                           "_contrib_DeformableConvolution", "fpn_roi_align", "_contrib_Proposal_v3",
-                          "get_top_proposal", "_contrib_DecodeBBox", "ProposalTarget_v2"}
+                          "get_top_proposal", "_contrib_DecodeBBox", "ProposalTarget_v2", "ProposalMaskTarget"}
     for name in props:
         assert "sd_" + name in mx.registry
     # aliases on the symbol namespaces the reference graph uses

@@ -30,7 +30,7 @@ NAMES = sorted(refcases.CASES)
 
 def _have_ref():
     from oracle import refmx
-    return all(refmx.available(l) for l in ("roi_align_v2", "roi_pooling_v1", "proposal_target", "proposal_target_v2",
+    return all(refmx.available(l) for l in ("roi_align_v2", "roi_pooling_v1", "proposal_target", "proposal_target_v2", "proposal_mask_target",
                                             "generate_anchor", "nms", "proposal_v3", "decodebbox"))
 
 
@@ -161,6 +161,10 @@ IFACE = [
     ("proposal_target_v2", "ProposalTarget_v2",
      dict(num_classes=81, batch_images=2, image_rois=128, fg_fraction=0.25, fg_thresh=0.5, bg_thresh_hi=0.5,
           bg_thresh_lo=0.0, proposal_without_gt=False, filter_scales=True), [(2, 2000, 4), (2, 100, 5), (2, 2)]),
+    ("proposal_mask_target", "ProposalMaskTarget",
+     dict(num_args=3, num_classes=81, batch_images=2, image_rois=512, mask_size=28, fg_fraction=0.25,
+          fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0, proposal_without_gt=False, output_iou=True),
+     [(2, 2000, 4), (2, 100, 5), (2, 100, 2500)]),
     ("generate_anchor", "_contrib_GenAnchor", dict(scales=(8,), ratios=(0.5, 1, 2), feature_stride=4),
      [(2, 6, 200, 334)]),
     ("nms", "_contrib_NMS", dict(rpn_pre_nms_top_n=-1, rpn_post_nms_top_n=1000, threshold=0.7),
