@@ -72,7 +72,7 @@ def test_hip_rasteriser_equals_oracle_on_many_polygons(ops, oracle):
     """One RoI per gt box (the box itself, jittered), fg_fraction 1: every row is rasterised."""
     import torch
     B, M = 2, 48
-    gt = synth.gt_boxes(21, B, M, min_n=M)
+    gt = synth.gt_boxes(21, B, M, min_n=M, max_n=M)
     polys = synth.gt_polys(21, gt, max_len=400)
     rs = np.random.RandomState(3)
     rois = gt[:, :, :4] + rs.uniform(-3, 3, (B, M, 4)).astype(np.float32)
