@@ -2,7 +2,7 @@
 # A/B of kernel variants on one GPU box (scratch helper): each argument is a bench.py flag string
 # ablation knobs live in the profiling build only (make -C simpledet_amd/csrc prof)
 [ -f tools/libsimpledet_ops_hip_prof.so ] && export SIMPLEDET_AMD_LIB=$PWD/tools/libsimpledet_ops_hip_prof.so
-run() { echo "== $*"; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops $* 2>/dev/null | python -c "
+run() { echo "== $*"; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops $* 2>/tmp/ab_err.log | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
