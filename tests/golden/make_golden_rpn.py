@@ -71,13 +71,23 @@ def main():
             res.append(op.apply(rec))
         state = np.random.get_state()
         for i, (lab, tgt, wgt) in enumerate(res):
-            out["%s/%d/label" % (name, i)] = np.asarray(lab, np.float32)
-            out["%s/%d/target" % (name, i)] = np.asarray(tgt, np.float32)
-            out["%s/%d/weight" % (name, i)] = np.asarray(wgt, np.float32)
+            # compact storage: labels are -1/0/1 (int8); targets / weights are zero except at the
+            # (<= image_anchor) foreground anchors: flat indices of weight != 0 + the values there
+            lab, tgt, wgt = np.asarray(lab, np.float32), np.asarray(tgt, np.float32), np.asarray(wgt, np.float32)
+            assert set(np.unique(lab)) <= {-1.0, 0.0, 1.0} and set(np.unique(wgt)) <= {0.0, 1.0}
+            nz = np.flatnonzero(wgt.reshape(-1))
+            assert not np.any(tgt.reshape(-1)[np.setdiff1d(np.arange(tgt.size), nz)])
+            out["%s/%d/label" % (name, i)] = lab.astype(np.int8)
+            out["%s/%d/shape" % (name, i)] = np.array(tgt.shape, np.int64)
+            out["%s/%d/nz" % (name, i)] = nz.astype(np.int64)
+            out["%s/%d/target_nz" % (name, i)] = tgt.reshape(-1)[nz]
         out["%s/mt_key" % name] = state[1].astype(np.uint32)
         out["%s/mt_pos" % name] = np.array([state[2]], np.int32)
-        anchors = op.h_all_anchor if not pyramid else op.h_all_anchor
-        out["%s/h_all_anchor" % name] = np.asarray(anchors, np.float64)
+        import hashlib
+        for orient in ("h", "v"):
+            a = np.ascontiguousarray(getattr(op, orient + "_all_anchor"), np.float64)
+            out["%s/%s_all_anchor_sha256" % (name, orient)] = np.frombuffer(
+                hashlib.sha256(a.tobytes()).digest(), np.uint8)
         nfg = [int((r[0] == 1).sum()) for r in res]
         nbg = [int((r[0] == 0).sum()) for r in res]
         print("%-24s images %d  fg %s  bg %s  label %s target %s" % (name, len(res), nfg, nbg, res[0][0].shape,
