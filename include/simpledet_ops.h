@@ -255,6 +255,41 @@ int sd_bbox_overlaps(const float* boxes, int n, const float* query_boxes, int k,
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * RPN anchor-target assignment -- SURVEY 8(f) rank 3.  The reference computes it on the host in its
+ * data loader:
+ *   replaces AnchorTarget2D.apply  core/detection_input.py:535-565 (anchors :373-437, label
+ *            assignment :450-482, random subsampling :484-499, box encoding :501-510, valid-anchor
+ *            gather / scatter :512-533) and PyramidAnchorTarget2D.apply  models/FPN/input.py:101-146,
+ *            IoU operator_py/cython/bbox.pyx:31-72, encoding operator_py/bbox_transform.py:52-77
+ *   im_info (B,3) DEVICE [h, w, scale]; gt_bbox (B,M,G) DEVICE, G = 4 or 5, rows with x1 == -1 padding
+ *   mt_state: DEVICE int32[625] = numpy RandomState MT19937 key[624] + position, the generator
+ *            np.random.choice draws from; advanced in place exactly as numpy advances it, images in
+ *            order.  sd_mt19937_seed_host(seed, ...) fills the state np.random.seed(seed) produces.
+ *   layout 0: cls_label (B,N), reg_target / reg_weight (B,N,4) in all-anchor order (level, y, x, a);
+ *   layout 1: the loader's final arrays: cls_label (B, A * sumHW), reg_target / reg_weight
+ *            (B, 4A, sumHW), levels concatenated along the last axis (one level: (4A, fh, fw)).
+ *   An image with h >= w uses the (long, short) feature sizes, otherwise (short, long).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int nlvl;
+  int stride[SD_MAX_FPN_LEVELS], short_side[SD_MAX_FPN_LEVELS], long_side[SD_MAX_FPN_LEVELS];
+  int n_scales, n_aspects;
+  double scales[16], aspects[16]; /* n_scales * n_aspects <= 16 */
+  int allowed_border;
+  float pos_thr, neg_thr, min_pos_thr;
+  int image_anchor;
+  double pos_fraction;
+} sd_rpn_target_param;
+#define SD_MT19937_STATE_WORDS 625
+int sd_mt19937_seed_host(uint32_t seed, int32_t* state_host);
+int sd_rpn_target_num_anchors(const sd_rpn_target_param* param_host);
+size_t sd_rpn_target_workspace_bytes(const sd_rpn_target_param* param_host, int B, int M);
+int sd_rpn_anchor_target(const float* im_info, const float* gt_bbox, int B, int M, int G,
+                         const sd_rpn_target_param* param_host, int32_t* mt_state,
+                         float* cls_label, float* reg_target, float* reg_weight, int layout,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * DeformableConvolution v1  (mx.sym.contrib.DeformableConvolution; call site models/dcn/
  *   builder.py:14-17).  The arithmetic is upstream MXNet 1.6.0 (un-vendored third party,
  *   src/operator/contrib/nn/deformable_im2col.cuh + deformable_convolution-inl.h): each entry point

@@ -455,6 +455,88 @@ def proposal_mask_target(rois, gt_boxes, gt_polys, num_classes, batch_images, im
 
 
 # --------------------------------------------------------------------------------------------------
+# RPN anchor-target assignment (core/detection_input.py:345-565, models/FPN/input.py:9-146)
+# --------------------------------------------------------------------------------------------------
+class RpnTargetParam(ctypes.Structure):
+    """sd_rpn_target_param"""
+    _fields_ = [("nlvl", ctypes.c_int), ("stride", ctypes.c_int * 8), ("short_side", ctypes.c_int * 8),
+                ("long_side", ctypes.c_int * 8), ("n_scales", ctypes.c_int), ("n_aspects", ctypes.c_int),
+                ("scales", ctypes.c_double * 16), ("aspects", ctypes.c_double * 16),
+                ("allowed_border", ctypes.c_int), ("pos_thr", ctypes.c_float), ("neg_thr", ctypes.c_float),
+                ("min_pos_thr", ctypes.c_float), ("image_anchor", ctypes.c_int),
+                ("pos_fraction", ctypes.c_double)]
+
+
+def _seq(v):
+    return list(v) if isinstance(v, (tuple, list)) else [v]
+
+
+def rpn_target_param(stride, short, long, scales, aspects, allowed_border=0, pos_thr=0.7, neg_thr=0.3,
+                     min_pos_thr=0.0, image_anchor=256, pos_fraction=0.5):
+    """the AnchorTarget2DParam of a config (config/faster_r50v1_fpn_1x.py:212-232) as the C struct"""
+    p = RpnTargetParam()
+    st, sh, lg, sc, asp = _seq(stride), _seq(short), _seq(long), _seq(scales), _seq(aspects)
+    if not (len(st) == len(sh) == len(lg)) or len(st) > 8 or len(sc) * len(asp) > 16:
+        raise ValueError("bad pyramid / anchor description")
+    p.nlvl, p.n_scales, p.n_aspects = len(st), len(sc), len(asp)
+    for i in range(len(st)):
+        p.stride[i], p.short_side[i], p.long_side[i] = int(st[i]), int(sh[i]), int(lg[i])
+    for i, v in enumerate(sc):
+        p.scales[i] = float(v)
+    for i, v in enumerate(asp):
+        p.aspects[i] = float(v)
+    p.allowed_border = int(allowed_border)
+    p.pos_thr, p.neg_thr, p.min_pos_thr = float(pos_thr), float(neg_thr), float(min_pos_thr)
+    p.image_anchor, p.pos_fraction = int(image_anchor), float(pos_fraction)
+    return p
+
+
+def mt19937_state(seed=None, numpy_state=None, device=None):
+    """Device copy (int32[625]) of a numpy RandomState: np.random.seed(seed), or an explicit
+    RandomState.get_state() tuple."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    host = (ctypes.c_int32 * 625)()
+    if numpy_state is not None:
+        key, pos = numpy_state[1], int(numpy_state[2])
+        vals = [int(k) - (1 << 32) if int(k) >= (1 << 31) else int(k) for k in key] + [pos]
+        return torch.tensor(vals, dtype=torch.int32, device=device)
+    lib().call("sd_mt19937_seed_host", ctypes.c_uint32(int(seed)), host)
+    return torch.tensor(list(host), dtype=torch.int32, device=device)
+
+
+def rpn_anchor_target(im_info, gt_bbox, param, mt_state, layout=1):
+    """RPN labels / box targets / weights for a batch of images, the reference loader's
+    (Pyramid)AnchorTarget2D on the device.  im_info (B,3), gt_bbox (B,M,4|5) padded with -1 rows.
+    layout 1: cls_label (B, A*sumHW), reg_target / reg_weight (B, 4A, sumHW); layout 0: (B,N), (B,N,4).
+    mt_state: mt19937_state(...), advanced in place like np.random."""
+    _chk(im_info, "im_info", ndim=2)
+    _chk(gt_bbox, "gt_bbox", ndim=3)
+    _chk(mt_state, "mt_state", dtype=torch.int32, ndim=1)
+    if mt_state.numel() != 625:
+        raise ValueError("mt_state must hold 625 int32 words")
+    B, M, G = gt_bbox.shape
+    N = int(lib().cdll.sd_rpn_target_num_anchors(ctypes.byref(param)))
+    if N < 0:
+        raise ValueError("bad rpn target parameters")
+    A = param.n_scales * param.n_aspects
+    dev = im_info.device
+    if layout == 1:
+        cls = torch.empty((B, N), device=dev, dtype=torch.float32)
+        tgt = torch.empty((B, 4 * A, N // A), device=dev, dtype=torch.float32)
+        wgt = torch.empty_like(tgt)
+    else:
+        cls = torch.empty((B, N), device=dev, dtype=torch.float32)
+        tgt = torch.empty((B, N, 4), device=dev, dtype=torch.float32)
+        wgt = torch.empty_like(tgt)
+    lib().cdll.sd_rpn_target_workspace_bytes.restype = ctypes.c_size_t
+    wsb = lib().cdll.sd_rpn_target_workspace_bytes(ctypes.byref(param), B, M)
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    lib().call("sd_rpn_anchor_target", _p(im_info), _p(gt_bbox), B, M, G, ctypes.byref(param), _p(mt_state),
+               _p(cls), _p(tgt), _p(wgt), int(layout), _p(ws), ctypes.c_size_t(wsb), _stream())
+    return cls, tgt, wgt
+
+
+# --------------------------------------------------------------------------------------------------
 # _contrib_NMS  (operator_cxx/contrib/nms{-inl.h,.cu}) and the Cython soft-NMS family
 # --------------------------------------------------------------------------------------------------
 def nms(dets, rpn_pre_nms_top_n=6000, rpn_post_nms_top_n=300, threshold=0.7, already_sorted=False,

@@ -78,3 +78,54 @@ def test_zero_overlap_gt_quirk_is_in_the_fixture():
     background is left."""
     lab, _, _ = _dense("fpn_zero_overlap_gt", 0)
     assert (lab == 1).sum() == 128 and (lab == 0).sum() == 0
+
+
+# ------------------------------------------------------------------------------------------ GPU --
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(rpncases.CASES))
+def test_hip_reproduces_reference(ops, name):
+    """labels, box targets, weights AND the MT19937 state after the calls, bit for bit against what
+    the reference's own classes produced (images of a case go through one generator state)."""
+    import torch
+    case = rpncases.CASES[name]
+    cfg = case["cfg"]
+    p = ops.rpn_target_param(cfg["stride"], cfg["short"], cfg["long"], cfg["scales"], cfg["aspects"],
+                             cfg["allowed_border"], cfg["pos_thr"], cfg["neg_thr"], cfg["min_pos_thr"],
+                             cfg["image_anchor"], cfg["pos_fraction"])
+    state = ops.mt19937_state(seed=case["seed"])
+    ref_state = np.random.RandomState(case["seed"]).get_state()
+    np.testing.assert_array_equal(state.cpu().numpy()[:624].astype(np.uint32), ref_state[1])
+    ins = rpncases.inputs(case)
+    for i, (im_info, gt) in enumerate(ins):  # one image per call: orientations may differ
+        cls, tgt, wgt = ops.rpn_anchor_target(torch.from_numpy(im_info[None]).cuda(),
+                                              torch.from_numpy(gt[None]).cuda(), p, state, layout=1)
+        wl, wt, ww = _dense(name, i)
+        np.testing.assert_array_equal(cls[0].cpu().numpy(), wl)
+        np.testing.assert_array_equal(wgt[0].cpu().numpy().reshape(ww.shape), ww)
+        np.testing.assert_array_equal(tgt[0].cpu().numpy().reshape(wt.shape), wt)
+    st = state.cpu().numpy()
+    np.testing.assert_array_equal(st[:624].astype(np.uint32), GOLD[name + "/mt_key"])
+    assert int(st[624]) == int(GOLD[name + "/mt_pos"][0])
+
+
+@pytest.mark.gpu
+def test_hip_batch_equals_image_by_image_and_flat_layout(ops):
+    """B = 2 in one call == two calls (the state carries), and layout 0 is the flat all-anchor order
+    of PyramidAnchorTarget2DBase."""
+    import torch
+    from oracle import rpn_target as orc
+    case = rpncases.CASES["fpn_landscape"]
+    cfg = case["cfg"]
+    p = ops.rpn_target_param(cfg["stride"], cfg["short"], cfg["long"], cfg["scales"], cfg["aspects"])
+    ins = rpncases.inputs(case)
+    im = torch.from_numpy(np.stack([x[0] for x in ins])).cuda()
+    gt = torch.from_numpy(np.stack([x[1] for x in ins])).cuda()
+    state = ops.mt19937_state(seed=case["seed"])
+    cls, tgt, wgt = ops.rpn_anchor_target(im, gt, p, state, layout=0)
+    rs = np.random.RandomState(case["seed"])
+    for i, (im_info, g) in enumerate(ins):
+        c, t, w, _ = orc.rpn_target_flat(im_info, g, cfg, rs)
+        np.testing.assert_array_equal(cls[i].cpu().numpy(), c)
+        np.testing.assert_array_equal(tgt[i].cpu().numpy(), t)
+        np.testing.assert_array_equal(wgt[i].cpu().numpy(), w)
+    assert int(state[624]) == rs.get_state()[2]
