@@ -76,6 +76,41 @@ def run(seed=0, cpu=True, only=None):
             rng = orc.GlibcRand(1)
             res["proposal_target"]["cpu_ms"] = _time_cpu(lambda: orc.proposal_target(rois, gt, p, rng=rng))
 
+    # ---- ProposalMaskTarget: the same sampling + 128 fg RoIs/img rasterised to 28x28 (mask head) ----
+    if want("proposal_mask_target"):
+        rois, gt = synth.proposal_target_inputs(seed, 2, 2000, 100)
+        polys = synth.gt_polys(seed, gt, max_len=2500)
+        tr, tg, tp = T(rois), T(gt), T(polys)
+        state = ops.glibc_rand_state(1)
+        ms = _time_gpu(lambda: ops.proposal_mask_target(tr, tg, tp, 81, 2, 512, mask_size=28, rng_state=state))
+        res["proposal_mask_target"] = {"ms": ms, "images_per_s": 2 / ms * 1e3,
+                                       "config": "B=2, 2000 proposals, 512 RoIs (128 fg masks 28x28) per image"}
+        if orc:
+            p = orc.make_pt_param(81, 2, 512)
+            rng = orc.GlibcRand(1)
+            res["proposal_mask_target"]["cpu_ms"] = _time_cpu(
+                lambda: orc.proposal_mask_target(rois, gt, polys, p, 28, rng=rng))
+
+    # ---- RPN anchor targets: P2-P6, 267k anchors/img, <= 40 gt, 256 sampled (loader op in the reference) ----
+    if want("rpn_anchor_target"):
+        gtb = synth.gt_boxes(seed, 2, 100)
+        im = np.array([[800, 1333, 1.0], [800, 1333, 1.0]], np.float32)
+        cfg = dict(stride=(4, 8, 16, 32, 64), short=(200, 100, 50, 25, 13), long=(334, 167, 84, 42, 21),
+                   scales=(8,), aspects=(0.5, 1.0, 2.0))
+        prm = ops.rpn_target_param(**cfg)
+        st = ops.mt19937_state(seed=0)
+        ti, tg = T(im), T(gtb)
+        ms = _time_gpu(lambda: ops.rpn_anchor_target(ti, tg, prm, st, layout=1))
+        res["rpn_anchor_target"] = {"ms": ms, "images_per_s": 2 / ms * 1e3,
+                                    "config": "B=2, P2-P6 267,069 anchors/img, 256 sampled, numpy MT19937 replay"}
+        if cpu:
+            from oracle import rpn_target as orpn
+            c2 = dict(cfg, allowed_border=0, pos_thr=0.7, neg_thr=0.3, min_pos_thr=0.0, image_anchor=256,
+                      pos_fraction=0.5)
+            rs = np.random.RandomState(0)
+            res["rpn_anchor_target"]["cpu_ms"] = _time_cpu(
+                lambda: [orpn.rpn_target(im[i], gtb[i], c2, rs) for i in range(2)], max_iter=5)
+
     # ---- _contrib_NMS: B=2 x 2000 boxes, thr 0.7, post 1000 (train proposals) ----
     if want("nms"):
         dets = np.stack([synth.nms_dets(seed + i, 2000) for i in range(2)])
