@@ -571,6 +571,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
       for (int u = 0; u < CHUNK; ++u) {
         const int it = chunk * CHUNK + u;
         if (it < ITER) {
+          if (SD_ABLATE(a, 2) && it >= 2) continue;  // profiling build: 2 of the ITER tap loads only
           const F2u v = *reinterpret_cast<const F2u*>(pl + (CACHE_GOFF ? voff[it] : calc_voff(it)));
           nxt[d][u] = make_float2(v.x, v.y);
         }
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
                 if (a.L.nlvl > 1) maxval = maxval + 0.0f;
                 po[bin + d * NWAVE * PP] = maxval;
                 if (PK) {
-                  pk[bin + d * NWAVE * PPS] = (unsigned char)(bk < 0 ? 255 : bk);
+                  if (!(SD_ABLATE(a, 4))) pk[bin + d * NWAVE * PPS] = (unsigned char)(bk < 0 ? 255 : bk);
                 } else {
                   px[bin + d * NWAVE * PP] = bx;
                   py[bin + d * NWAVE * PP] = by;
@@ -664,6 +665,330 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     };
     if (any_dup) channel_loop(std::true_type{});
     else channel_loop(std::false_type{});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense-window forward (7x7)
+// ------------------------------------------------------------------------------------------------
+// The tiled kernel above fetches every (left,right) tap pair of a RoI with its own 8-byte gather:
+// 7 wave-level loads per (RoI, channel), 822 MB of taps per launch, and the address unit spends
+// ~16 clocks per wave instruction whatever its width -- that gather rate (64 us even when every
+// tap hits L2, profiles/r01_gather_microbench.txt), not HBM, bounds it.  Here a wave fetches the
+// RoI's WINDOW of the channel plane instead -- the rows r0..r1 and columns c0..c1 its samples
+// touch, 16 bytes per lane, contiguous runs per row -- 1-3 loads per (RoI, channel) at the
+// baseline, into a private LDS window with an odd-multiple-of-4 pitch; the 49 bin lanes then read
+// their taps straight out of the window (two ds_read2_b32 per sample) with addresses they keep in
+// registers.  Same arithmetic, same evaluation order, bit-identical results.
+// A RoI whose window does not fit (more than DENSE_MAXIT loads or DENSE_CAPF floats: extreme
+// aspect ratios) takes the exact per-element path.
+constexpr int DENSE_MAXIT = 5;     // 16-byte loads per lane and channel
+constexpr int DENSE_CAPF = 1280;   // floats of one wave's window
+
+template <int PH, int PW, int NROI>
+struct DenseSmem {
+  static constexpr int NWAVE = 8;
+  __attribute__((aligned(16))) float stage[NWAVE * (DENSE_CAPF + 4)];
+  struct Roi {
+    int rowidx[4 * PH];      // [p*4 + 2k + {lo,hi}] row index, -1 unused
+    int colidx[4 * PW];
+    float hval[2 * PH], alpha[2 * PH];
+    float wval[2 * PW], beta[2 * PW];
+    int hcnt[PH], wcnt[PW];
+    int lvl, n, fb_row, fb_col, fb_win, any_valid;
+    int r0, nr, c0a, nlr, pitch, nit;
+    float box[4];
+  } roi[NROI];
+};
+
+template <int PH, int PW, int NROI, bool PK>
+__global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
+  using S = DenseSmem<PH, PW, NROI>;
+  constexpr int PP = PH * PW, NWAVE = S::NWAVE, THREADS = NWAVE * kWave, PPS = amax_stride(PP);
+  static_assert(PP <= kWave, "one bin per lane");
+  static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
+  __shared__ S s;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int nslice = a.nslice;
+  const int grp = blockIdx.x / nslice, slice = blockIdx.x % nslice;
+  const int nroi_total = a.B * a.R;
+  const int nch = a.C / nslice;
+  const int cbeg = slice * nch;
+
+  // ---- per-RoI sample tables: wave 2i rows, wave 2i+1 columns of RoI i ----
+  if (wave < 2 * NROI) {
+    const int i = wave >> 1, slot = grp * NROI + i;
+    typename S::Roi& t = s.roi[i];
+    int lvl = -2, cnt = 0, n = 0;
+    if (slot < nroi_total) {
+      n = a.order ? a.order[slot] : slot;
+      const float* r = a.rois + (long)n * 4;
+      const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+      lvl = 0;
+      if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
+      if (lvl >= 0) {
+        const int H = a.L.H[lvl], W = a.L.W[lvl];
+        const float scale = a.L.scale[lvl];
+        if ((wave & 1) == 0 && lane < PH) {
+          cnt = axis_samples(lane, PH, y1, y2, scale, H, 1, &t.hval[2 * lane], &t.alpha[2 * lane],
+                             &t.rowidx[4 * lane]);
+          t.hcnt[lane] = cnt;
+        } else if ((wave & 1) == 1 && lane < PW) {
+          cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
+                             &t.colidx[4 * lane]);
+          t.wcnt[lane] = cnt;
+        }
+      }
+      if ((wave & 1) == 0 && lane == 0) {
+        t.box[0] = x1; t.box[1] = y1; t.box[2] = x2; t.box[3] = y2;
+      }
+    }
+    const int fb = __any(cnt >= 3);
+    if (lane == 0) {
+      if (wave & 1) t.fb_col = fb;
+      else { t.fb_row = fb; t.lvl = lvl; t.n = n; }
+    }
+  }
+  __syncthreads();
+  // ---- window of every RoI (one lane each) ----
+  if (tid < NROI) {
+    typename S::Roi& t = s.roi[tid];
+    t.any_valid = 0;
+    t.fb_win = 0;
+    if (t.lvl >= 0 && !t.fb_row && !t.fb_col) {
+      int r0 = 1 << 30, r1 = -1, c0 = 1 << 30, c1 = -1;
+      bool vr = false, vc = false;
+      for (int e = 0; e < 4 * PH; ++e) {
+        const int v = t.rowidx[e];
+        if (v >= 0 && (e & 3) / 2 < t.hcnt[e >> 2]) { r0 = v < r0 ? v : r0; r1 = v > r1 ? v : r1; vr = true; }
+      }
+      for (int e = 0; e < 4 * PW; ++e) {
+        const int v = t.colidx[e];
+        if (v >= 0 && (e & 3) / 2 < t.wcnt[e >> 2]) { c0 = v < c0 ? v : c0; c1 = v > c1 ? v : c1; vc = true; }
+      }
+      if (vr && vc) {
+        t.any_valid = 1;
+        const int c0a = c0 & ~3;
+        const int nlr = (c1 - c0a) / 4 + 1;
+        const int pitch = 4 * (nlr | 1);  // odd multiple of 4 floats: rows 1..7 apart never share a bank
+        const int nr = r1 - r0 + 1;
+        t.r0 = r0; t.nr = nr; t.c0a = c0a; t.nlr = nlr; t.pitch = pitch;
+        t.nit = (nr * nlr + kWave - 1) / kWave;
+        if (t.nit > DENSE_MAXIT || nr * pitch > DENSE_CAPF || a.L.W[t.lvl] < 4) t.fb_win = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (PK && slice == 0) {  // the sample coordinates the packed arg-max indexes, once per RoI
+    for (int e = tid; e < NROI * 3 * (PH + PW); e += THREADS) {
+      const int i = e / (3 * (PH + PW)), j = e % (3 * (PH + PW));
+      const typename S::Roi& t = s.roi[i];
+      if (t.lvl < 0) continue;
+      const bool row = j < 3 * PH;
+      const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
+      float v;
+      if (k < 2 && !(t.fb_row | t.fb_col)) {
+        v = row ? t.hval[2 * p + k] : t.wval[2 * p + k];
+        // a sample the loop never reached has no coordinate in the table: recompute like the tiled kernel
+        const int cnt = row ? t.hcnt[p] : t.wcnt[p];
+        if (k >= cnt) {
+          const int lv = t.lvl;
+          v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
+                  : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
+        }
+      } else {
+        const int lv = t.lvl;
+        v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
+                : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
+      }
+      float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
+      base[j] = v;
+      store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
+    }
+  }
+
+  // rare RoIs first (assigned to no level, 3-iteration sample loop, oversized window): exact path
+#pragma unroll 1
+  for (int i = 0; i < NROI; ++i) {
+    const typename S::Roi& t = s.roi[i];
+    const int n = t.n, lvl = t.lvl;
+    if (lvl == -2) break;
+    const long obase = ((long)n * a.C + cbeg) * PP;
+    const long abase = ((long)n * a.C + cbeg) * PPS;
+    if (lvl < 0 || (!t.any_valid && !(t.fb_row || t.fb_col))) {
+      for (int e = tid; e < nch * PP; e += THREADS) {
+        a.out[obase + e] = 0.f;
+        if (PK) {
+          a.amax8[abase + (e / PP) * PPS + e % PP] = 255;
+        } else {
+          a.ax[obase + e] = -1.f;
+          a.ay[obase + e] = -1.f;
+        }
+      }
+    } else if (t.fb_row || t.fb_col || t.fb_win) {
+      const int H = a.L.H[lvl], W = a.L.W[lvl];
+      const long plane = (long)H * W;
+      const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
+      const float scale = a.L.scale[lvl];
+      for (int e = tid; e < nch * PP; e += THREADS) {
+        const int c = e / PP, bin = e % PP;
+        FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, t.box[0], t.box[1], t.box[2],
+                                      t.box[3], scale, bin / PW, bin % PW, PH, PW);
+        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
+        a.out[obase + e] = o.val;
+        if (PK) {
+          a.amax8[abase + c * PPS + bin] = (unsigned char)o.code;
+        } else {
+          a.ax[obase + e] = o.ax;
+          a.ay[obase + e] = o.ay;
+        }
+      }
+    }
+  }
+
+  // ===== from here on every wave runs on its own: no workgroup barrier =====
+  float* win = s.stage + wave * (DENSE_CAPF + 4);
+#pragma unroll 1
+  for (int i = 0; i < NROI; ++i) {
+    const typename S::Roi& t = s.roi[i];
+    const int n = __builtin_amdgcn_readfirstlane(t.n);
+    const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
+    if (lvl == -2) break;
+    if (lvl < 0 || !__builtin_amdgcn_readfirstlane(t.any_valid) ||
+        __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col | t.fb_win))
+      continue;
+    const long obase = ((long)n * a.C + cbeg) * PP;
+    const long abase = ((long)n * a.C + cbeg) * PPS;
+    const int W = a.L.W[lvl], H = a.L.H[lvl];
+    const long plane = (long)H * W;
+    const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
+    const long pstep = (long)NWAVE * plane * 4;  // bytes between this wave's channels
+    const int r0 = __builtin_amdgcn_readfirstlane(t.r0), nr = __builtin_amdgcn_readfirstlane(t.nr);
+    const int c0a = __builtin_amdgcn_readfirstlane(t.c0a), nlr = __builtin_amdgcn_readfirstlane(t.nlr);
+    const int pitch = __builtin_amdgcn_readfirstlane(t.pitch), nit = __builtin_amdgcn_readfirstlane(t.nit);
+
+    // ---- load plan of this lane: 16-byte piece `sg` of window row `j` per load ----
+    unsigned voff[DENSE_MAXIT];
+    int loff[DENSE_MAXIT], shl[DENSE_MAXIT];
+#pragma unroll
+    for (int it = 0; it < DENSE_MAXIT; ++it) {
+      const int g = it * kWave + lane;
+      const int j = g / nlr, sg = g - j * nlr;
+      const bool ok = it < nit && j < nr;
+      int col = c0a + 4 * sg;
+      // the last piece of a row may reach past column W-1; inside the plane that is the next row
+      // (harmless), on the LAST row it would leave the plane: start it earlier and shift the lanes
+      int over = 0;
+      if (ok && r0 + j == H - 1 && col + 3 > W - 1) over = col + 3 - (W - 1);
+      // (W >= 4 on this path, so col - over >= 0: the piece stays inside the row)
+      voff[it] = ok ? (unsigned)(((r0 + j) * W + col - over) * 4) : 0u;
+      loff[it] = ok ? j * pitch + 4 * sg : -1;
+      shl[it] = over;
+    }
+    // ---- this lane's bin: window addresses of its 4 samples, weights, coordinates ----
+    const int bb = lane < PP ? lane : 0, p = bb / PW, q = bb % PW;
+    int rlo[2], rhi[2], clo[2];
+    bool cdup[2];
+    float4 wreg[4];
+    float cxv[2], cyv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int lo = t.rowidx[4 * p + 2 * k], hi = t.rowidx[4 * p + 2 * k + 1];
+      rlo[k] = ((lo < 0 ? r0 : lo) - r0) * pitch;
+      rhi[k] = ((hi < 0 ? r0 : hi) - r0) * pitch;
+      const int cl = t.colidx[4 * q + 2 * k], cr = t.colidx[4 * q + 2 * k + 1];
+      clo[k] = (cl < 0 ? c0a : cl) - c0a;
+      cdup[k] = cl == cr;
+      cxv[k] = t.wval[2 * q + k];
+      cyv[k] = t.hval[2 * p + k];
+    }
+#pragma unroll
+    for (int kl = 0; kl < 4; ++kl) {
+      const int k = kl >> 1, l = kl & 1;
+      const bool valid = k < t.hcnt[p] && l < t.wcnt[q];
+      const float al = t.alpha[2 * p + k], be = t.beta[2 * q + l];
+      float4 w;
+      w.x = (1 - al) * (1 - be);
+      w.y = al * (1 - be);
+      w.z = (1 - al) * be;
+      w.w = al * be;
+      if (!valid) w.x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
+      wreg[kl] = w;
+    }
+    const float init = (t.hcnt[p] >= 0 && t.wcnt[q] >= 0) ? -FLT_MAX : 0.f;
+
+    const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
+    float* po = a.out + obase + (long)wave * PP;
+    float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
+    float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
+    unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
+    float4 nxt[DENSE_MAXIT];
+    auto issue = [&](const char* plc) {
+#pragma unroll
+      for (int it = 0; it < DENSE_MAXIT; ++it)
+        if (it < nit) {
+          const F4u v = *reinterpret_cast<const F4u*>(plc + voff[it]);
+          nxt[it] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    if (wave < nch) issue(pl);
+    for (int c0 = wave; c0 < nch; c0 += NWAVE) {
+#pragma unroll
+      for (int it = 0; it < DENSE_MAXIT; ++it)
+        if (it < nit && loff[it] >= 0) {
+          float4 v = nxt[it];
+          if (shl[it]) {  // rare: piece started `shl` columns early (last row of the plane)
+            const int sh = shl[it];
+            v.x = sh == 1 ? v.y : sh == 2 ? v.z : v.w;
+            v.y = sh == 1 ? v.z : v.w;
+            v.z = v.w;
+          }
+          *reinterpret_cast<float4*>(win + loff[it]) = v;
+        }
+      if (c0 + NWAVE < nch) issue(pl + pstep);  // the next channel travels while this one is reduced
+      wave_lds_sync();
+      if (lane < PP) {
+        float maxval = init, bx = -1.f, by = -1.f;
+        int bk = -1;
+#pragma unroll
+        for (int kl = 0; kl < 4; ++kl) {
+          const int k = kl >> 1, l = kl & 1;
+          const F2u top = *reinterpret_cast<const F2u*>(win + rlo[k] + clo[l]);
+          const F2u bot = *reinterpret_cast<const F2u*>(win + rhi[k] + clo[l]);
+          const float tl = top.x, tr = cdup[l] ? top.x : top.y;
+          const float bl = bot.x, br = cdup[l] ? bot.x : bot.y;
+          const float4 w = wreg[kl];
+          const float value = w.x * tl + w.y * bl + w.z * tr + w.w * br;
+          if (value > maxval) {
+            maxval = value;
+            if (PK) {
+              bk = k * 3 + l;
+            } else {
+              bx = cxv[l];
+              by = cyv[k];
+            }
+          }
+        }
+        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+        po[lane] = maxval;
+        if (PK) {
+          pk[lane] = (unsigned char)(bk < 0 ? 255 : bk);
+        } else {
+          px[lane] = bx;
+          py[lane] = by;
+        }
+      }
+      wave_lds_sync();
+      pl += pstep;
+      po += NWAVE * PP;
+      if (PK) {
+        pk += NWAVE * PPS;
+      } else {
+        px += NWAVE * PP;
+        py += NWAVE * PP;
+      }
+    }
   }
 }
 
@@ -1680,7 +2005,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   const int nroi = a.B * a.R;
   a.order = nullptr;
   const int nbuckets = (a.L.nlvl + 1) * a.B * kOrderCells * kOrderCells;
-  if (variant == 1 && workspace && workspace_bytes >= (size_t)nroi * sizeof(int) + 16 &&
+  if (variant >= 1 && workspace && workspace_bytes >= (size_t)nroi * sizeof(int) + 16 &&
       nroi <= 16384 && nbuckets <= kOrderMaxBuckets && tuning("roi_align_fwd_order", 0)) {
     int* order = reinterpret_cast<int*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
     int l0 = 0;
@@ -1703,7 +2028,16 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   for (int l = 0; l < a.L.nlvl; ++l)
     if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
   const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
-  if (variant == 1 && wide && a.PH == 7 && a.PW == 7) {
+  if (variant == 2 && wide && a.PH == 7 && a.PW == 7) {
+    const int nr2 = rpw >= 4 ? 4 : 2;
+    if (a.amax8) {
+      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, true>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), 0, st, a);
+    } else {
+      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, false>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, false>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), 0, st, a);
+    }
+  } else if (variant >= 1 && wide && a.PH == 7 && a.PW == 7) {
 #define SD_FWD77(NROI)                                                                           \
   do {                                                                                           \
     if (a.amax8)                                                                                 \
@@ -1715,7 +2049,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   } while (0)
     if (rpw >= 4) SD_FWD77(4); else if (rpw >= 2) SD_FWD77(2); else SD_FWD77(1);
 #undef SD_FWD77
-  } else if (variant == 1 && wide && a.PH == 14 && a.PW == 14) {
+  } else if (variant >= 1 && wide && a.PH == 14 && a.PW == 14) {
     if (a.amax8)
       hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1, true>), dim3(nroi * a.nslice), dim3(512), 0,
                          st, a);
