@@ -195,7 +195,6 @@ struct FwdSmem {
   __attribute__((aligned(16))) float tile[NWAVE * CH];
   struct Roi {
     float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab  (kl = 2k+l); x = NaN: none
-    float2 coord[4 * PP];   // [kl][bin]: (w, h) of the sample
     int rowoff[NR];         // row * W, or -1 for an unused slot
     int coloff[NC];
     float hval[2 * PH], alpha[2 * PH];
@@ -313,8 +312,8 @@ __global__ __launch_bounds__(64) void roi_coords_kernel(const float* rois, int n
   }
 }
 
-template <int PH, int PW, int NROI, bool PK>
-__global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
+template <int PH, int PW, int NROI, bool PK, bool LEAN>
+__device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
   constexpr int D = 1;  // channels in flight per wave (deeper batches measured slower)
   using S = FwdSmem<PH, PW, NROI>;
   constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, PPP = S::PPP, CH = S::CH, NWAVE = S::NWAVE;
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
   constexpr int CHUNK = ITER < 8 ? ITER : 8;    // loads kept in flight per lane
   constexpr int NCHUNK = (ITER + CHUNK - 1) / CHUNK;
   constexpr int NI = (PP + kWave - 1) / kWave;  // bins per lane
-  constexpr bool REGW = NI == 1;                // keep the bin's 16 weights in registers
+  constexpr bool REGW = NI == 1 && !LEAN;       // keep the bin's 16 weights in registers
   constexpr bool CACHE_GOFF = ITER <= 8;        // keep the fill offsets in registers
   __shared__ S s;
 
@@ -397,7 +396,6 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
     w.w = al * be;
     if (!valid) w.x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
     t.wts[tt] = w;
-    t.coord[tt] = make_float2(t.wval[2 * q + l], t.hval[2 * p + k]);
     if (kl == 0) t.binflag[bin] = (t.hcnt[p] >= 0 && t.wcnt[q] >= 0) ? 1 : 0;
     if (__any(valid) && valid) t.any_valid = 1;  // benign same-value race
   }
@@ -410,14 +408,11 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
       if (t.lvl < 0) continue;
       const bool row = j < 3 * PH;
       const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
-      float v;
-      if (k < 2 && !(t.fb_row | t.fb_col)) {
-        v = row ? t.hval[2 * p + k] : t.wval[2 * p + k];
-      } else {
-        const int lv = t.lvl;
-        v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
-                : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
-      }
+      // recomputed, not taken from hval / wval: those hold only the samples the loop reached, and
+      // the table is written in full so that its content does not depend on LDS leftovers
+      const int lv = t.lvl;
+      const float v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
+                          : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
       float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
       base[j] = v;
       store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
@@ -668,44 +663,67 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
   }
 }
 
+template <int PH, int PW, int NROI, bool PK>
+__global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
+  fwd_tiled_body<PH, PW, NROI, PK, false>(a);
+}
+
+// The same kernel held to 64 VGPRs (weights re-read from LDS per channel) and two RoIs of tables:
+// four workgroups = 8 waves per SIMD fit a CU instead of three.  The forward is latency bound
+// (1 -> 2 -> 3 workgroups per CU: 238 -> 149 -> 127 us in the profiling build).
+template <int NROI, bool PK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_tiled_lean(
+    FwdArgs a) {
+  fwd_tiled_body<7, 7, NROI, PK, true>(a);
+}
+
 // ------------------------------------------------------------------------------------------------
 // dense-window forward (7x7)
 // ------------------------------------------------------------------------------------------------
 // The tiled kernel above fetches every (left,right) tap pair of a RoI with its own 8-byte gather:
-// 7 wave-level loads per (RoI, channel), 822 MB of taps per launch, and the address unit spends
-// ~16 clocks per wave instruction whatever its width -- that gather rate (64 us even when every
-// tap hits L2, profiles/r01_gather_microbench.txt), not HBM, bounds it.  Here a wave fetches the
-// RoI's WINDOW of the channel plane instead -- the rows r0..r1 and columns c0..c1 its samples
-// touch, 16 bytes per lane, contiguous runs per row -- 1-3 loads per (RoI, channel) at the
-// baseline, into a private LDS window with an odd-multiple-of-4 pitch; the 49 bin lanes then read
-// their taps straight out of the window (two ds_read2_b32 per sample) with addresses they keep in
-// registers.  Same arithmetic, same evaluation order, bit-identical results.
-// A RoI whose window does not fit (more than DENSE_MAXIT loads or DENSE_CAPF floats: extreme
-// aspect ratios) takes the exact per-element path.
-constexpr int DENSE_MAXIT = 5;     // 16-byte loads per lane and channel
-constexpr int DENSE_CAPF = 1280;   // floats of one wave's window
+// 7 wave-level loads per (RoI, channel), and the texture-address unit of the CU -- 16 clocks per
+// wave instruction whatever its width -- is its busiest resource (~60%).  Here a wave fetches the
+// RoI's WINDOW of the channel plane instead: the distinct rows its samples touch (at most 28, a
+// compacted list for tall RoIs) x the contiguous column range, 16 bytes per lane, 1-3 loads per
+// (RoI, channel) at the baseline, into a private LDS window whose pitch is an odd multiple of four
+// floats.  The 49 bin lanes read their taps straight out of the window (ds_read2_b32 of the
+// (left,right) pair, addresses held in registers).  Same arithmetic, same evaluation order,
+// bit-identical results.  The channel loop is instantiated per load count so that its body is
+// branch-free.  RoIs whose window does not fit (more than DENSE_MAXIT loads: extreme aspect
+// ratios) or whose window would have to be read past the end of the tensor take the exact
+// per-element path.
+constexpr int DENSE_MAXIT = 5;                    // 16-byte loads per lane and channel
+constexpr int DENSE_CAPF = DENSE_MAXIT * 64 * 4;  // floats of one wave's window
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) V2u {
+  v2f v;
+};
 
 template <int PH, int PW, int NROI>
 struct DenseSmem {
   static constexpr int NWAVE = 8;
-  __attribute__((aligned(16))) float stage[NWAVE * (DENSE_CAPF + 4)];
+  __attribute__((aligned(16))) float stage[NWAVE * DENSE_CAPF];
   struct Roi {
     int rowidx[4 * PH];      // [p*4 + 2k + {lo,hi}] row index, -1 unused
     int colidx[4 * PW];
+    int crow[4 * PH];        // window row of the entry (index into rowlist)
+    int rowlist[4 * PH];     // distinct rows of the window, ascending
     float hval[2 * PH], alpha[2 * PH];
     float wval[2 * PW], beta[2 * PW];
     int hcnt[PH], wcnt[PW];
-    int lvl, n, fb_row, fb_col, fb_win, any_valid;
-    int r0, nr, c0a, nlr, pitch, nit;
+    int lvl, n, fb_row, fb_col, fb_win, any_valid, any_dup;
+    int nr, c0w, nlr, pitch, nit, magic;
     float box[4];
   } roi[NROI];
 };
 
 template <int PH, int PW, int NROI, bool PK>
-__global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void roi_align_fwd_dense(
+    FwdArgs a) {
   using S = DenseSmem<PH, PW, NROI>;
   constexpr int PP = PH * PW, NWAVE = S::NWAVE, THREADS = NWAVE * kWave, PPS = amax_stride(PP);
-  static_assert(PP <= kWave, "one bin per lane");
+  static_assert(PP <= kWave && 4 * PH <= 32 && 4 * PW <= 32, "one bin per lane, axis entries in half a wave");
   static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
   __shared__ S s;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -751,32 +769,57 @@ __global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
     }
   }
   __syncthreads();
-  // ---- window of every RoI (one lane each) ----
-  if (tid < NROI) {
-    typename S::Roi& t = s.roi[tid];
-    t.any_valid = 0;
-    t.fb_win = 0;
-    if (t.lvl >= 0 && !t.fb_row && !t.fb_col) {
-      int r0 = 1 << 30, r1 = -1, c0 = 1 << 30, c1 = -1;
-      bool vr = false, vc = false;
+  // ---- window of RoI i, by wave i: lanes 0..27 hold the row entries, the same lanes the column
+  // entries.  The distinct rows are numbered with a ballot prefix over "first lane holding it".
+  if (wave < NROI) {
+    typename S::Roi& t = s.roi[wave];
+    const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
+    const int fbt = __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col);
+    int any_valid = 0, fb_win = 0, any_dup = 0, nr = 0, c0w = 0, nlr = 1, pitch = 4, nit = 1;
+    if (lvl >= 0 && !fbt) {
+      const int rv = lane < 4 * PH ? t.rowidx[lane] : -1;
+      const int cv = lane < 4 * PW ? t.colidx[lane] : -1;
+      // entries are NOT monotone (floor of the second sample may lie below ceil of the first):
+      // every entry looks for the first lane that holds its row
+      int first = -1;
+#pragma unroll 1
       for (int e = 0; e < 4 * PH; ++e) {
-        const int v = t.rowidx[e];
-        if (v >= 0 && (e & 3) / 2 < t.hcnt[e >> 2]) { r0 = v < r0 ? v : r0; r1 = v > r1 ? v : r1; vr = true; }
+        const int re = __builtin_amdgcn_readlane(rv, e);
+        if (first < 0 && re == rv) first = e;
       }
-      for (int e = 0; e < 4 * PW; ++e) {
-        const int v = t.colidx[e];
-        if (v >= 0 && (e & 3) / 2 < t.wcnt[e >> 2]) { c0 = v < c0 ? v : c0; c1 = v > c1 ? v : c1; vc = true; }
+      const bool isnew = rv >= 0 && first == lane;
+      const unsigned long long nb = __ballot(isnew), cb = __ballot(cv >= 0);
+      if (nb != 0 && cb != 0) {
+        any_valid = 1;
+        const int cidx = __popcll(nb & ((1ull << (first < 0 ? 0 : first)) - 1ull));  // rank of the first holder
+        if (lane < 4 * PH) t.crow[lane] = rv >= 0 ? cidx : 0;
+        if (isnew) t.rowlist[cidx] = rv;
+        nr = __popcll(nb);
+        const int c0 = __builtin_amdgcn_readlane(cv, __ffsll((long long)cb) - 1);
+        const int c1 = __builtin_amdgcn_readlane(cv, 63 - __clzll((long long)cb));
+        const int W = a.L.W[lvl], H = a.L.H[lvl];
+        nlr = (c1 - c0) / 4 + 1;
+        pitch = 4 * (nlr | 1);  // odd multiple of 4 floats
+        // the window is moved left when its last piece would reach past the row, so that no load
+        // leaves the plane; when the plane is narrower than the window the pieces of a row run
+        // into the next row (harmless) -- except on the last row of the plane
+        c0w = c0 < W - 4 * nlr ? c0 : W - 4 * nlr;
+        const int rlast = __builtin_amdgcn_readlane(rv, 63 - __clzll((long long)__ballot(rv >= 0)));
+        if (c0w < 0) {
+          c0w = 0;
+          if (rlast == H - 1) fb_win = 1;
+        }
+        nit = (nr * nlr + kWave - 1) / kWave;
+        if (nit > DENSE_MAXIT || nr * pitch > DENSE_CAPF) fb_win = 1;
+        // a sample on an integer column reads the same tap twice
+        const int cnext = lane + 1 < 4 * PW ? t.colidx[lane + 1] : -1;
+        any_dup = __any((lane & 1) == 0 && cv >= 0 && cv == cnext);
       }
-      if (vr && vc) {
-        t.any_valid = 1;
-        const int c0a = c0 & ~3;
-        const int nlr = (c1 - c0a) / 4 + 1;
-        const int pitch = 4 * (nlr | 1);  // odd multiple of 4 floats: rows 1..7 apart never share a bank
-        const int nr = r1 - r0 + 1;
-        t.r0 = r0; t.nr = nr; t.c0a = c0a; t.nlr = nlr; t.pitch = pitch;
-        t.nit = (nr * nlr + kWave - 1) / kWave;
-        if (t.nit > DENSE_MAXIT || nr * pitch > DENSE_CAPF || a.L.W[t.lvl] < 4) t.fb_win = 1;
-      }
+    }
+    if (lane == 0) {
+      t.any_valid = any_valid; t.fb_win = fb_win; t.any_dup = any_dup;
+      t.nr = nr; t.c0w = c0w; t.nlr = nlr; t.pitch = pitch; t.nit = nit;
+      t.magic = (65536 + nlr - 1) / nlr;  // g / nlr == (g * magic) >> 16 for g < 512, nlr <= 32
     }
   }
   __syncthreads();
@@ -787,28 +830,17 @@ __global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
       if (t.lvl < 0) continue;
       const bool row = j < 3 * PH;
       const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
-      float v;
-      if (k < 2 && !(t.fb_row | t.fb_col)) {
-        v = row ? t.hval[2 * p + k] : t.wval[2 * p + k];
-        // a sample the loop never reached has no coordinate in the table: recompute like the tiled kernel
-        const int cnt = row ? t.hcnt[p] : t.wcnt[p];
-        if (k >= cnt) {
-          const int lv = t.lvl;
-          v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
-                  : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
-        }
-      } else {
-        const int lv = t.lvl;
-        v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
-                : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
-      }
+      const int lv = t.lvl;
+      const float v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
+                          : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
       float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
       base[j] = v;
       store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
     }
   }
 
-  // rare RoIs first (assigned to no level, 3-iteration sample loop, oversized window): exact path
+  // rare RoIs first (assigned to no level, nothing to pool, 3-iteration sample loop, window that
+  // does not fit): exact and simple, by the whole workgroup
 #pragma unroll 1
   for (int i = 0; i < NROI; ++i) {
     const typename S::Roi& t = s.roi[i];
@@ -816,7 +848,8 @@ __global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
     if (lvl == -2) break;
     const long obase = ((long)n * a.C + cbeg) * PP;
     const long abase = ((long)n * a.C + cbeg) * PPS;
-    if (lvl < 0 || (!t.any_valid && !(t.fb_row || t.fb_col))) {
+    const bool exact = t.fb_row || t.fb_col || t.fb_win;
+    if (lvl < 0 || (!t.any_valid && !exact)) {
       for (int e = tid; e < nch * PP; e += THREADS) {
         a.out[obase + e] = 0.f;
         if (PK) {
@@ -826,7 +859,8 @@ __global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
           a.ay[obase + e] = -1.f;
         }
       }
-    } else if (t.fb_row || t.fb_col || t.fb_win) {
+    } else if (exact) {
+      if (SD_ABLATE(a, 8)) continue;  // profiling build: skip the exact path
       const int H = a.L.H[lvl], W = a.L.W[lvl];
       const long plane = (long)H * W;
       const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
@@ -848,7 +882,10 @@ __global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
   }
 
   // ===== from here on every wave runs on its own: no workgroup barrier =====
-  float* win = s.stage + wave * (DENSE_CAPF + 4);
+  const bool tuning_pf = !(SD_ABLATE(a, 32));  // profiling build: 32 = no prefetch loops
+  float* win = s.stage + wave * DENSE_CAPF;
+  const int bin = lane < PP ? lane : PP - 1;  // lanes past the last bin repeat it (same stores)
+  const int p = bin / PW, q = bin % PW;
 #pragma unroll 1
   for (int i = 0; i < NROI; ++i) {
     const typename S::Roi& t = s.roi[i];
@@ -860,133 +897,208 @@ __global__ __launch_bounds__(512) void roi_align_fwd_dense(FwdArgs a) {
       continue;
     const long obase = ((long)n * a.C + cbeg) * PP;
     const long abase = ((long)n * a.C + cbeg) * PPS;
-    const int W = a.L.W[lvl], H = a.L.H[lvl];
-    const long plane = (long)H * W;
+    const int W = a.L.W[lvl];
+    const long plane = (long)a.L.H[lvl] * W;
     const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
     const long pstep = (long)NWAVE * plane * 4;  // bytes between this wave's channels
-    const int r0 = __builtin_amdgcn_readfirstlane(t.r0), nr = __builtin_amdgcn_readfirstlane(t.nr);
-    const int c0a = __builtin_amdgcn_readfirstlane(t.c0a), nlr = __builtin_amdgcn_readfirstlane(t.nlr);
-    const int pitch = __builtin_amdgcn_readfirstlane(t.pitch), nit = __builtin_amdgcn_readfirstlane(t.nit);
+    const int nr = __builtin_amdgcn_readfirstlane(t.nr), nlr = __builtin_amdgcn_readfirstlane(t.nlr);
+    const int c0w = __builtin_amdgcn_readfirstlane(t.c0w), pitch = __builtin_amdgcn_readfirstlane(t.pitch);
+    const int magic = __builtin_amdgcn_readfirstlane(t.magic);
+    int nit = __builtin_amdgcn_readfirstlane(t.nit);
+    if (SD_ABLATE(a, 2)) nit = 1;  // profiling build: one window load per channel
 
-    // ---- load plan of this lane: 16-byte piece `sg` of window row `j` per load ----
+    // ---- load plan of this lane: piece g = it*64 + lane -> 16 bytes `sg` of window row `j` ----
     unsigned voff[DENSE_MAXIT];
-    int loff[DENSE_MAXIT], shl[DENSE_MAXIT];
+    int loff[DENSE_MAXIT];  // LDS byte offset inside the window
+    const int npiece = nr * nlr;
 #pragma unroll
     for (int it = 0; it < DENSE_MAXIT; ++it) {
       const int g = it * kWave + lane;
-      const int j = g / nlr, sg = g - j * nlr;
-      const bool ok = it < nit && j < nr;
-      int col = c0a + 4 * sg;
-      // the last piece of a row may reach past column W-1; inside the plane that is the next row
-      // (harmless), on the LAST row it would leave the plane: start it earlier and shift the lanes
-      int over = 0;
-      if (ok && r0 + j == H - 1 && col + 3 > W - 1) over = col + 3 - (W - 1);
-      // (W >= 4 on this path, so col - over >= 0: the piece stays inside the row)
-      voff[it] = ok ? (unsigned)(((r0 + j) * W + col - over) * 4) : 0u;
-      loff[it] = ok ? j * pitch + 4 * sg : -1;
-      shl[it] = over;
+      const int j = (g * magic) >> 16, sg = g - j * nlr;
+      const bool ok = g < npiece;
+      const int row = t.rowlist[ok ? j : 0];
+      voff[it] = ok ? (unsigned)((row * W + c0w + 4 * sg) * 4) : 0u;
+      loff[it] = ok ? (j * pitch + 4 * sg) * 4 : -1;
     }
-    // ---- this lane's bin: window addresses of its 4 samples, weights, coordinates ----
-    const int bb = lane < PP ? lane : 0, p = bb / PW, q = bb % PW;
-    int rlo[2], rhi[2], clo[2];
+    // ---- this lane's bin: window addresses of its samples, weights, coordinates ----
+    int atop[4], abot[4];
     bool cdup[2];
-    float4 wreg[4];
+    v2f wT[4], wB[4];  // (TL, TR) and (BL, BR) weight products of sample kl
     float cxv[2], cyv[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int lo = t.rowidx[4 * p + 2 * k], hi = t.rowidx[4 * p + 2 * k + 1];
-      rlo[k] = ((lo < 0 ? r0 : lo) - r0) * pitch;
-      rhi[k] = ((hi < 0 ? r0 : hi) - r0) * pitch;
-      const int cl = t.colidx[4 * q + 2 * k], cr = t.colidx[4 * q + 2 * k + 1];
-      clo[k] = (cl < 0 ? c0a : cl) - c0a;
-      cdup[k] = cl == cr;
-      cxv[k] = t.wval[2 * q + k];
-      cyv[k] = t.hval[2 * p + k];
-    }
 #pragma unroll
     for (int kl = 0; kl < 4; ++kl) {
       const int k = kl >> 1, l = kl & 1;
+      const int cl = t.colidx[4 * q + 2 * l], cr = t.colidx[4 * q + 2 * l + 1];
+      const int cofs = (cl < 0 ? c0w : cl) - c0w;
+      atop[kl] = (t.crow[4 * p + 2 * k] * pitch + cofs) * 4;
+      abot[kl] = (t.crow[4 * p + 2 * k + 1] * pitch + cofs) * 4;
+      if (SD_ABLATE(a, 16)) atop[kl] = abot[kl] = 0;  // profiling build: conflict-free reads
+      cdup[l] = cl == cr;
       const bool valid = k < t.hcnt[p] && l < t.wcnt[q];
       const float al = t.alpha[2 * p + k], be = t.beta[2 * q + l];
-      float4 w;
-      w.x = (1 - al) * (1 - be);
-      w.y = al * (1 - be);
-      w.z = (1 - al) * be;
-      w.w = al * be;
-      if (!valid) w.x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
-      wreg[kl] = w;
+      wT[kl].x = (1 - al) * (1 - be);
+      wB[kl].x = al * (1 - be);
+      wT[kl].y = (1 - al) * be;
+      wB[kl].y = al * be;
+      if (!valid) wT[kl].x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
+      cxv[l] = t.wval[2 * q + l];
+      cyv[k] = t.hval[2 * p + k];
     }
     const float init = (t.hcnt[p] >= 0 && t.wcnt[q] >= 0) ? -FLT_MAX : 0.f;
+    const char* winb = reinterpret_cast<const char*>(win);
 
-    const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
-    float* po = a.out + obase + (long)wave * PP;
-    float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
-    float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
-    unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
-    float4 nxt[DENSE_MAXIT];
-    auto issue = [&](const char* plc) {
+    auto channel_loop = [&](auto nit_tag, auto dup_tag) {
+      constexpr int NIT = decltype(nit_tag)::value;
+      constexpr bool kDup = decltype(dup_tag)::value;
+      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
+      float* po = a.out + obase + (long)wave * PP + bin;
+      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP + bin;
+      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP + bin;
+      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS + bin : nullptr;
+      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
+        F4u v[NIT];
 #pragma unroll
-      for (int it = 0; it < DENSE_MAXIT; ++it)
-        if (it < nit) {
-          const F4u v = *reinterpret_cast<const F4u*>(plc + voff[it]);
-          nxt[it] = make_float4(v.x, v.y, v.z, v.w);
-        }
-    };
-    if (wave < nch) issue(pl);
-    for (int c0 = wave; c0 < nch; c0 += NWAVE) {
+        for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const F4u*>(pl + voff[it]);
 #pragma unroll
-      for (int it = 0; it < DENSE_MAXIT; ++it)
-        if (it < nit && loff[it] >= 0) {
-          float4 v = nxt[it];
-          if (shl[it]) {  // rare: piece started `shl` columns early (last row of the plane)
-            const int sh = shl[it];
-            v.x = sh == 1 ? v.y : sh == 2 ? v.z : v.w;
-            v.y = sh == 1 ? v.z : v.w;
-            v.z = v.w;
-          }
-          *reinterpret_cast<float4*>(win + loff[it]) = v;
+        for (int it = 0; it < NIT; ++it) {
+          // only the last load has lanes without a piece (the coincident-column instance runs
+          // with the maximum load count whatever the window: every load is checked there)
+          if ((!kDup && it < NIT - 1) || loff[it] >= 0)
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(win) + loff[it]) =
+                make_float4(v[it].x, v[it].y, v[it].z, v[it].w);
         }
-      if (c0 + NWAVE < nch) issue(pl + pstep);  // the next channel travels while this one is reduced
-      wave_lds_sync();
-      if (lane < PP) {
+        wave_lds_sync();
         float maxval = init, bx = -1.f, by = -1.f;
         int bk = -1;
 #pragma unroll
         for (int kl = 0; kl < 4; ++kl) {
-          const int k = kl >> 1, l = kl & 1;
-          const F2u top = *reinterpret_cast<const F2u*>(win + rlo[k] + clo[l]);
-          const F2u bot = *reinterpret_cast<const F2u*>(win + rhi[k] + clo[l]);
-          const float tl = top.x, tr = cdup[l] ? top.x : top.y;
-          const float bl = bot.x, br = cdup[l] ? bot.x : bot.y;
-          const float4 w = wreg[kl];
-          const float value = w.x * tl + w.y * bl + w.z * tr + w.w * br;
+          v2f top = reinterpret_cast<const V2u*>(winb + atop[kl])->v;
+          v2f bot = reinterpret_cast<const V2u*>(winb + abot[kl])->v;
+          if (kDup && cdup[kl & 1]) {
+            top.y = top.x;
+            bot.y = bot.x;
+          }
+          const v2f pt = wT[kl] * top, pb = wB[kl] * bot;
+          const float value = ((pt.x + pb.x) + pt.y) + pb.y;  // the reference's order: TL, BL, TR, BR
           if (value > maxval) {
             maxval = value;
             if (PK) {
-              bk = k * 3 + l;
+              bk = (kl >> 1) * 3 + (kl & 1);
             } else {
-              bx = cxv[l];
-              by = cyv[k];
+              bx = cxv[kl & 1];
+              by = cyv[kl >> 1];
             }
           }
         }
         if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-        po[lane] = maxval;
+        *po = maxval;
         if (PK) {
-          pk[lane] = (unsigned char)(bk < 0 ? 255 : bk);
+          *pk = (unsigned char)(bk < 0 ? 255 : bk);
         } else {
-          px[lane] = bx;
-          py[lane] = by;
+          *px = bx;
+          *py = by;
+        }
+        wave_lds_sync();
+        pl += pstep;
+        po += NWAVE * PP;
+        if (PK) {
+          pk += NWAVE * PPS;
+        } else {
+          px += NWAVE * PP;
+          py += NWAVE * PP;
         }
       }
-      wave_lds_sync();
-      pl += pstep;
-      po += NWAVE * PP;
-      if (PK) {
-        pk += NWAVE * PPS;
-      } else {
-        px += NWAVE * PP;
-        py += NWAVE * PP;
+    };
+    // Small windows (<= 3 loads): the next channel's window is requested before this one is
+    // reduced.  Loads and waits are written by hand so that the wait at the end of the body is
+    // vmcnt(<stores of this channel>): the window has arrived, the stores may still be in flight
+    // (the compiler's own bookkeeping merges the loop entry with the back edge into vmcnt(0)).
+    auto channel_loop_pf = [&](auto nit_tag) {
+      constexpr int NIT = decltype(nit_tag)::value;
+      static_assert(NIT >= 1 && NIT <= 3, "prefetch variant");
+      constexpr int NST = PK ? 2 : 3;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f r0, r1, r2;
+      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
+      auto issue = [&]() {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r0) : "v"(voff[0]), "s"(pl));
+        if (NIT > 1) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r1) : "v"(voff[1]), "s"(pl));
+        if (NIT > 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r2) : "v"(voff[2]), "s"(pl));
+      };
+      float* po = a.out + obase + (long)wave * PP + bin;
+      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP + bin;
+      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP + bin;
+      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS + bin : nullptr;
+      char* wb = reinterpret_cast<char*>(win);
+      if (wave < nch) {
+        issue();
+        if (NIT == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0));
+        if (NIT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1));
+        if (NIT == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2));
+      }
+      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
+        if (NIT > 1 || loff[0] >= 0) *reinterpret_cast<v4f*>(wb + loff[0]) = r0;
+        if (NIT == 2 && loff[1] >= 0) *reinterpret_cast<v4f*>(wb + loff[1]) = r1;
+        if (NIT > 2) *reinterpret_cast<v4f*>(wb + loff[1]) = r1;
+        if (NIT == 3 && loff[2] >= 0) *reinterpret_cast<v4f*>(wb + loff[2]) = r2;
+        pl += (c0 + NWAVE < nch) ? pstep : 0;  // the last iteration re-requests its own plane
+        issue();
+        wave_lds_sync();
+        float maxval = init, bx = -1.f, by = -1.f;
+        int bk = -1;
+#pragma unroll
+        for (int kl = 0; kl < 4; ++kl) {
+          const v2f top = reinterpret_cast<const V2u*>(winb + atop[kl])->v;
+          const v2f bot = reinterpret_cast<const V2u*>(winb + abot[kl])->v;
+          const v2f pt = wT[kl] * top, pb = wB[kl] * bot;
+          const float value = ((pt.x + pb.x) + pt.y) + pb.y;
+          if (value > maxval) {
+            maxval = value;
+            if (PK) {
+              bk = (kl >> 1) * 3 + (kl & 1);
+            } else {
+              bx = cxv[kl & 1];
+              by = cyv[kl >> 1];
+            }
+          }
+        }
+        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+        *po = maxval;
+        if (PK) {
+          *pk = (unsigned char)(bk < 0 ? 255 : bk);
+        } else {
+          *px = bx;
+          *py = by;
+        }
+        wave_lds_sync();
+        if (NIT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "n"(NST));
+        if (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(NST));
+        if (NIT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(NST));
+        po += NWAVE * PP;
+        if (PK) {
+          pk += NWAVE * PPS;
+        } else {
+          px += NWAVE * PP;
+          py += NWAVE * PP;
+        }
+      }
+    };
+    const bool pf = tuning_pf;
+    if (__builtin_amdgcn_readfirstlane(t.any_dup)) {
+      channel_loop(std::integral_constant<int, DENSE_MAXIT>{}, std::true_type{});
+    } else if (pf && nit <= 3) {
+      switch (nit) {
+        case 1: channel_loop_pf(std::integral_constant<int, 1>{}); break;
+        case 2: channel_loop_pf(std::integral_constant<int, 2>{}); break;
+        default: channel_loop_pf(std::integral_constant<int, 3>{}); break;
+      }
+    } else {
+      switch (nit) {
+        case 1: channel_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
+        case 2: channel_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
+        case 3: channel_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
+        case 4: channel_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
+        default: channel_loop(std::integral_constant<int, 5>{}, std::false_type{}); break;
       }
     }
   }
@@ -2000,7 +2112,9 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
                       size_t workspace_bytes = 0) {
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
-  const int variant = tuning("roi_align_fwd", 1);  // 0 naive, 1 tiled
+  // 0 naive, 1 tiled (default; the 64-VGPR build for the packed 7x7 path), 2 dense window (7x7),
+  // 3 tiled without the 64-VGPR build
+  const int variant = tuning("roi_align_fwd", 1);
   a.ablate = SD_PROF_TUNING("roi_align_fwd_ablate", 0);
   const int nroi = a.B * a.R;
   a.order = nullptr;
@@ -2028,24 +2142,28 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   for (int l = 0; l < a.L.nlvl; ++l)
     if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
   const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
+  const int padlds = SD_PROF_TUNING("roi_align_fwd_padlds", 0);  // profiling build: occupancy sweep
   if (variant == 2 && wide && a.PH == 7 && a.PW == 7) {
     const int nr2 = rpw >= 4 ? 4 : 2;
     if (a.amax8) {
-      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, true>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), 0, st, a);
+      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, true>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), padlds, st, a);
+      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
     } else {
-      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, false>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, false>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), 0, st, a);
+      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, false>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), padlds, st, a);
+      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, false>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
     }
+  } else if (variant == 1 && a.amax8 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
+    // packed arg-max (the fused op): the 64-VGPR build, four workgroups per CU
+    hipLaunchKernelGGL((roi_align_fwd_tiled_lean<2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
   } else if (variant >= 1 && wide && a.PH == 7 && a.PW == 7) {
 #define SD_FWD77(NROI)                                                                           \
   do {                                                                                           \
     if (a.amax8)                                                                                 \
       hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, true>),                                \
-                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), 0, st, a);                \
+                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), padlds, st, a);           \
     else                                                                                         \
       hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, false>),                               \
-                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), 0, st, a);                \
+                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), padlds, st, a);           \
   } while (0)
     if (rpw >= 4) SD_FWD77(4); else if (rpw >= 2) SD_FWD77(2); else SD_FWD77(1);
 #undef SD_FWD77

@@ -28,10 +28,11 @@ struct Knob {
 };
 // every knob a kernel launcher reads must be listed here (sd_set_tuning rejects unknown keys)
 Knob g_knobs[] = {
-    {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default)
+    {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default), 2 dense window, 3 tiled 3 WG/CU
 #ifdef SD_PROFILING
     {"roi_align_fwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
     {"roi_align_bwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
+    {"roi_align_fwd_padlds", 0, false},  // profiling build only: extra dynamic LDS bytes (occupancy sweep)
 #endif
     {"roi_align_fwd_order", 0, false},   // 1: locality order of the RoIs (-25% L2-miss reads, same time; default 0)
     {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)

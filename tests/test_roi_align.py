@@ -132,7 +132,7 @@ def _assert_bwd_close(got, want, tol=1e-4):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0, 2, 3])  # tiled (default), naive, dense window, tiled 3 WG/CU
 @pytest.mark.parametrize("case", ["small", "c4", "p2", "mask14", "odd_pool"])
 def test_single_level_forward_bit_exact(ops, oracle, case, variant):
     from simpledet_amd._lib import lib
@@ -342,7 +342,7 @@ def _decode_packed(am, rois, feats_shapes, strides, level):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0, 2, 3])
 def test_fpn_packed_argmax_forward_backward(ops, oracle, variant):
     import torch
     from simpledet_amd._lib import lib
@@ -403,6 +403,34 @@ def test_fpn_packed_equals_float_argmax_path_full_size(ops):
     g2 = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
     for a, b in zip(g1, g2):
         assert float((a - b).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [2, 3, 0])
+def test_forward_variants_agree_at_full_size(ops, variant):
+    """Baseline shapes (2 x 512 RoIs x 256 channels, degenerate RoIs included): every forward
+    variant -- dense window (16-byte window loads, row-compacted windows, exact path for windows
+    that do not fit), tiled at 3 workgroups per CU, naive -- gives the default kernel's bits, in
+    both the packed and the float arg-max form."""
+    import torch
+    from simpledet_amd._lib import lib
+    feats = [_t(f) for f in synth.feature_maps(2, batch=2, channels=256)]
+    rois = _t(synth.random_rois(2, 2, 512))
+    o1, am1 = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, (7, 7))
+    f1 = ops.fpn_roi_align_forward(feats, rois, STRIDES, (7, 7))
+    lib().set_tuning("roi_align_fwd", variant)
+    try:
+        o2, am2 = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, (7, 7))
+        f2 = ops.fpn_roi_align_forward(feats, rois, STRIDES, (7, 7))
+    finally:
+        lib().set_tuning("roi_align_fwd", 1)
+    assert torch.equal(o1, o2)
+    assert torch.equal(ops.argmax_codes(am1[0], (7, 7)), ops.argmax_codes(am2[0], (7, 7)))
+    # the coordinate table has entries only for RoIs assigned to a level (the rest is never read)
+    lvl = ops.fpn_roi_assign(rois, STRIDES)[1].reshape(-1) >= 0
+    assert torch.equal(am1[1].reshape(lvl.numel(), -1)[lvl], am2[1].reshape(lvl.numel(), -1)[lvl])
+    for x, y in zip(f1, f2):
+        assert torch.equal(x, y)
 
 
 @pytest.mark.gpu

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Kernel-only durations (rocprofv3 --kernel-trace --stats) of the bench step for several knob sets.
+#   (profiling build by default; KT_PRODUCT=1 times the product library)
 #   usage: tools/kt_bench.sh "<bench flags 1>" "<bench flags 2>" ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-[ -f $ROOT/tools/libsimpledet_ops_hip_prof.so ] && export SIMPLEDET_AMD_LIB=$ROOT/tools/libsimpledet_ops_hip_prof.so
+[ -z "$KT_PRODUCT" ] && [ -f $ROOT/tools/libsimpledet_ops_hip_prof.so ] && export SIMPLEDET_AMD_LIB=$ROOT/tools/libsimpledet_ops_hip_prof.so
 cd /tmp && export TMPDIR=/tmp
 i=0
 for flags in "$@"; do
