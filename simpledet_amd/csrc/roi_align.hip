@@ -677,6 +677,431 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   fwd_tiled_body<7, 7, NROI, PK, true>(a);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------
+// row-compacted tiled forward (7x7)
+// ------------------------------------------------------------------------------------------------
+// The tiled kernel fetches 28 tile rows per (RoI, channel) -- (lo, hi) of two samples of seven
+// bins -- with seven 8-byte gathers, although the rows repeat: hi of one sample is lo of the next
+// whenever the bins are less than a pixel apart, and a RoI h feature rows tall has at most h + 2
+// distinct rows (median 17 at the baseline).  The texture-address unit is the busiest resource of
+// that kernel (~75-85%).  Here the distinct rows are listed once per RoI and only those are
+// fetched: ceil(distinct / 4) gathers (4.4 instead of 7 at the baseline), the same (left,right)
+// column pairs per row.  The tile is row major (row, pair) and the bin lanes read the top and the
+// bottom pair of a sample with two ds_read_b64 at addresses they compose from per-lane row and
+// column offsets.  Arithmetic and evaluation order are the tiled kernel's: bit-identical results.
+template <int PH, int PW, int NROI>
+struct RowsSmem {
+  static constexpr int NR = 4 * PH, NC = 4 * PW, PP = PH * PW, NWAVE = 8;
+  static constexpr int PITCH = NC / 2 * 2 + 2;  // floats per tile row: 14 pairs + 2 (bank spread)
+  static constexpr int CH = NR * PITCH;
+  __attribute__((aligned(16))) float tile[NWAVE * CH];
+  struct Roi {
+    float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab  (kl = 2k+l); x = NaN: none
+    int rowoff[NR];         // row * W, or -1 for an unused slot
+    int coloff[NC];
+    int crow[NR];           // tile row of the entry
+    int rowlist[NR];        // row * W of tile row r
+    float hval[2 * PH], alpha[2 * PH];
+    float wval[2 * PW], beta[2 * PW];
+    int hcnt[PH], wcnt[PW];
+    int binflag[PP];
+    int lvl, n, fb_row, fb_col, any_valid, nrd;
+    float box[4];
+  } roi[NROI];
+};
+
+template <int PH, int PW, int NROI, bool PK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_rows(
+    FwdArgs a) {
+  using S = RowsSmem<PH, PW, NROI>;
+  constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, CH = S::CH, NWAVE = S::NWAVE, PITCH = S::PITCH;
+  constexpr int PPS = amax_stride(PP);
+  constexpr int THREADS = NWAVE * kWave;
+  constexpr int NPAIR = NC / 2, RPW = kWave / NPAIR, ACT = RPW * NPAIR, ITER = NR / RPW;
+  static_assert(PP <= kWave && NR <= 32, "one bin per lane, row entries in half a wave");
+  static_assert(RPW == 4 && NR % RPW == 0 && ITER == 7, "fill geometry of the 7x7 tile");
+  static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
+  __shared__ S s;
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int nslice = a.nslice;
+  const int grp = blockIdx.x / nslice, slice = blockIdx.x % nslice;
+  const int nroi_total = a.B * a.R;
+  const int nch = a.C / nslice;
+  const int cbeg = slice * nch;
+
+  // ---- per-RoI sample tables: wave 2i rows, wave 2i+1 columns of RoI i ----
+  if (wave < 2 * NROI) {
+    const int i = wave >> 1, slot = grp * NROI + i;
+    typename S::Roi& t = s.roi[i];
+    int lvl = -2, cnt = 0, n = 0;
+    if (slot < nroi_total) {
+      n = a.order ? a.order[slot] : slot;
+      const float* r = a.rois + (long)n * 4;
+      const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+      lvl = 0;
+      if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
+      if (lvl >= 0) {
+        const int H = a.L.H[lvl], W = a.L.W[lvl];
+        const float scale = a.L.scale[lvl];
+        if ((wave & 1) == 0 && lane < PH) {
+          cnt = axis_samples(lane, PH, y1, y2, scale, H, W, &t.hval[2 * lane], &t.alpha[2 * lane],
+                             &t.rowoff[4 * lane]);
+          t.hcnt[lane] = cnt;
+        } else if ((wave & 1) == 1 && lane < PW) {
+          cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
+                             &t.coloff[4 * lane]);
+          t.wcnt[lane] = cnt;
+        }
+      }
+      if ((wave & 1) == 0 && lane == 0) {
+        t.box[0] = x1; t.box[1] = y1; t.box[2] = x2; t.box[3] = y2;
+      }
+    }
+    const int fb = __any(cnt >= 3);
+    if (lane == 0) {
+      if (wave & 1) t.fb_col = fb;
+      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; t.n = n; }
+    }
+  }
+  __syncthreads();
+
+  // ---- distinct rows of RoI i, by wave NWAVE-1-i (the waves that did no axis table first):
+  // every entry looks for the first lane holding its row; the first holders are numbered with a
+  // ballot prefix and become the tile rows
+  if (wave >= NWAVE - NROI) {
+    typename S::Roi& t = s.roi[NWAVE - 1 - wave];
+    if (__builtin_amdgcn_readfirstlane(t.lvl) >= 0 && !__builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col)) {
+      const int rv = lane < NR ? t.rowoff[lane] : -1;
+      int first = -1;
+#pragma unroll 1
+      for (int e = 0; e < NR; ++e) {
+        const int re = __builtin_amdgcn_readlane(rv, e);
+        if (first < 0 && re == rv) first = e;
+      }
+      const bool isnew = rv >= 0 && first == lane;
+      const unsigned long long nb = __ballot(isnew);
+      const int cidx = __popcll(nb & ((1ull << (first < 0 ? 0 : first)) - 1ull));
+      if (lane < NR) t.crow[lane] = rv >= 0 ? cidx : 0;
+      if (isnew) t.rowlist[cidx] = rv;
+      if (lane == 0) t.nrd = __popcll(nb);
+    }
+  }
+  // ---- per (RoI, bin, k, l): weight products, shared by all channels ----
+  for (int e = tid; e < NROI * 4 * PP; e += THREADS) {
+    const int i = e / (4 * PP), tt = e % (4 * PP);
+    typename S::Roi& t = s.roi[i];
+    if (t.lvl < 0 || t.fb_row || t.fb_col) continue;
+    const int kl = tt / PP, bin = tt % PP, p = bin / PW, q = bin % PW, k = kl >> 1, l = kl & 1;
+    const bool valid = k < t.hcnt[p] && l < t.wcnt[q];
+    const float al = t.alpha[2 * p + k], be = t.beta[2 * q + l];
+    float4 w;
+    w.x = (1 - al) * (1 - be);
+    w.y = al * (1 - be);
+    w.z = (1 - al) * be;
+    w.w = al * be;
+    if (!valid) w.x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
+    t.wts[tt] = w;
+    if (kl == 0) t.binflag[bin] = (t.hcnt[p] >= 0 && t.wcnt[q] >= 0) ? 1 : 0;
+    if (__any(valid) && valid) t.any_valid = 1;  // benign same-value race
+  }
+  __syncthreads();
+  if (PK && slice == 0) {  // the sample coordinates the packed arg-max indexes, once per RoI
+    for (int e = tid; e < NROI * 3 * (PH + PW); e += THREADS) {
+      const int i = e / (3 * (PH + PW)), j = e % (3 * (PH + PW));
+      const typename S::Roi& t = s.roi[i];
+      if (t.lvl < 0) continue;
+      const bool row = j < 3 * PH;
+      const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
+      const int lv = t.lvl;
+      const float v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
+                          : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
+      float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
+      base[j] = v;
+      store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
+    }
+  }
+
+  // rare RoIs first (assigned to no level, or a 3-iteration sample loop), exact and simple
+#pragma unroll 1
+  for (int i = 0; i < NROI; ++i) {
+    const typename S::Roi& t = s.roi[i];
+    const int n = t.n;
+    const int lvl = t.lvl;
+    if (lvl == -2) break;
+    const long obase = ((long)n * a.C + cbeg) * PP;
+    const long abase = ((long)n * a.C + cbeg) * PPS;
+    const bool exact = t.fb_row || t.fb_col;
+    if (lvl < 0 || (!exact && !t.any_valid)) {  // every per-level op sees a zero box / nothing to pool
+      for (int e = tid; e < nch * PP; e += THREADS) {
+        a.out[obase + e] = 0.f;
+        if (PK) {
+          a.amax8[abase + (e / PP) * PPS + e % PP] = 255;
+        } else {
+          a.ax[obase + e] = -1.f;
+          a.ay[obase + e] = -1.f;
+        }
+      }
+    } else if (exact) {
+      const int H = a.L.H[lvl], W = a.L.W[lvl];
+      const long plane = (long)H * W;
+      const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
+      const float scale = a.L.scale[lvl];
+      for (int e = tid; e < nch * PP; e += THREADS) {
+        const int c = e / PP, bin = e % PP;
+        FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, t.box[0], t.box[1], t.box[2],
+                                      t.box[3], scale, bin / PW, bin % PW, PH, PW);
+        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
+        a.out[obase + e] = o.val;
+        if (PK) {
+          a.amax8[abase + c * PPS + bin] = (unsigned char)o.code;
+        } else {
+          a.ax[obase + e] = o.ax;
+          a.ay[obase + e] = o.ay;
+        }
+      }
+    }
+  }
+
+  // ===== from here on every wave runs on its own: no workgroup barrier =====
+  float* tile = s.tile + wave * CH;
+  const bool fill_lane = lane < ACT;
+  const int jp = lane % NPAIR, r0 = lane / NPAIR;
+  const int fill_base = r0 * PITCH + jp * 2;  // floats; + it * RPW * PITCH (an immediate)
+  const int bin = lane < PP ? lane : PP - 1;  // lanes past the last bin repeat it (same stores)
+  const int bp = bin / PW, bq = bin % PW;
+
+#pragma unroll 1
+  for (int i = 0; i < NROI; ++i) {
+    const typename S::Roi& t = s.roi[i];
+    const int n = __builtin_amdgcn_readfirstlane(t.n);
+    const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
+    if (lvl == -2) break;
+    if (lvl < 0 || __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col) ||
+        !__builtin_amdgcn_readfirstlane(t.any_valid))
+      continue;
+    const long obase = ((long)n * a.C + cbeg) * PP;
+    const long abase = ((long)n * a.C + cbeg) * PPS;
+    const int W = a.L.W[lvl];
+    const long plane = (long)a.L.H[lvl] * W;
+    const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
+    const long pstep = (long)NWAVE * plane * 4;
+    const int nrd = __builtin_amdgcn_readfirstlane(t.nrd);
+    const int nit = (nrd + RPW - 1) / RPW;
+
+    // ---- per-lane constants of this RoI ----
+    int dup = 0;
+    unsigned colbyte = 0;
+    bool colok = false;
+    if (fill_lane) {
+      const int cl = t.coloff[2 * jp], cr = t.coloff[2 * jp + 1];
+      if (cl >= 0) {
+        const int co = cl == cr ? (cl < W - 1 ? cl : W - 2) : cl;
+        dup = cl == cr ? (co == cl ? 1 : 2) : 0;
+        colbyte = (unsigned)co * 4u;
+        colok = true;
+      }
+    }
+    const bool any_dup = __any(dup != 0);
+    unsigned voff[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int rr = it * RPW + r0;
+      const bool ok = fill_lane && colok && rr < nrd;
+      voff[it] = ok ? (unsigned)t.rowlist[ok ? rr : 0] * 4u + colbyte : 0u;
+    }
+    // tile byte offsets of this lane's bin: rows of sample k (top, bottom), pair of sample l
+    // (the pair of sample l = 1 is the next 8 bytes: one ds_read2_b64 fetches both)
+    const char* tb = reinterpret_cast<const char*>(tile) + 2 * bq * 8;
+    const char* rt[2];
+    const char* rb[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      rt[k] = tb + t.crow[4 * bp + 2 * k] * (PITCH * 4);
+      rb[k] = tb + t.crow[4 * bp + 2 * k + 1] * (PITCH * 4);
+    }
+    const float init = t.binflag[bin] ? -FLT_MAX : 0.f;
+    const float cx0 = t.wval[2 * bq], cx1 = t.wval[2 * bq + 1];
+    const float cy0 = t.hval[2 * bp], cy1 = t.hval[2 * bp + 1];
+
+    auto channel_loop = [&](auto nit_tag, auto dup_tag) {
+      constexpr int NIT = decltype(nit_tag)::value;
+      constexpr bool kDup = decltype(dup_tag)::value;
+      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
+      // uniform bases + the lane's bin: stores are "SGPR base + 32-bit lane offset"
+      float* po = a.out + obase + (long)wave * PP;
+      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
+      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
+      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
+      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
+        F2u v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (!kDup || it < nit) v[it] = *reinterpret_cast<const F2u*>(pl + voff[it]);
+        if (fill_lane) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            if (kDup && it >= nit) continue;
+            float2 w2 = make_float2(v[it].x, v[it].y);
+            if (kDup) {
+              if (dup == 1) w2.y = w2.x;
+              if (dup == 2) w2.x = w2.y;
+            }
+            *reinterpret_cast<float2*>(tile + fill_base + it * RPW * PITCH) = w2;
+          }
+        }
+        wave_lds_sync();
+        float maxval = init, bx = -1.f, by = -1.f;
+        int bk = -1;
+#pragma unroll
+        for (int kl = 0; kl < 4; ++kl) {
+          const int k = kl >> 1, l = kl & 1;
+          const float4 w = t.wts[kl * PP + bin];
+          const float2 top = *reinterpret_cast<const float2*>(rt[k] + l * 8);  // (TL, TR)
+          const float2 bot = *reinterpret_cast<const float2*>(rb[k] + l * 8);  // (BL, BR)
+          const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
+          if (value > maxval) {
+            maxval = value;
+            if (PK) {
+              bk = k * 3 + l;
+            } else {
+              bx = l ? cx1 : cx0;
+              by = k ? cy1 : cy0;
+            }
+          }
+        }
+        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+        po[bin] = maxval;
+        if (PK) {
+          pk[bin] = (unsigned char)(bk < 0 ? 255 : bk);
+        } else {
+          px[bin] = bx;
+          py[bin] = by;
+        }
+        wave_lds_sync();
+        pl += pstep;
+        po += NWAVE * PP;
+        if (PK) {
+          pk += NWAVE * PPS;
+        } else {
+          px += NWAVE * PP;
+          py += NWAVE * PP;
+        }
+      }
+    };
+    // The same loop with the next channel's rows requested before this channel is reduced.  Loads
+    // and waits are written by hand: the wait at the end of the body is vmcnt(<stores of this
+    // channel>) -- the rows have arrived, the stores may still be in flight -- where the
+    // compiler's bookkeeping (loop entry merged with the back edge) would wait for vmcnt(0).
+    auto channel_loop_pf = [&](auto nit_tag) {
+      constexpr int NIT = decltype(nit_tag)::value;
+      constexpr int NST = PK ? 2 : 3;
+      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
+      float* po = a.out + obase + (long)wave * PP;
+      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
+      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
+      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
+      v2f v[NIT];
+      // (asm operands cannot name captures of a nested lambda: macros)
+#define SD_ROWS_ISSUE()                                                                          \
+  _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
+    const unsigned vo = voff[it];                                                                \
+    v2f r;                                                                                       \
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(r) : "v"(vo), "s"(pl));                \
+    v[it] = r;                                                                                   \
+  }
+#define SD_ROWS_ARRIVED(n)                                                                       \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n));                                                  \
+  _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
+    v2f r = v[it];                                                                               \
+    asm volatile("" : "+v"(r)); /* uses stay below the wait */                                   \
+    v[it] = r;                                                                                   \
+  }
+      if (wave < nch) {
+        SD_ROWS_ISSUE();
+        SD_ROWS_ARRIVED(0);
+      }
+      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
+        if (fill_lane) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it)
+            *reinterpret_cast<v2f*>(tile + fill_base + it * RPW * PITCH) = v[it];
+        }
+        if (c0 + NWAVE < nch) {  // (uniform)
+          pl += pstep;
+          SD_ROWS_ISSUE();
+        }
+        wave_lds_sync();
+        float maxval = init, bx = -1.f, by = -1.f;
+        int bk = -1;
+#pragma unroll
+        for (int kl = 0; kl < 4; ++kl) {
+          const int k = kl >> 1, l = kl & 1;
+          const float4 w = t.wts[kl * PP + bin];
+          const float2 top = *reinterpret_cast<const float2*>(rt[k] + l * 8);  // (TL, TR)
+          const float2 bot = *reinterpret_cast<const float2*>(rb[k] + l * 8);  // (BL, BR)
+          const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
+          if (value > maxval) {
+            maxval = value;
+            if (PK) {
+              bk = k * 3 + l;
+            } else {
+              bx = l ? cx1 : cx0;
+              by = k ? cy1 : cy0;
+            }
+          }
+        }
+        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+        // stores as "uniform base + 32-bit lane offset" (no 64-bit pointer per lane to keep)
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(bin * 4), "v"(maxval), "s"(po) : "memory");
+        if (PK) {
+          asm volatile("global_store_byte %0, %1, %2" ::"v"(bin), "v"(bk < 0 ? 255 : bk), "s"(pk) : "memory");
+        } else {
+          asm volatile("global_store_dword %0, %1, %2" ::"v"(bin * 4), "v"(bx), "s"(px) : "memory");
+          asm volatile("global_store_dword %0, %1, %2" ::"v"(bin * 4), "v"(by), "s"(py) : "memory");
+        }
+        wave_lds_sync();
+        SD_ROWS_ARRIVED(NST);
+        po += NWAVE * PP;
+        if (PK) {
+          pk += NWAVE * PPS;
+        } else {
+          px += NWAVE * PP;
+          py += NWAVE * PP;
+        }
+      }
+    };
+#undef SD_ROWS_ISSUE
+#undef SD_ROWS_ARRIVED
+    if (any_dup) {
+      channel_loop(std::integral_constant<int, ITER>{}, std::true_type{});
+    } else if (!(SD_ABLATE(a, 32))) {
+      switch (nit) {
+        case 1: channel_loop_pf(std::integral_constant<int, 1>{}); break;
+        case 2: channel_loop_pf(std::integral_constant<int, 2>{}); break;
+        case 3: channel_loop_pf(std::integral_constant<int, 3>{}); break;
+        case 4: channel_loop_pf(std::integral_constant<int, 4>{}); break;
+        case 5: channel_loop_pf(std::integral_constant<int, 5>{}); break;
+        case 6: channel_loop_pf(std::integral_constant<int, 6>{}); break;
+        default: channel_loop_pf(std::integral_constant<int, 7>{}); break;
+      }
+    } else {
+      switch (nit) {
+        case 1: channel_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
+        case 2: channel_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
+        case 3: channel_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
+        case 4: channel_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
+        case 5: channel_loop(std::integral_constant<int, 5>{}, std::false_type{}); break;
+        case 6: channel_loop(std::integral_constant<int, 6>{}, std::false_type{}); break;
+        default: channel_loop(std::integral_constant<int, 7>{}, std::false_type{}); break;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dense-window forward (7x7)
 // ------------------------------------------------------------------------------------------------
@@ -695,7 +1120,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 constexpr int DENSE_MAXIT = 5;                    // 16-byte loads per lane and channel
 constexpr int DENSE_CAPF = DENSE_MAXIT * 64 * 4;  // floats of one wave's window
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) V2u {
   v2f v;
 };
@@ -2152,6 +2576,10 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, false>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), padlds, st, a);
       else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, false>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
     }
+  } else if (variant == 4 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
+    const dim3 g(cdiv(nroi, 2) * a.nslice);
+    if (a.amax8) hipLaunchKernelGGL((roi_align_fwd_rows<7, 7, 2, true>), g, dim3(512), padlds, st, a);
+    else hipLaunchKernelGGL((roi_align_fwd_rows<7, 7, 2, false>), g, dim3(512), padlds, st, a);
   } else if (variant == 1 && a.amax8 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
     // packed arg-max (the fused op): the 64-VGPR build, four workgroups per CU
     hipLaunchKernelGGL((roi_align_fwd_tiled_lean<2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
