@@ -669,863 +669,20 @@ __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
 }
 
 // The same kernel held to 64 VGPRs (weights re-read from LDS per channel) and two RoIs of tables:
-// four workgroups = 8 waves per SIMD fit a CU instead of three.  The forward is latency bound
-// (1 -> 2 -> 3 workgroups per CU: 238 -> 149 -> 127 us in the profiling build).
+// four workgroups = 8 waves per SIMD fit a CU instead of three (1 -> 2 -> 3 -> 4 workgroups per
+// CU: 238 -> 149 -> 127 -> 110 us in the profiling build, 104 -> 98-100 us in the product).
+// Where the time goes at 4 workgroups per CU (rocprofv3 PMC, profiles/r02e_fwd_pmc.txt): the
+// texture-address unit is busy ~75-85% of the kernel (7 tap gathers + 2 stores per RoI x channel,
+// ~16 clocks each), 39% of the wave time is VMEM issue stall, LDS is ~40% busy and the VALU 38%.
+// What did not help, each bit-exact and measured: requesting the next channel's
+// taps before reducing this one, with hand-placed s_waitcnt so that store acknowledgements leave
+// the critical path (100.7 vs 100.8 us: not latency bound); fetching the RoI's window with
+// 16-byte loads (2.4 instead of 7 loads, 110 us) or only the distinct rows (5.4 loads, 108 us):
+// the per-lane-addressed LDS reads those need cost more than the gathers they save.
 template <int NROI, bool PK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_tiled_lean(
     FwdArgs a) {
   fwd_tiled_body<7, 7, NROI, PK, true>(a);
-}
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// ------------------------------------------------------------------------------------------------
-// row-compacted tiled forward (7x7)
-// ------------------------------------------------------------------------------------------------
-// The tiled kernel fetches 28 tile rows per (RoI, channel) -- (lo, hi) of two samples of seven
-// bins -- with seven 8-byte gathers, although the rows repeat: hi of one sample is lo of the next
-// whenever the bins are less than a pixel apart, and a RoI h feature rows tall has at most h + 2
-// distinct rows (median 17 at the baseline).  The texture-address unit is the busiest resource of
-// that kernel (~75-85%).  Here the distinct rows are listed once per RoI and only those are
-// fetched: ceil(distinct / 4) gathers (4.4 instead of 7 at the baseline), the same (left,right)
-// column pairs per row.  The tile is row major (row, pair) and the bin lanes read the top and the
-// bottom pair of a sample with two ds_read_b64 at addresses they compose from per-lane row and
-// column offsets.  Arithmetic and evaluation order are the tiled kernel's: bit-identical results.
-template <int PH, int PW, int NROI>
-struct RowsSmem {
-  static constexpr int NR = 4 * PH, NC = 4 * PW, PP = PH * PW, NWAVE = 8;
-  static constexpr int PITCH = NC / 2 * 2 + 2;  // floats per tile row: 14 pairs + 2 (bank spread)
-  static constexpr int CH = NR * PITCH;
-  __attribute__((aligned(16))) float tile[NWAVE * CH];
-  struct Roi {
-    float4 wts[4 * PP];     // [kl][bin]: (1-a)(1-b), a(1-b), (1-a)b, ab  (kl = 2k+l); x = NaN: none
-    int rowoff[NR];         // row * W, or -1 for an unused slot
-    int coloff[NC];
-    int crow[NR];           // tile row of the entry
-    int rowlist[NR];        // row * W of tile row r
-    float hval[2 * PH], alpha[2 * PH];
-    float wval[2 * PW], beta[2 * PW];
-    int hcnt[PH], wcnt[PW];
-    int binflag[PP];
-    int lvl, n, fb_row, fb_col, any_valid, nrd;
-    float box[4];
-  } roi[NROI];
-};
-
-template <int PH, int PW, int NROI, bool PK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_rows(
-    FwdArgs a) {
-  using S = RowsSmem<PH, PW, NROI>;
-  constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, CH = S::CH, NWAVE = S::NWAVE, PITCH = S::PITCH;
-  constexpr int PPS = amax_stride(PP);
-  constexpr int THREADS = NWAVE * kWave;
-  constexpr int NPAIR = NC / 2, RPW = kWave / NPAIR, ACT = RPW * NPAIR, ITER = NR / RPW;
-  static_assert(PP <= kWave && NR <= 32, "one bin per lane, row entries in half a wave");
-  static_assert(RPW == 4 && NR % RPW == 0 && ITER == 7, "fill geometry of the 7x7 tile");
-  static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
-  __shared__ S s;
-
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-  const int nslice = a.nslice;
-  const int grp = blockIdx.x / nslice, slice = blockIdx.x % nslice;
-  const int nroi_total = a.B * a.R;
-  const int nch = a.C / nslice;
-  const int cbeg = slice * nch;
-
-  // ---- per-RoI sample tables: wave 2i rows, wave 2i+1 columns of RoI i ----
-  if (wave < 2 * NROI) {
-    const int i = wave >> 1, slot = grp * NROI + i;
-    typename S::Roi& t = s.roi[i];
-    int lvl = -2, cnt = 0, n = 0;
-    if (slot < nroi_total) {
-      n = a.order ? a.order[slot] : slot;
-      const float* r = a.rois + (long)n * 4;
-      const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-      lvl = 0;
-      if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
-      if (lvl >= 0) {
-        const int H = a.L.H[lvl], W = a.L.W[lvl];
-        const float scale = a.L.scale[lvl];
-        if ((wave & 1) == 0 && lane < PH) {
-          cnt = axis_samples(lane, PH, y1, y2, scale, H, W, &t.hval[2 * lane], &t.alpha[2 * lane],
-                             &t.rowoff[4 * lane]);
-          t.hcnt[lane] = cnt;
-        } else if ((wave & 1) == 1 && lane < PW) {
-          cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
-                             &t.coloff[4 * lane]);
-          t.wcnt[lane] = cnt;
-        }
-      }
-      if ((wave & 1) == 0 && lane == 0) {
-        t.box[0] = x1; t.box[1] = y1; t.box[2] = x2; t.box[3] = y2;
-      }
-    }
-    const int fb = __any(cnt >= 3);
-    if (lane == 0) {
-      if (wave & 1) t.fb_col = fb;
-      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; t.n = n; }
-    }
-  }
-  __syncthreads();
-
-  // ---- distinct rows of RoI i, by wave NWAVE-1-i (the waves that did no axis table first):
-  // every entry looks for the first lane holding its row; the first holders are numbered with a
-  // ballot prefix and become the tile rows
-  if (wave >= NWAVE - NROI) {
-    typename S::Roi& t = s.roi[NWAVE - 1 - wave];
-    if (__builtin_amdgcn_readfirstlane(t.lvl) >= 0 && !__builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col)) {
-      const int rv = lane < NR ? t.rowoff[lane] : -1;
-      int first = -1;
-#pragma unroll 1
-      for (int e = 0; e < NR; ++e) {
-        const int re = __builtin_amdgcn_readlane(rv, e);
-        if (first < 0 && re == rv) first = e;
-      }
-      const bool isnew = rv >= 0 && first == lane;
-      const unsigned long long nb = __ballot(isnew);
-      const int cidx = __popcll(nb & ((1ull << (first < 0 ? 0 : first)) - 1ull));
-      if (lane < NR) t.crow[lane] = rv >= 0 ? cidx : 0;
-      if (isnew) t.rowlist[cidx] = rv;
-      if (lane == 0) t.nrd = __popcll(nb);
-    }
-  }
-  // ---- per (RoI, bin, k, l): weight products, shared by all channels ----
-  for (int e = tid; e < NROI * 4 * PP; e += THREADS) {
-    const int i = e / (4 * PP), tt = e % (4 * PP);
-    typename S::Roi& t = s.roi[i];
-    if (t.lvl < 0 || t.fb_row || t.fb_col) continue;
-    const int kl = tt / PP, bin = tt % PP, p = bin / PW, q = bin % PW, k = kl >> 1, l = kl & 1;
-    const bool valid = k < t.hcnt[p] && l < t.wcnt[q];
-    const float al = t.alpha[2 * p + k], be = t.beta[2 * q + l];
-    float4 w;
-    w.x = (1 - al) * (1 - be);
-    w.y = al * (1 - be);
-    w.z = (1 - al) * be;
-    w.w = al * be;
-    if (!valid) w.x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
-    t.wts[tt] = w;
-    if (kl == 0) t.binflag[bin] = (t.hcnt[p] >= 0 && t.wcnt[q] >= 0) ? 1 : 0;
-    if (__any(valid) && valid) t.any_valid = 1;  // benign same-value race
-  }
-  __syncthreads();
-  if (PK && slice == 0) {  // the sample coordinates the packed arg-max indexes, once per RoI
-    for (int e = tid; e < NROI * 3 * (PH + PW); e += THREADS) {
-      const int i = e / (3 * (PH + PW)), j = e % (3 * (PH + PW));
-      const typename S::Roi& t = s.roi[i];
-      if (t.lvl < 0) continue;
-      const bool row = j < 3 * PH;
-      const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
-      const int lv = t.lvl;
-      const float v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
-                          : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
-      float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
-      base[j] = v;
-      store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
-    }
-  }
-
-  // rare RoIs first (assigned to no level, or a 3-iteration sample loop), exact and simple
-#pragma unroll 1
-  for (int i = 0; i < NROI; ++i) {
-    const typename S::Roi& t = s.roi[i];
-    const int n = t.n;
-    const int lvl = t.lvl;
-    if (lvl == -2) break;
-    const long obase = ((long)n * a.C + cbeg) * PP;
-    const long abase = ((long)n * a.C + cbeg) * PPS;
-    const bool exact = t.fb_row || t.fb_col;
-    if (lvl < 0 || (!exact && !t.any_valid)) {  // every per-level op sees a zero box / nothing to pool
-      for (int e = tid; e < nch * PP; e += THREADS) {
-        a.out[obase + e] = 0.f;
-        if (PK) {
-          a.amax8[abase + (e / PP) * PPS + e % PP] = 255;
-        } else {
-          a.ax[obase + e] = -1.f;
-          a.ay[obase + e] = -1.f;
-        }
-      }
-    } else if (exact) {
-      const int H = a.L.H[lvl], W = a.L.W[lvl];
-      const long plane = (long)H * W;
-      const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
-      const float scale = a.L.scale[lvl];
-      for (int e = tid; e < nch * PP; e += THREADS) {
-        const int c = e / PP, bin = e % PP;
-        FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, t.box[0], t.box[1], t.box[2],
-                                      t.box[3], scale, bin / PW, bin % PW, PH, PW);
-        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
-        a.out[obase + e] = o.val;
-        if (PK) {
-          a.amax8[abase + c * PPS + bin] = (unsigned char)o.code;
-        } else {
-          a.ax[obase + e] = o.ax;
-          a.ay[obase + e] = o.ay;
-        }
-      }
-    }
-  }
-
-  // ===== from here on every wave runs on its own: no workgroup barrier =====
-  float* tile = s.tile + wave * CH;
-  const bool fill_lane = lane < ACT;
-  const int jp = lane % NPAIR, r0 = lane / NPAIR;
-  const int fill_base = r0 * PITCH + jp * 2;  // floats; + it * RPW * PITCH (an immediate)
-  const int bin = lane < PP ? lane : PP - 1;  // lanes past the last bin repeat it (same stores)
-  const int bp = bin / PW, bq = bin % PW;
-
-#pragma unroll 1
-  for (int i = 0; i < NROI; ++i) {
-    const typename S::Roi& t = s.roi[i];
-    const int n = __builtin_amdgcn_readfirstlane(t.n);
-    const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
-    if (lvl == -2) break;
-    if (lvl < 0 || __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col) ||
-        !__builtin_amdgcn_readfirstlane(t.any_valid))
-      continue;
-    const long obase = ((long)n * a.C + cbeg) * PP;
-    const long abase = ((long)n * a.C + cbeg) * PPS;
-    const int W = a.L.W[lvl];
-    const long plane = (long)a.L.H[lvl] * W;
-    const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
-    const long pstep = (long)NWAVE * plane * 4;
-    const int nrd = __builtin_amdgcn_readfirstlane(t.nrd);
-    const int nit = (nrd + RPW - 1) / RPW;
-
-    // ---- per-lane constants of this RoI ----
-    int dup = 0;
-    unsigned colbyte = 0;
-    bool colok = false;
-    if (fill_lane) {
-      const int cl = t.coloff[2 * jp], cr = t.coloff[2 * jp + 1];
-      if (cl >= 0) {
-        const int co = cl == cr ? (cl < W - 1 ? cl : W - 2) : cl;
-        dup = cl == cr ? (co == cl ? 1 : 2) : 0;
-        colbyte = (unsigned)co * 4u;
-        colok = true;
-      }
-    }
-    const bool any_dup = __any(dup != 0);
-    unsigned voff[ITER];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int rr = it * RPW + r0;
-      const bool ok = fill_lane && colok && rr < nrd;
-      voff[it] = ok ? (unsigned)t.rowlist[ok ? rr : 0] * 4u + colbyte : 0u;
-    }
-    // tile byte offsets of this lane's bin: rows of sample k (top, bottom), pair of sample l
-    // (the pair of sample l = 1 is the next 8 bytes: one ds_read2_b64 fetches both)
-    const char* tb = reinterpret_cast<const char*>(tile) + 2 * bq * 8;
-    const char* rt[2];
-    const char* rb[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      rt[k] = tb + t.crow[4 * bp + 2 * k] * (PITCH * 4);
-      rb[k] = tb + t.crow[4 * bp + 2 * k + 1] * (PITCH * 4);
-    }
-    const float init = t.binflag[bin] ? -FLT_MAX : 0.f;
-    const float cx0 = t.wval[2 * bq], cx1 = t.wval[2 * bq + 1];
-    const float cy0 = t.hval[2 * bp], cy1 = t.hval[2 * bp + 1];
-
-    auto channel_loop = [&](auto nit_tag, auto dup_tag) {
-      constexpr int NIT = decltype(nit_tag)::value;
-      constexpr bool kDup = decltype(dup_tag)::value;
-      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
-      // uniform bases + the lane's bin: stores are "SGPR base + 32-bit lane offset"
-      float* po = a.out + obase + (long)wave * PP;
-      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
-      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
-      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
-      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
-        F2u v[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (!kDup || it < nit) v[it] = *reinterpret_cast<const F2u*>(pl + voff[it]);
-        if (fill_lane) {
-#pragma unroll
-          for (int it = 0; it < NIT; ++it) {
-            if (kDup && it >= nit) continue;
-            float2 w2 = make_float2(v[it].x, v[it].y);
-            if (kDup) {
-              if (dup == 1) w2.y = w2.x;
-              if (dup == 2) w2.x = w2.y;
-            }
-            *reinterpret_cast<float2*>(tile + fill_base + it * RPW * PITCH) = w2;
-          }
-        }
-        wave_lds_sync();
-        float maxval = init, bx = -1.f, by = -1.f;
-        int bk = -1;
-#pragma unroll
-        for (int kl = 0; kl < 4; ++kl) {
-          const int k = kl >> 1, l = kl & 1;
-          const float4 w = t.wts[kl * PP + bin];
-          const float2 top = *reinterpret_cast<const float2*>(rt[k] + l * 8);  // (TL, TR)
-          const float2 bot = *reinterpret_cast<const float2*>(rb[k] + l * 8);  // (BL, BR)
-          const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
-          if (value > maxval) {
-            maxval = value;
-            if (PK) {
-              bk = k * 3 + l;
-            } else {
-              bx = l ? cx1 : cx0;
-              by = k ? cy1 : cy0;
-            }
-          }
-        }
-        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-        po[bin] = maxval;
-        if (PK) {
-          pk[bin] = (unsigned char)(bk < 0 ? 255 : bk);
-        } else {
-          px[bin] = bx;
-          py[bin] = by;
-        }
-        wave_lds_sync();
-        pl += pstep;
-        po += NWAVE * PP;
-        if (PK) {
-          pk += NWAVE * PPS;
-        } else {
-          px += NWAVE * PP;
-          py += NWAVE * PP;
-        }
-      }
-    };
-    // The same loop with the next channel's rows requested before this channel is reduced.  Loads
-    // and waits are written by hand: the wait at the end of the body is vmcnt(<stores of this
-    // channel>) -- the rows have arrived, the stores may still be in flight -- where the
-    // compiler's bookkeeping (loop entry merged with the back edge) would wait for vmcnt(0).
-    auto channel_loop_pf = [&](auto nit_tag) {
-      constexpr int NIT = decltype(nit_tag)::value;
-      constexpr int NST = PK ? 2 : 3;
-      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
-      float* po = a.out + obase + (long)wave * PP;
-      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
-      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
-      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
-      v2f v[NIT];
-      // (asm operands cannot name captures of a nested lambda: macros)
-#define SD_ROWS_ISSUE()                                                                          \
-  _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
-    const unsigned vo = voff[it];                                                                \
-    v2f r;                                                                                       \
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(r) : "v"(vo), "s"(pl));                \
-    v[it] = r;                                                                                   \
-  }
-#define SD_ROWS_ARRIVED(n)                                                                       \
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n));                                                  \
-  _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
-    v2f r = v[it];                                                                               \
-    asm volatile("" : "+v"(r)); /* uses stay below the wait */                                   \
-    v[it] = r;                                                                                   \
-  }
-      if (wave < nch) {
-        SD_ROWS_ISSUE();
-        SD_ROWS_ARRIVED(0);
-      }
-      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
-        if (fill_lane) {
-#pragma unroll
-          for (int it = 0; it < NIT; ++it)
-            *reinterpret_cast<v2f*>(tile + fill_base + it * RPW * PITCH) = v[it];
-        }
-        if (c0 + NWAVE < nch) {  // (uniform)
-          pl += pstep;
-          SD_ROWS_ISSUE();
-        }
-        wave_lds_sync();
-        float maxval = init, bx = -1.f, by = -1.f;
-        int bk = -1;
-#pragma unroll
-        for (int kl = 0; kl < 4; ++kl) {
-          const int k = kl >> 1, l = kl & 1;
-          const float4 w = t.wts[kl * PP + bin];
-          const float2 top = *reinterpret_cast<const float2*>(rt[k] + l * 8);  // (TL, TR)
-          const float2 bot = *reinterpret_cast<const float2*>(rb[k] + l * 8);  // (BL, BR)
-          const float value = w.x * top.x + w.y * bot.x + w.z * top.y + w.w * bot.y;
-          if (value > maxval) {
-            maxval = value;
-            if (PK) {
-              bk = k * 3 + l;
-            } else {
-              bx = l ? cx1 : cx0;
-              by = k ? cy1 : cy0;
-            }
-          }
-        }
-        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-        // stores as "uniform base + 32-bit lane offset" (no 64-bit pointer per lane to keep)
-        asm volatile("global_store_dword %0, %1, %2" ::"v"(bin * 4), "v"(maxval), "s"(po) : "memory");
-        if (PK) {
-          asm volatile("global_store_byte %0, %1, %2" ::"v"(bin), "v"(bk < 0 ? 255 : bk), "s"(pk) : "memory");
-        } else {
-          asm volatile("global_store_dword %0, %1, %2" ::"v"(bin * 4), "v"(bx), "s"(px) : "memory");
-          asm volatile("global_store_dword %0, %1, %2" ::"v"(bin * 4), "v"(by), "s"(py) : "memory");
-        }
-        wave_lds_sync();
-        SD_ROWS_ARRIVED(NST);
-        po += NWAVE * PP;
-        if (PK) {
-          pk += NWAVE * PPS;
-        } else {
-          px += NWAVE * PP;
-          py += NWAVE * PP;
-        }
-      }
-    };
-#undef SD_ROWS_ISSUE
-#undef SD_ROWS_ARRIVED
-    if (any_dup) {
-      channel_loop(std::integral_constant<int, ITER>{}, std::true_type{});
-    } else if (!(SD_ABLATE(a, 32))) {
-      switch (nit) {
-        case 1: channel_loop_pf(std::integral_constant<int, 1>{}); break;
-        case 2: channel_loop_pf(std::integral_constant<int, 2>{}); break;
-        case 3: channel_loop_pf(std::integral_constant<int, 3>{}); break;
-        case 4: channel_loop_pf(std::integral_constant<int, 4>{}); break;
-        case 5: channel_loop_pf(std::integral_constant<int, 5>{}); break;
-        case 6: channel_loop_pf(std::integral_constant<int, 6>{}); break;
-        default: channel_loop_pf(std::integral_constant<int, 7>{}); break;
-      }
-    } else {
-      switch (nit) {
-        case 1: channel_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
-        case 2: channel_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
-        case 3: channel_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
-        case 4: channel_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
-        case 5: channel_loop(std::integral_constant<int, 5>{}, std::false_type{}); break;
-        case 6: channel_loop(std::integral_constant<int, 6>{}, std::false_type{}); break;
-        default: channel_loop(std::integral_constant<int, 7>{}, std::false_type{}); break;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dense-window forward (7x7)
-// ------------------------------------------------------------------------------------------------
-// The tiled kernel above fetches every (left,right) tap pair of a RoI with its own 8-byte gather:
-// 7 wave-level loads per (RoI, channel), and the texture-address unit of the CU -- 16 clocks per
-// wave instruction whatever its width -- is its busiest resource (~60%).  Here a wave fetches the
-// RoI's WINDOW of the channel plane instead: the distinct rows its samples touch (at most 28, a
-// compacted list for tall RoIs) x the contiguous column range, 16 bytes per lane, 1-3 loads per
-// (RoI, channel) at the baseline, into a private LDS window whose pitch is an odd multiple of four
-// floats.  The 49 bin lanes read their taps straight out of the window (ds_read2_b32 of the
-// (left,right) pair, addresses held in registers).  Same arithmetic, same evaluation order,
-// bit-identical results.  The channel loop is instantiated per load count so that its body is
-// branch-free.  RoIs whose window does not fit (more than DENSE_MAXIT loads: extreme aspect
-// ratios) or whose window would have to be read past the end of the tensor take the exact
-// per-element path.
-constexpr int DENSE_MAXIT = 5;                    // 16-byte loads per lane and channel
-constexpr int DENSE_CAPF = DENSE_MAXIT * 64 * 4;  // floats of one wave's window
-
-struct __attribute__((packed, aligned(4))) V2u {
-  v2f v;
-};
-
-template <int PH, int PW, int NROI>
-struct DenseSmem {
-  static constexpr int NWAVE = 8;
-  __attribute__((aligned(16))) float stage[NWAVE * DENSE_CAPF];
-  struct Roi {
-    int rowidx[4 * PH];      // [p*4 + 2k + {lo,hi}] row index, -1 unused
-    int colidx[4 * PW];
-    int crow[4 * PH];        // window row of the entry (index into rowlist)
-    int rowlist[4 * PH];     // distinct rows of the window, ascending
-    float hval[2 * PH], alpha[2 * PH];
-    float wval[2 * PW], beta[2 * PW];
-    int hcnt[PH], wcnt[PW];
-    int lvl, n, fb_row, fb_col, fb_win, any_valid, any_dup;
-    int nr, c0w, nlr, pitch, nit, magic;
-    float box[4];
-  } roi[NROI];
-};
-
-template <int PH, int PW, int NROI, bool PK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void roi_align_fwd_dense(
-    FwdArgs a) {
-  using S = DenseSmem<PH, PW, NROI>;
-  constexpr int PP = PH * PW, NWAVE = S::NWAVE, THREADS = NWAVE * kWave, PPS = amax_stride(PP);
-  static_assert(PP <= kWave && 4 * PH <= 32 && 4 * PW <= 32, "one bin per lane, axis entries in half a wave");
-  static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
-  __shared__ S s;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-  const int nslice = a.nslice;
-  const int grp = blockIdx.x / nslice, slice = blockIdx.x % nslice;
-  const int nroi_total = a.B * a.R;
-  const int nch = a.C / nslice;
-  const int cbeg = slice * nch;
-
-  // ---- per-RoI sample tables: wave 2i rows, wave 2i+1 columns of RoI i ----
-  if (wave < 2 * NROI) {
-    const int i = wave >> 1, slot = grp * NROI + i;
-    typename S::Roi& t = s.roi[i];
-    int lvl = -2, cnt = 0, n = 0;
-    if (slot < nroi_total) {
-      n = a.order ? a.order[slot] : slot;
-      const float* r = a.rois + (long)n * 4;
-      const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-      lvl = 0;
-      if (a.L.nlvl > 1) lvl = fpn_level(x1, y1, x2, y2, a.L);
-      if (lvl >= 0) {
-        const int H = a.L.H[lvl], W = a.L.W[lvl];
-        const float scale = a.L.scale[lvl];
-        if ((wave & 1) == 0 && lane < PH) {
-          cnt = axis_samples(lane, PH, y1, y2, scale, H, 1, &t.hval[2 * lane], &t.alpha[2 * lane],
-                             &t.rowidx[4 * lane]);
-          t.hcnt[lane] = cnt;
-        } else if ((wave & 1) == 1 && lane < PW) {
-          cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
-                             &t.colidx[4 * lane]);
-          t.wcnt[lane] = cnt;
-        }
-      }
-      if ((wave & 1) == 0 && lane == 0) {
-        t.box[0] = x1; t.box[1] = y1; t.box[2] = x2; t.box[3] = y2;
-      }
-    }
-    const int fb = __any(cnt >= 3);
-    if (lane == 0) {
-      if (wave & 1) t.fb_col = fb;
-      else { t.fb_row = fb; t.lvl = lvl; t.n = n; }
-    }
-  }
-  __syncthreads();
-  // ---- window of RoI i, by wave i: lanes 0..27 hold the row entries, the same lanes the column
-  // entries.  The distinct rows are numbered with a ballot prefix over "first lane holding it".
-  if (wave < NROI) {
-    typename S::Roi& t = s.roi[wave];
-    const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
-    const int fbt = __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col);
-    int any_valid = 0, fb_win = 0, any_dup = 0, nr = 0, c0w = 0, nlr = 1, pitch = 4, nit = 1;
-    if (lvl >= 0 && !fbt) {
-      const int rv = lane < 4 * PH ? t.rowidx[lane] : -1;
-      const int cv = lane < 4 * PW ? t.colidx[lane] : -1;
-      // entries are NOT monotone (floor of the second sample may lie below ceil of the first):
-      // every entry looks for the first lane that holds its row
-      int first = -1;
-#pragma unroll 1
-      for (int e = 0; e < 4 * PH; ++e) {
-        const int re = __builtin_amdgcn_readlane(rv, e);
-        if (first < 0 && re == rv) first = e;
-      }
-      const bool isnew = rv >= 0 && first == lane;
-      const unsigned long long nb = __ballot(isnew), cb = __ballot(cv >= 0);
-      if (nb != 0 && cb != 0) {
-        any_valid = 1;
-        const int cidx = __popcll(nb & ((1ull << (first < 0 ? 0 : first)) - 1ull));  // rank of the first holder
-        if (lane < 4 * PH) t.crow[lane] = rv >= 0 ? cidx : 0;
-        if (isnew) t.rowlist[cidx] = rv;
-        nr = __popcll(nb);
-        const int c0 = __builtin_amdgcn_readlane(cv, __ffsll((long long)cb) - 1);
-        const int c1 = __builtin_amdgcn_readlane(cv, 63 - __clzll((long long)cb));
-        const int W = a.L.W[lvl], H = a.L.H[lvl];
-        nlr = (c1 - c0) / 4 + 1;
-        pitch = 4 * (nlr | 1);  // odd multiple of 4 floats
-        // the window is moved left when its last piece would reach past the row, so that no load
-        // leaves the plane; when the plane is narrower than the window the pieces of a row run
-        // into the next row (harmless) -- except on the last row of the plane
-        c0w = c0 < W - 4 * nlr ? c0 : W - 4 * nlr;
-        const int rlast = __builtin_amdgcn_readlane(rv, 63 - __clzll((long long)__ballot(rv >= 0)));
-        if (c0w < 0) {
-          c0w = 0;
-          if (rlast == H - 1) fb_win = 1;
-        }
-        nit = (nr * nlr + kWave - 1) / kWave;
-        if (nit > DENSE_MAXIT || nr * pitch > DENSE_CAPF) fb_win = 1;
-        // a sample on an integer column reads the same tap twice
-        const int cnext = lane + 1 < 4 * PW ? t.colidx[lane + 1] : -1;
-        any_dup = __any((lane & 1) == 0 && cv >= 0 && cv == cnext);
-      }
-    }
-    if (lane == 0) {
-      t.any_valid = any_valid; t.fb_win = fb_win; t.any_dup = any_dup;
-      t.nr = nr; t.c0w = c0w; t.nlr = nlr; t.pitch = pitch; t.nit = nit;
-      t.magic = (65536 + nlr - 1) / nlr;  // g / nlr == (g * magic) >> 16 for g < 512, nlr <= 32
-    }
-  }
-  __syncthreads();
-  if (PK && slice == 0) {  // the sample coordinates the packed arg-max indexes, once per RoI
-    for (int e = tid; e < NROI * 3 * (PH + PW); e += THREADS) {
-      const int i = e / (3 * (PH + PW)), j = e % (3 * (PH + PW));
-      const typename S::Roi& t = s.roi[i];
-      if (t.lvl < 0) continue;
-      const bool row = j < 3 * PH;
-      const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
-      const int lv = t.lvl;
-      const float v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
-                          : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
-      float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
-      base[j] = v;
-      store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
-    }
-  }
-
-  // rare RoIs first (assigned to no level, nothing to pool, 3-iteration sample loop, window that
-  // does not fit): exact and simple, by the whole workgroup
-#pragma unroll 1
-  for (int i = 0; i < NROI; ++i) {
-    const typename S::Roi& t = s.roi[i];
-    const int n = t.n, lvl = t.lvl;
-    if (lvl == -2) break;
-    const long obase = ((long)n * a.C + cbeg) * PP;
-    const long abase = ((long)n * a.C + cbeg) * PPS;
-    const bool exact = t.fb_row || t.fb_col || t.fb_win;
-    if (lvl < 0 || (!t.any_valid && !exact)) {
-      for (int e = tid; e < nch * PP; e += THREADS) {
-        a.out[obase + e] = 0.f;
-        if (PK) {
-          a.amax8[abase + (e / PP) * PPS + e % PP] = 255;
-        } else {
-          a.ax[obase + e] = -1.f;
-          a.ay[obase + e] = -1.f;
-        }
-      }
-    } else if (exact) {
-      if (SD_ABLATE(a, 8)) continue;  // profiling build: skip the exact path
-      const int H = a.L.H[lvl], W = a.L.W[lvl];
-      const long plane = (long)H * W;
-      const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
-      const float scale = a.L.scale[lvl];
-      for (int e = tid; e < nch * PP; e += THREADS) {
-        const int c = e / PP, bin = e % PP;
-        FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, t.box[0], t.box[1], t.box[2],
-                                      t.box[3], scale, bin / PW, bin % PW, PH, PW);
-        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
-        a.out[obase + e] = o.val;
-        if (PK) {
-          a.amax8[abase + c * PPS + bin] = (unsigned char)o.code;
-        } else {
-          a.ax[obase + e] = o.ax;
-          a.ay[obase + e] = o.ay;
-        }
-      }
-    }
-  }
-
-  // ===== from here on every wave runs on its own: no workgroup barrier =====
-  const bool tuning_pf = !(SD_ABLATE(a, 32));  // profiling build: 32 = no prefetch loops
-  float* win = s.stage + wave * DENSE_CAPF;
-  const int bin = lane < PP ? lane : PP - 1;  // lanes past the last bin repeat it (same stores)
-  const int p = bin / PW, q = bin % PW;
-#pragma unroll 1
-  for (int i = 0; i < NROI; ++i) {
-    const typename S::Roi& t = s.roi[i];
-    const int n = __builtin_amdgcn_readfirstlane(t.n);
-    const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
-    if (lvl == -2) break;
-    if (lvl < 0 || !__builtin_amdgcn_readfirstlane(t.any_valid) ||
-        __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col | t.fb_win))
-      continue;
-    const long obase = ((long)n * a.C + cbeg) * PP;
-    const long abase = ((long)n * a.C + cbeg) * PPS;
-    const int W = a.L.W[lvl];
-    const long plane = (long)a.L.H[lvl] * W;
-    const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
-    const long pstep = (long)NWAVE * plane * 4;  // bytes between this wave's channels
-    const int nr = __builtin_amdgcn_readfirstlane(t.nr), nlr = __builtin_amdgcn_readfirstlane(t.nlr);
-    const int c0w = __builtin_amdgcn_readfirstlane(t.c0w), pitch = __builtin_amdgcn_readfirstlane(t.pitch);
-    const int magic = __builtin_amdgcn_readfirstlane(t.magic);
-    int nit = __builtin_amdgcn_readfirstlane(t.nit);
-    if (SD_ABLATE(a, 2)) nit = 1;  // profiling build: one window load per channel
-
-    // ---- load plan of this lane: piece g = it*64 + lane -> 16 bytes `sg` of window row `j` ----
-    unsigned voff[DENSE_MAXIT];
-    int loff[DENSE_MAXIT];  // LDS byte offset inside the window
-    const int npiece = nr * nlr;
-#pragma unroll
-    for (int it = 0; it < DENSE_MAXIT; ++it) {
-      const int g = it * kWave + lane;
-      const int j = (g * magic) >> 16, sg = g - j * nlr;
-      const bool ok = g < npiece;
-      const int row = t.rowlist[ok ? j : 0];
-      voff[it] = ok ? (unsigned)((row * W + c0w + 4 * sg) * 4) : 0u;
-      loff[it] = ok ? (j * pitch + 4 * sg) * 4 : -1;
-    }
-    // ---- this lane's bin: window addresses of its samples, weights, coordinates ----
-    int atop[4], abot[4];
-    bool cdup[2];
-    v2f wT[4], wB[4];  // (TL, TR) and (BL, BR) weight products of sample kl
-    float cxv[2], cyv[2];
-#pragma unroll
-    for (int kl = 0; kl < 4; ++kl) {
-      const int k = kl >> 1, l = kl & 1;
-      const int cl = t.colidx[4 * q + 2 * l], cr = t.colidx[4 * q + 2 * l + 1];
-      const int cofs = (cl < 0 ? c0w : cl) - c0w;
-      atop[kl] = (t.crow[4 * p + 2 * k] * pitch + cofs) * 4;
-      abot[kl] = (t.crow[4 * p + 2 * k + 1] * pitch + cofs) * 4;
-      if (SD_ABLATE(a, 16)) atop[kl] = abot[kl] = 0;  // profiling build: conflict-free reads
-      cdup[l] = cl == cr;
-      const bool valid = k < t.hcnt[p] && l < t.wcnt[q];
-      const float al = t.alpha[2 * p + k], be = t.beta[2 * q + l];
-      wT[kl].x = (1 - al) * (1 - be);
-      wB[kl].x = al * (1 - be);
-      wT[kl].y = (1 - al) * be;
-      wB[kl].y = al * be;
-      if (!valid) wT[kl].x = __int_as_float(0x7fc00000);  // NaN marks "no such sample"
-      cxv[l] = t.wval[2 * q + l];
-      cyv[k] = t.hval[2 * p + k];
-    }
-    const float init = (t.hcnt[p] >= 0 && t.wcnt[q] >= 0) ? -FLT_MAX : 0.f;
-    const char* winb = reinterpret_cast<const char*>(win);
-
-    auto channel_loop = [&](auto nit_tag, auto dup_tag) {
-      constexpr int NIT = decltype(nit_tag)::value;
-      constexpr bool kDup = decltype(dup_tag)::value;
-      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
-      float* po = a.out + obase + (long)wave * PP + bin;
-      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP + bin;
-      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP + bin;
-      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS + bin : nullptr;
-      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
-        F4u v[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const F4u*>(pl + voff[it]);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          // only the last load has lanes without a piece (the coincident-column instance runs
-          // with the maximum load count whatever the window: every load is checked there)
-          if ((!kDup && it < NIT - 1) || loff[it] >= 0)
-            *reinterpret_cast<float4*>(reinterpret_cast<char*>(win) + loff[it]) =
-                make_float4(v[it].x, v[it].y, v[it].z, v[it].w);
-        }
-        wave_lds_sync();
-        float maxval = init, bx = -1.f, by = -1.f;
-        int bk = -1;
-#pragma unroll
-        for (int kl = 0; kl < 4; ++kl) {
-          v2f top = reinterpret_cast<const V2u*>(winb + atop[kl])->v;
-          v2f bot = reinterpret_cast<const V2u*>(winb + abot[kl])->v;
-          if (kDup && cdup[kl & 1]) {
-            top.y = top.x;
-            bot.y = bot.x;
-          }
-          const v2f pt = wT[kl] * top, pb = wB[kl] * bot;
-          const float value = ((pt.x + pb.x) + pt.y) + pb.y;  // the reference's order: TL, BL, TR, BR
-          if (value > maxval) {
-            maxval = value;
-            if (PK) {
-              bk = (kl >> 1) * 3 + (kl & 1);
-            } else {
-              bx = cxv[kl & 1];
-              by = cyv[kl >> 1];
-            }
-          }
-        }
-        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-        *po = maxval;
-        if (PK) {
-          *pk = (unsigned char)(bk < 0 ? 255 : bk);
-        } else {
-          *px = bx;
-          *py = by;
-        }
-        wave_lds_sync();
-        pl += pstep;
-        po += NWAVE * PP;
-        if (PK) {
-          pk += NWAVE * PPS;
-        } else {
-          px += NWAVE * PP;
-          py += NWAVE * PP;
-        }
-      }
-    };
-    // Small windows (<= 3 loads): the next channel's window is requested before this one is
-    // reduced.  Loads and waits are written by hand so that the wait at the end of the body is
-    // vmcnt(<stores of this channel>): the window has arrived, the stores may still be in flight
-    // (the compiler's own bookkeeping merges the loop entry with the back edge into vmcnt(0)).
-    auto channel_loop_pf = [&](auto nit_tag) {
-      constexpr int NIT = decltype(nit_tag)::value;
-      static_assert(NIT >= 1 && NIT <= 3, "prefetch variant");
-      constexpr int NST = PK ? 2 : 3;
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      v4f r0, r1, r2;
-      const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
-      auto issue = [&]() {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r0) : "v"(voff[0]), "s"(pl));
-        if (NIT > 1) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r1) : "v"(voff[1]), "s"(pl));
-        if (NIT > 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r2) : "v"(voff[2]), "s"(pl));
-      };
-      float* po = a.out + obase + (long)wave * PP + bin;
-      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP + bin;
-      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP + bin;
-      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS + bin : nullptr;
-      char* wb = reinterpret_cast<char*>(win);
-      if (wave < nch) {
-        issue();
-        if (NIT == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0));
-        if (NIT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1));
-        if (NIT == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2));
-      }
-      for (int c0 = wave; c0 < nch; c0 += NWAVE) {
-        if (NIT > 1 || loff[0] >= 0) *reinterpret_cast<v4f*>(wb + loff[0]) = r0;
-        if (NIT == 2 && loff[1] >= 0) *reinterpret_cast<v4f*>(wb + loff[1]) = r1;
-        if (NIT > 2) *reinterpret_cast<v4f*>(wb + loff[1]) = r1;
-        if (NIT == 3 && loff[2] >= 0) *reinterpret_cast<v4f*>(wb + loff[2]) = r2;
-        pl += (c0 + NWAVE < nch) ? pstep : 0;  // the last iteration re-requests its own plane
-        issue();
-        wave_lds_sync();
-        float maxval = init, bx = -1.f, by = -1.f;
-        int bk = -1;
-#pragma unroll
-        for (int kl = 0; kl < 4; ++kl) {
-          const v2f top = reinterpret_cast<const V2u*>(winb + atop[kl])->v;
-          const v2f bot = reinterpret_cast<const V2u*>(winb + abot[kl])->v;
-          const v2f pt = wT[kl] * top, pb = wB[kl] * bot;
-          const float value = ((pt.x + pb.x) + pt.y) + pb.y;
-          if (value > maxval) {
-            maxval = value;
-            if (PK) {
-              bk = (kl >> 1) * 3 + (kl & 1);
-            } else {
-              bx = cxv[kl & 1];
-              by = cyv[kl >> 1];
-            }
-          }
-        }
-        if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-        *po = maxval;
-        if (PK) {
-          *pk = (unsigned char)(bk < 0 ? 255 : bk);
-        } else {
-          *px = bx;
-          *py = by;
-        }
-        wave_lds_sync();
-        if (NIT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "n"(NST));
-        if (NIT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(NST));
-        if (NIT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(NST));
-        po += NWAVE * PP;
-        if (PK) {
-          pk += NWAVE * PPS;
-        } else {
-          px += NWAVE * PP;
-          py += NWAVE * PP;
-        }
-      }
-    };
-    const bool pf = tuning_pf;
-    if (__builtin_amdgcn_readfirstlane(t.any_dup)) {
-      channel_loop(std::integral_constant<int, DENSE_MAXIT>{}, std::true_type{});
-    } else if (pf && nit <= 3) {
-      switch (nit) {
-        case 1: channel_loop_pf(std::integral_constant<int, 1>{}); break;
-        case 2: channel_loop_pf(std::integral_constant<int, 2>{}); break;
-        default: channel_loop_pf(std::integral_constant<int, 3>{}); break;
-      }
-    } else {
-      switch (nit) {
-        case 1: channel_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
-        case 2: channel_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
-        case 3: channel_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
-        case 4: channel_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
-        default: channel_loop(std::integral_constant<int, 5>{}, std::false_type{}); break;
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2536,8 +1693,8 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
                       size_t workspace_bytes = 0) {
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
-  // 0 naive, 1 tiled (default; the 64-VGPR build for the packed 7x7 path), 2 dense window (7x7),
-  // 3 tiled without the 64-VGPR build
+  // 0 naive, 1 tiled (default; the 64-VGPR build for the packed 7x7 path), 3 tiled without the
+  // 64-VGPR build
   const int variant = tuning("roi_align_fwd", 1);
   a.ablate = SD_PROF_TUNING("roi_align_fwd_ablate", 0);
   const int nroi = a.B * a.R;
@@ -2567,20 +1724,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
   const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
   const int padlds = SD_PROF_TUNING("roi_align_fwd_padlds", 0);  // profiling build: occupancy sweep
-  if (variant == 2 && wide && a.PH == 7 && a.PW == 7) {
-    const int nr2 = rpw >= 4 ? 4 : 2;
-    if (a.amax8) {
-      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, true>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), padlds, st, a);
-      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
-    } else {
-      if (nr2 == 4) hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 4, false>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), padlds, st, a);
-      else hipLaunchKernelGGL((roi_align_fwd_dense<7, 7, 2, false>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
-    }
-  } else if (variant == 4 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
-    const dim3 g(cdiv(nroi, 2) * a.nslice);
-    if (a.amax8) hipLaunchKernelGGL((roi_align_fwd_rows<7, 7, 2, true>), g, dim3(512), padlds, st, a);
-    else hipLaunchKernelGGL((roi_align_fwd_rows<7, 7, 2, false>), g, dim3(512), padlds, st, a);
-  } else if (variant == 1 && a.amax8 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
+  if (variant == 1 && a.amax8 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
     // packed arg-max (the fused op): the 64-VGPR build, four workgroups per CU
     hipLaunchKernelGGL((roi_align_fwd_tiled_lean<2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
   } else if (variant >= 1 && wide && a.PH == 7 && a.PW == 7) {

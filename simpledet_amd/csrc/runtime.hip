@@ -28,7 +28,7 @@ struct Knob {
 };
 // every knob a kernel launcher reads must be listed here (sd_set_tuning rejects unknown keys)
 Knob g_knobs[] = {
-    {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default), 2 dense window, 3 tiled 3 WG/CU
+    {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default), 3 tiled at 3 WG/CU
 #ifdef SD_PROFILING
     {"roi_align_fwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
     {"roi_align_bwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
