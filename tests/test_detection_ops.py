@@ -39,11 +39,17 @@ def test_roi_pool_reference_docstring_golden_on_gpu(ops):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(0, 7, 7, 1 / 32.0), (1, 7, 7, 1 / 16.0), (2, 3, 5, 1 / 32.0),
                                   (3, 14, 14, 1 / 32.0)])
-def test_roi_pool_forward_backward(ops, oracle, case):
+@pytest.mark.parametrize("fwd", [1, 0])  # plane in LDS (default), wave per (roi, channel)
+def test_roi_pool_forward_backward(ops, oracle, case, fwd):
+    from simpledet_amd._lib import lib
     seed, ph, pw, scale = case
     data, rois = _pool_case(seed)
     want, widx = oracle.roi_pool_v1_fwd(data, rois, (ph, pw), scale)
-    out, idx = ops.roi_pool_v1_forward(_t(data), _t(rois), (ph, pw), scale)
+    lib().set_tuning("roi_pool_fwd", fwd)
+    try:
+        out, idx = ops.roi_pool_v1_forward(_t(data), _t(rois), (ph, pw), scale)
+    finally:
+        lib().set_tuning("roi_pool_fwd", 1)
     np.testing.assert_array_equal(out.cpu().numpy(), want)
     np.testing.assert_array_equal(idx.cpu().numpy(), widx)
     dy = np.random.RandomState(9).standard_normal(want.shape).astype(np.float32)
@@ -57,6 +63,29 @@ def test_roi_pool_forward_backward(ops, oracle, case):
     np.testing.assert_allclose(dx2.cpu().numpy(), 2 * wdx, rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError, match="kWriteInplace"):
         ops.roi_pool_v1_backward(_t(dy), _t(rois), idx, data.shape, scale, req_data=2)
+
+
+@pytest.mark.gpu
+def test_roi_pool_forward_kernels_agree_at_c4_size(ops):
+    """C4 baseline shape (1024 RoIs x 1024 channels on a 50x84 map, two images, a few batch indices
+    out of range, more RoIs than one 512-RoI chunk): the plane-in-LDS kernel and the
+    wave-per-(roi, channel) kernel give the same bits."""
+    import torch
+    from simpledet_amd._lib import lib
+    g = torch.Generator(device="cuda").manual_seed(5)
+    data = torch.randn((2, 1024, 50, 84), device="cuda", generator=g)
+    r = synth.random_rois(5, 1, 1024)[0]
+    bi = np.random.RandomState(5).randint(0, 2, (1024, 1)).astype(np.float32)
+    bi[[7, 600]] = [[5.0], [-2.0]]
+    rois = _t(np.concatenate([bi, r], 1))
+    o1, i1 = ops.roi_pool_v1_forward(data, rois, (7, 7), 1 / 16.0)
+    lib().set_tuning("roi_pool_fwd", 0)
+    try:
+        o0, i0 = ops.roi_pool_v1_forward(data, rois, (7, 7), 1 / 16.0)
+    finally:
+        lib().set_tuning("roi_pool_fwd", 1)
+    assert torch.equal(o1, o0) and torch.equal(i1, i0)
+    assert float(o1[[7, 600]].abs().max()) == 0 and float((i1[[7, 600]] + 1).abs().max()) == 0
 
 
 @pytest.mark.gpu
