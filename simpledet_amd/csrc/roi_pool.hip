@@ -84,24 +84,28 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(PoolArgs a) {
 // Plane-resident forward: workgroup = (channel, image).  The channel plane (H*W floats, 16.8 KB on
 // the C4 shape) is read ONCE, coalesced, into LDS; the image's RoIs are listed in chunks of 256
 // with their bin boundaries per axis (PH + PW packed (start, end) pairs: 14 instead of 4 x 49
-// floor/ceil/clamp evaluations per RoI); then thread <- (RoI, bin) items in output order: every
-// visited pixel is one ds_read_b32 instead of one uncoalesced global load (435 M visits for
-// 1024 RoIs x 1024 channels, ~16 clocks of the texture-address unit per wave load before).  Same
-// scan order per bin (rows, then columns, strict >) as the reference: identical values and
-// arg-max.
+// floor/ceil/clamp evaluations per RoI) and the largest bin extent per axis; then wave <- RoI,
+// lane <- bin: every visited pixel is one ds_read_b32 instead of one uncoalesced global load
+// (435 M visits for 1024 RoIs x 1024 channels, ~16 clocks of the texture-address unit per wave
+// load before).  The scan loops run to the RoI's largest bin extent -- wave-uniform trip counts,
+// loop control on the scalar unit -- and a lane whose bin is smaller re-reads its last row /
+// column: an equal value never wins the strict comparison, so every bin still sees the
+// reference's scan order (rows, then columns, strict >) and gives identical values and arg-max.
+// (The first version ran per-lane loops: 95% VALU-busy, 11 VALU per LDS read.)
 constexpr int kPoolChunk = 256;
 
 template <int PHc, int PWc>  // 0, 0: runtime pooled size
 __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
-  constexpr int T = 512, CHUNK = kPoolChunk;
+  constexpr int T = 512, CHUNK = kPoolChunk, NWAVE = T / kWave;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int HW = a.H * a.W;
   const int PH = PHc ? PHc : a.PH, PW = PWc ? PWc : a.PW, PP = PH * PW;
-  const int ES = 2 + PH + PW;  // table words per RoI: index, valid, PH row pairs, PW column pairs
+  const int ES = 4 + PH + PW;  // table words per RoI: index, valid, max extents, row / column pairs
   float* plane = smem;
   int* tab = reinterpret_cast<int*>(smem + ((HW + 3) & ~3));
   __shared__ int cnt;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   // Workgroup i runs on XCD i % 8, and the 196-byte output rows of neighbouring channels share
   // cache lines: neighbouring channels go to the SAME XCD so that one L2 assembles whole lines
   // (channel = XCD's eighth of the range + position within it).
@@ -132,14 +136,17 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
         const int len = imaxr(end - start + 1, 1);
         const int P = axis ? PW : PH, size = axis ? a.W : a.H;
         const float bin_size = (float)len / (float)P;
-        int* dst = e + 2 + (axis ? PH : 0);
+        int* dst = e + 4 + (axis ? PH : 0);
+        int ext = 0;
         for (int p = 0; p < P; ++p) {
           int lo = (int)floorf((float)p * bin_size);
           int hi = (int)ceilf((float)(p + 1) * bin_size);
           lo = iminr(imaxr(lo + start, 0), size);
           hi = iminr(imaxr(hi + start, 0), size);
           dst[p] = lo | (hi << 16);
+          ext = imaxr(ext, hi - lo);
         }
+        e[2 + axis] = ext;
         if (axis == 0) {
           e[0] = k;
           e[1] = batch_ok;
@@ -147,37 +154,45 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
       }
     }
     __syncthreads();
-    const int nitem = cnt * PP;
-    for (int idx = tid; idx < nitem; idx += T) {
-      const int ri = idx / PP, bin = idx - ri * PP;
-      const int ph = bin / PW, pw = bin - ph * PW;
+    const int n = cnt;
+    for (int ri = wave; ri < n; ri += NWAVE) {
       const int* e = tab + ES * ri;
-      const int hb = e[2 + ph], wb = e[2 + PH + pw];
-      const int hstart = hb & 0xffff, hend = hb >> 16, wstart = wb & 0xffff, wend = wb >> 16;
-      const bool is_empty = (hend <= hstart) || (wend <= wstart) || !e[1];
-      float maxval = is_empty ? 0.f : -FLT_MAX;
-      int maxi = -1;
-      if (!is_empty) {
-        for (int h = hstart; h < hend; ++h) {
-          const float* row = plane + h * a.W;
-          const int ib = h * a.W;
-          int w = wstart;
-          for (; w + 4 <= wend; w += 4) {  // four ds_read_b32 with immediate offsets
-            const float v0 = row[w], v1 = row[w + 1], v2 = row[w + 2], v3 = row[w + 3];
-            if (v0 > maxval) { maxval = v0; maxi = ib + w; }
-            if (v1 > maxval) { maxval = v1; maxi = ib + w + 1; }
-            if (v2 > maxval) { maxval = v2; maxi = ib + w + 2; }
-            if (v3 > maxval) { maxval = v3; maxi = ib + w + 3; }
-          }
-          for (; w < wend; ++w) {
+      const long obase = ((long)__builtin_amdgcn_readfirstlane(e[0]) * a.C + c) * PP;
+      const bool valid = __builtin_amdgcn_readfirstlane(e[1]) != 0;
+      const int hext = __builtin_amdgcn_readfirstlane(e[2]), wext = __builtin_amdgcn_readfirstlane(e[3]);
+      for (int bin0 = 0; bin0 < PP; bin0 += kWave) {
+        const int bin = bin0 + lane;
+        const bool active = bin < PP;
+        const int bb = active ? bin : 0;
+        const int ph = bb / PW, pw = bb - ph * PW;
+        const int hb = e[4 + ph], wb = e[4 + PH + pw];
+        int hstart = hb & 0xffff, hend = hb >> 16, wstart = wb & 0xffff, wend = wb >> 16;
+        const bool is_empty = (hend <= hstart) || (wend <= wstart) || !valid;
+        if (is_empty) {  // scans pixel (0, 0), result discarded
+          hstart = wstart = 0;
+          hend = wend = 1;
+        }
+        const int hl = hend - 1, wl = wend - 1;
+        float maxval = -FLT_MAX;
+        int maxi = -1;
+        for (int dh = 0; dh < hext; ++dh) {
+          const int ib = iminr(hstart + dh, hl) * a.W;
+          const float* row = plane + ib;
+#pragma unroll 4
+          for (int dw = 0; dw < wext; ++dw) {
+            const int w = iminr(wstart + dw, wl);
             const float v = row[w];
-            if (v > maxval) { maxval = v; maxi = ib + w; }
+            if (v > maxval) {
+              maxval = v;
+              maxi = ib + w;
+            }
           }
         }
+        if (active) {
+          a.out[obase + bin] = is_empty ? 0.f : maxval;
+          a.maxidx[obase + bin] = (float)(is_empty ? -1 : maxi);
+        }
       }
-      const long o = ((long)e[0] * a.C + c) * PP + bin;
-      a.out[o] = maxval;
-      a.maxidx[o] = (float)maxi;
     }
   }
 }
@@ -256,7 +271,7 @@ extern "C" int sd_roi_pool_v1_fwd(const float* data, const float* rois, float* o
   if ((long)K * C == 0) return SD_OK;
   SD_REQUIRE(data && rois && out && maxidx, "null tensor pointer");
   PoolArgs a{data, rois, out, maxidx, B, C, H, W, K, pooled_h, pooled_w, spatial_scale};
-  const size_t lds = (size_t)((((long)H * W + 3) & ~3L) + kPoolChunk * (2 + pooled_h + pooled_w)) * 4;
+  const size_t lds = (size_t)((((long)H * W + 3) & ~3L) + kPoolChunk * (4 + pooled_h + pooled_w)) * 4;
   if (lds <= 64 * 1024 && H <= 32767 && W <= 32767 && B >= 1 && B <= 65535 &&
       tuning("roi_pool_fwd", 1) == 1) {
     // (with B == 0 every batch index is out of range: the wave-per-item kernel writes the zeros)
