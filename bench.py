@@ -269,11 +269,18 @@ def main():
     for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))[::-1]:
         try:
             ks = json.load(open(pmc_path))["kernels"]
-            for name, d in ks.items():
-                if "roi_align_fwd" in name and "fetch_bytes_x2_gfx950" in d and traffic is None:
-                    traffic = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
-                if "roi_align_bwd" in name and "fetch_bytes_x2_gfx950" in d and bwd_traffic is None:
-                    bwd_traffic = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
+            # the step's kernel is the most-dispatched forward / backward kernel of the profile
+            # (the per-level kernels of the --extra leg run a handful of times)
+            for pat in ("roi_align_fwd", "roi_align_bwd"):
+                cand = [(d.get("n_dispatch", 0), d) for name, d in ks.items()
+                        if pat in name and "fetch_bytes_x2_gfx950" in d]
+                if cand:
+                    d = max(cand, key=lambda t: t[0])[1]
+                    tot = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
+                    if pat == "roi_align_fwd":
+                        traffic = tot
+                    else:
+                        bwd_traffic = tot
             if traffic is not None:
                 traffic_source = ("%s (rocprofv3 --pmc passes of this command at commit time; "
                                   "not re-measured in this run)" % os.path.relpath(pmc_path, ROOT))
@@ -281,7 +288,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "kernel": "sd::roi_align_fwd_tiled<7,7,4,1> (fused FPN forward, 1 launch/step)",
+        "kernel": "sd::roi_align_fwd_tiled_lean<2,true> (fused FPN forward, packed arg-max, 1 launch/step)",
         "bound": "hbm",
         "achieved": alg / (fwd_ms * 1e-3) / 1e9,
         "peak": PEAK_HBM_GBS,
