@@ -16,6 +16,14 @@ where they lie):
   py_nms.npz       operator_py/nms.py:41-75   nms  (pure numpy hard NMS, suppress IoU > thresh)
   cython_nms.npz   operator_py/cython/cpu_nms.pyx soft_nms / greedy_nms and bbox.pyx
                    bbox_overlaps_cython, compiled by oracle/build_ref.py into oracle/_ref
+  top_proposal.npz models/FPN/get_top_proposal.py:10-67  GetTopProposalOperator.forward and
+                   GetTopProposalProp (arguments, outputs, infer_shape), run with a numpy shim of
+                   mx.operator.CustomOp / mx.nd.argsort / mx.nd.stack.  The ONE thing the shim
+                   decides is the order of equal scores: mx.nd.argsort(is_ascend=False) is MXNet's
+                   SortByKey, a STABLE sort with a descending comparator on both devices
+                   (std::stable_sort / thrust::stable_sort_by_key), i.e. equal scores keep their
+                   input order -- np.argsort(-x, kind="stable").  The cases hold tied scores, so
+                   the fixture pins that choice too; everything else is the reference's code.
 """
 import ast
 import os
@@ -152,7 +160,91 @@ def make_cython_nms():
     np.savez_compressed(os.path.join(HERE, "cython_nms.npz"), **out)
 
 
+def make_top_proposal():
+    class _Arr:
+        """the slice of mx.nd.NDArray the operator touches, on numpy float32"""
+        def __init__(self, a):
+            self.a = np.asarray(a)
+
+        @property
+        def shape(self):
+            return self.a.shape
+
+        def __getitem__(self, i):
+            if isinstance(i, _Arr):
+                return _Arr(self.a[i.a.astype(np.int64)])
+            return _Arr(self.a[i])
+
+    class _ND:
+        @staticmethod
+        def argsort(x, is_ascend=True):
+            k = x.a if is_ascend else -x.a
+            return _Arr(np.argsort(k, kind="stable").astype(np.float32))  # mx returns float indices
+
+        @staticmethod
+        def stack(*xs):
+            return _Arr(np.stack([x.a for x in xs]))
+
+    class _CustomOp:
+        def __init__(self):
+            pass
+
+        def assign(self, dst, req, src):
+            assert req == "write"
+            assert dst.a.shape == src.a.shape, (dst.a.shape, src.a.shape)
+            dst.a[...] = src.a
+
+    class _CustomOpProp:
+        def __init__(self, need_top_grad=True):
+            self.need_top_grad_ = need_top_grad
+
+    def register(name):
+        def deco(cls):
+            reg[name] = cls
+            return cls
+        return deco
+
+    reg = {}
+    mx = types.SimpleNamespace(nd=_ND, operator=types.SimpleNamespace(
+        CustomOp=_CustomOp, CustomOpProp=_CustomOpProp, register=register))
+    env = {}
+    sys.modules["mxnet"] = mx  # the file's own `import mxnet as mx` finds the shim
+    try:
+        exec(compile(open(os.path.join(REF, "models", "FPN", "get_top_proposal.py")).read(),
+                     "get_top_proposal.py", "exec"), env)
+    finally:
+        del sys.modules["mxnet"]
+    prop_cls = reg["get_top_proposal"]
+    out = {}
+    prop = prop_cls(top_n="2000")
+    out["iface_arguments"] = np.array(prop.list_arguments())
+    out["iface_outputs"] = np.array(prop.list_outputs())
+    ins, outs = prop.infer_shape([(2, 10000, 4), (2, 10000, 1)])
+    out["iface_infer_in"] = np.array([list(s) + [0] * (3 - len(s)) for s in ins])
+    out["iface_infer_out"] = np.array([list(s) for s in outs])
+    out["iface_need_top_grad"] = np.array(prop.need_top_grad_)
+    out["iface_backward_dependency"] = np.array(len(prop.declare_backward_dependency([], [], [])))
+    # (seed, B, N, top_n, score quantisation: 0 = distinct floats, q = scores rounded to 1/q -> ties)
+    cases = [(0, 2, 10000, 2000, 0), (1, 2, 10000, 2000, 64), (2, 1, 3000, 3000, 16), (3, 3, 257, 100, 4),
+             (4, 2, 10000, 1, 0), (5, 2, 64, 64, 1)]
+    out["cases"] = np.array(cases)
+    for seed, B, N, top_n, q in cases:
+        rs = np.random.RandomState(seed)
+        bbox = (rs.rand(B, N, 4) * 800).astype(np.float32)
+        score = rs.rand(B, N, 1).astype(np.float32)
+        if q:
+            score = (np.round(score * q) / q).astype(np.float32)
+        op = prop_cls(top_n=str(top_n)).create_operator(None, None, None)
+        ob, os_ = _Arr(np.zeros((B, top_n, 4), np.float32)), _Arr(np.zeros((B, top_n, 1), np.float32))
+        op.forward(True, ["write", "write"], [_Arr(bbox), _Arr(score)], [ob, os_], [])
+        # inputs are regenerated from the seed by the tests (same expressions); outputs are stored
+        out["bbox_%d" % seed] = ob.a
+        out["score_%d" % seed] = os_.a
+    np.savez_compressed(os.path.join(HERE, "top_proposal.npz"), **out)
+
+
 if __name__ == "__main__":
+    make_top_proposal()
     make_anchors()
     make_fpn_assign()
     make_py_nms()

@@ -434,6 +434,40 @@ def test_proposal_v3_score_ties_are_stable(ops, oracle, topk):
     np.testing.assert_array_equal(out.cpu().numpy(), want[0])
 
 
+def _top_proposal_cases():
+    """tests/golden/top_proposal.npz: outputs of the reference's GetTopProposalOperator
+    (models/FPN/get_top_proposal.py:10-43) run on a numpy shim of mx.nd (make_golden.py); inputs
+    are regenerated from the seed with the generator's expressions."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "top_proposal.npz"))
+    for seed, B, N, top_n, q in g["cases"]:
+        rs = np.random.RandomState(int(seed))
+        bbox = (rs.rand(B, N, 4) * 800).astype(np.float32)
+        score = rs.rand(B, N, 1).astype(np.float32)
+        if q:
+            score = (np.round(score * q) / q).astype(np.float32)
+        yield int(seed), bbox, score, int(top_n), g["bbox_%d" % seed], g["score_%d" % seed]
+
+
+def test_oracle_get_top_proposal_reproduces_reference_class(oracle):
+    """includes tied scores (quantised): equal scores keep their input order, MXNet's stable
+    descending SortByKey"""
+    n = 0
+    for seed, bbox, score, top_n, wb, ws_ in _top_proposal_cases():
+        ob, os_ = oracle.get_top_proposal(bbox, score, top_n)
+        np.testing.assert_array_equal(os_, ws_, err_msg="case %d" % seed)
+        np.testing.assert_array_equal(ob, wb, err_msg="case %d" % seed)
+        n += 1
+    assert n == 6
+
+
+@pytest.mark.gpu
+def test_hip_get_top_proposal_reproduces_reference_class(ops):
+    for seed, bbox, score, top_n, wb, ws_ in _top_proposal_cases():
+        ob, os_ = ops.get_top_proposal(_t(bbox), _t(score), top_n)
+        np.testing.assert_array_equal(os_.cpu().numpy(), ws_, err_msg="case %d" % seed)
+        np.testing.assert_array_equal(ob.cpu().numpy(), wb, err_msg="case %d" % seed)
+
+
 @pytest.mark.gpu
 def test_get_top_proposal(ops, oracle):
     rs = np.random.RandomState(0)

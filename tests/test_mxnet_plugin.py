@@ -95,6 +95,17 @@ def test_proposal_v3_prop(plugin):
     assert outs == [(2, 2000, 4), (2, 2000, 1)]
     t = props["get_top_proposal"](top_n="2000")
     assert t.infer_shape([(2, 10000, 4), (2, 10000, 1)])[1] == [(2, 2000, 4), (2, 2000, 1)]
+    # ... and the registration of the reference's own class (models/FPN/get_top_proposal.py:46-72),
+    # recorded by tests/golden/make_golden.py
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "top_proposal.npz"))
+    assert t.list_arguments() == list(g["iface_arguments"])
+    assert t.list_outputs() == list(g["iface_outputs"])
+    ins, outs = t.infer_shape([(2, 10000, 4), (2, 10000, 1)])
+    assert [list(x) for x in outs] == g["iface_infer_out"].tolist()
+    assert [list(x) + [0] * (3 - len(x)) for x in ins] == g["iface_infer_in"].tolist()
+    assert bool(t.need_top_grad_) == bool(g["iface_need_top_grad"])
+    assert len(t.declare_backward_dependency([], [], [])) == int(g["iface_backward_dependency"])
 
 
 def test_fused_fpn_roi_align_prop(plugin):
