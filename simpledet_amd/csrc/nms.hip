@@ -27,8 +27,14 @@ namespace sd {
 
 constexpr int kMaxSortKeys = 16384;
 
+// Sort key of a score: smaller key = better score.  -0.0 and +0.0 get the SAME key (the reference's
+// thrust::stable_sort_by_key(greater<float>) and MXNet's SortByKey compare them equal and keep
+// their input order; the index in the low half of the 64-bit key does the same here).  NaN scores,
+// which the reference's comparator leaves in an unspecified place, are ordered by their bits:
+// positive NaNs before +inf, negative NaNs after -inf.
 __device__ __forceinline__ unsigned ordered_desc_bits(float f) {
   unsigned u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;                     // -0.0 == +0.0
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-order-preserving map
   return ~u;                                        // descending
 }

@@ -128,3 +128,31 @@ def test_fused_fpn_roi_align_14x14_mask_head(ops, oracle):
         s = max(1.0, float(np.abs(w).max()))
         assert np.abs(a.cpu().numpy() - w).max() <= 1e-4 * s
         assert np.abs(b.cpu().numpy() - w).max() <= 1e-4 * s
+
+
+@pytest.mark.gpu
+def test_signed_zero_scores_tie_like_the_reference(ops, oracle):
+    """-0.0 and +0.0 compare equal in the reference's sorts (thrust::stable_sort_by_key with
+    greater<float>, contrib/nms.cu:304-312; MXNet SortByKey behind mx.nd.argsort,
+    models/FPN/get_top_proposal.py:26): zero-padded rows with either sign keep their input order."""
+    rs = np.random.RandomState(11)
+    N = 600
+    bbox = (rs.rand(2, N, 4) * 500).astype(np.float32)
+    score = rs.rand(2, N, 1).astype(np.float32)
+    zero = rs.rand(2, N, 1) < 0.4
+    sign = np.where(rs.rand(2, N, 1) < 0.5, np.float32(-0.0), np.float32(0.0))
+    score = np.where(zero, sign, score).astype(np.float32)
+    assert np.signbit(score).any() and (score == 0).sum() > 300
+    for top_n in (100, 450, N):
+        wb, ws_ = oracle.get_top_proposal(bbox, score, top_n)
+        ob, os_ = ops.get_top_proposal(_t(bbox), _t(score), top_n)
+        np.testing.assert_array_equal(ob.cpu().numpy(), wb)
+        np.testing.assert_array_equal(os_.cpu().numpy().view(np.uint32), ws_.view(np.uint32))
+    # _contrib_NMS: far-apart boxes so that nothing is suppressed and the output order is the sort's
+    ctr = np.stack([np.arange(N) % 30 * 40.0, np.arange(N) // 30 * 40.0], 1)
+    dets = np.concatenate([ctr, ctr + 10, np.zeros((N, 1))], 1)[None].repeat(2, 0).astype(np.float32)
+    dets[..., 4:] = score
+    wo, ws2, _ = oracle.nms(dets, N, N, 0.7)
+    go, gs = ops.nms(_t(dets), rpn_pre_nms_top_n=N, rpn_post_nms_top_n=N, threshold=0.7)[:2]
+    np.testing.assert_array_equal(go.cpu().numpy(), wo)
+    np.testing.assert_array_equal(gs.cpu().numpy().view(np.uint32), ws2.view(np.uint32))
