@@ -1160,11 +1160,10 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
 //   * a lane owns FOUR consecutive bins of one RoI: one aligned 4-byte load brings their four
 //     arg-max codes (rows are padded to whole dwords, amax_stride) and one 16-byte load the four
 //     gradients: 0.5 load per item instead of 2;
-//   * the per-RoI tap tables ({neighbours, fraction} per sample coordinate, written by the forward
-//     with the backward's own expressions: floor / ceil / clamp, v - low) of the RoIs on the band
-//     are staged ONCE per workgroup into LDS, the row entries turned into offsets inside the band;
-//     an item picks its row and column entry with two ds_read_b64 (the first version recomputed
-//     the neighbours per bin and the kernel was 81 % VALU-busy: profiles/r02g_bwd_pmc.txt);
+//   * the per-RoI sample-coordinate tables (3*(PH+PW) floats each, written by the forward) of the
+//     RoIs on the band are staged ONCE per workgroup into LDS with 8-byte loads; an item then picks
+//     its row / column coordinate with two ds_read_b32 and derives the neighbours and the
+//     interpolation fraction with the backward's own expressions (floor / ceil / clamp, v - low);
 //   * the band is accumulated in 32-bit FIXED POINT with plain integer LDS atomics (ds_add_u32,
 //     fire and forget: 3.5 adds/clk/CU against 1.9 for the float compare-and-swap loop whose two
 //     dependent LDS round trips per add were the longest chain of the workgroup).  Every tap value
@@ -1181,11 +1180,10 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
 template <int PH, int PW, int THREADS, int TCH>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: four 512-thread workgroups per CU
 void roi_align_bwd_packed4(BwdFusedArgs a) {
-  constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4;
-  constexpr int NE = 3 * (PH + PW);            // sample coordinates per RoI (3 per bin row / column)
-  constexpr int TS = 2 * NE;                   // staged words per RoI: an 8-byte tap entry each
+  constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4, TS = 3 * (PH + PW);
   constexpr int CW = kCoordWords * (PH + PW);  // words per RoI in the forward's table
   constexpr bool TAIL = (PP % 4) != 0;         // last lane of a RoI owns fewer than four bins
+  static_assert(TS % 2 == 0, "table rows are copied as float2");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   // ---- block -> (level, image, band, channel) ----
@@ -1318,91 +1316,57 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
       it.code = code;
     }
   };
-  // An item's bin reads the two 8-byte tap entries of its winning sample (row entry: the band
-  // offsets of the two neighbour rows, 0xffff = outside the band, + the interpolation fraction;
-  // column entry: the two neighbour columns + fraction) and needs no floor / ceil / clamp / row
-  // multiply of its own: stage_tables derives them once per (RoI, sample) from the pairs the
-  // forward wrote with the backward's own expressions (store_tap), seven bins share each.
-  // With fixed point the gradient is scaled first (a power of two: the products are the same
-  // floats times 2^S), so a tap is two multiplies, one round and the add.
   auto scatter_item = [&](const Item& it, int slot) {
     if (it.code == 0xffffffffu || (SD_ABLATE(a, 1))) return;  // (profiling build, 1: no scatter)
     const float* tj = tab + slot * TS;
     const float gg[4] = {it.g.x, it.g.y, it.g.z, it.g.w};
-    int p = it.b0 / PW, q = it.b0 - p * PW;
 #pragma unroll
-    for (int s = 0; s < 4; ++s, ++q) {
-      if (q == PW) { q = 0; ++p; }
+    for (int s = 0; s < 4; ++s) {
       const int code = (it.code >> (8 * s)) & 0xff;
       if (code == 255) continue;
+      const int bin = it.b0 + s;
+      const int p = bin / PW, q = bin - p * PW;
       const int k = (code * 11) >> 5, l = code - 3 * k;  // code = 3k + l, k,l in 0..2
-      const float2 re = *reinterpret_cast<const float2*>(tj + 2 * (p * 3 + k));
-      const float2 ce = *reinterpret_cast<const float2*>(tj + 2 * (3 * PH + q * 3 + l));
-      const unsigned rp = __float_as_uint(re.x), cp = __float_as_uint(ce.x);
-      const int o0 = rp & 0xffffu, o1 = rp >> 16, wleft = cp & 0xffffu, wright = cp >> 16;
-      const float alpha = re.y, beta = ce.y;
-      const float g = use_fx ? gg[s] * fx_scale : gg[s];
+      const float a_y = tj[p * 3 + k];
+      const float a_x = tj[3 * PH + q * 3 + l];
+      const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+      const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+      const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+      const int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+      // (v - low) / (high - low) with high - low == 1
+      const float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow);
+      const float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft);
+      const float g = gg[s];
       const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
       const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
+      const int o0 = (hlow - row0) * W, o1 = (hhigh - row0) * W;
       if (use_fx) {
-        if (o0 != 0xffff) {
-          lds_add_i32(plane_i + o0 + wleft, w00, 1.f);
-          lds_add_i32(plane_i + o0 + wright, w01, 1.f);
+        if (hlow >= row0 && hlow < row1) {
+          lds_add_i32(plane_i + o0 + wleft, w00, fx_scale);
+          lds_add_i32(plane_i + o0 + wright, w01, fx_scale);
         }
-        if (o1 != 0xffff) {
-          lds_add_i32(plane_i + o1 + wleft, w10, 1.f);
-          lds_add_i32(plane_i + o1 + wright, w11, 1.f);
+        if (hhigh >= row0 && hhigh < row1) {
+          lds_add_i32(plane_i + o1 + wleft, w10, fx_scale);
+          lds_add_i32(plane_i + o1 + wright, w11, fx_scale);
         }
         continue;
       }
-      if (o0 != 0xffff) {
+      if (hlow >= row0 && hlow < row1) {
         lds_add_cas(plane + o0 + wleft, w00);
         lds_add_cas(plane + o0 + wright, w01);
       }
-      if (o1 != 0xffff) {
+      if (hhigh >= row0 && hhigh < row1) {
         lds_add_cas(plane + o1 + wleft, w10);
         lds_add_cas(plane + o1 + wright, w11);
       }
     }
   };
 
-  // Table staging in two halves so that the global round trip of chunk n+1 runs under the scatter of
-  // chunk n: fetch_tables brings a chunk's sample coordinates (4 bytes each, the forward's table)
-  // into registers, put_tables derives the 8-byte tap entries (the backward's expressions: floor /
-  // ceil / clamp, v - low; rows as offsets inside this band) and writes them to LDS.
-  constexpr int TPT = (TCH * NE + THREADS - 1) / THREADS;  // entries per thread and chunk
-  float tv[TPT];
-  auto fetch_tables = [&](int cb, int ncur) {
-#pragma unroll
-    for (int u = 0; u < TPT; ++u) {
-      const int i = tid + u * THREADS;
-      tv[u] = 0.f;
-      if (i < ncur * NE) {
-        const int j = i / NE, e = i - j * NE;
-        tv[u] = cob[list[cb + j] * CW + e];
-      }
-    }
-  };
-  auto put_tables = [&](int ncur) {
-#pragma unroll
-    for (int u = 0; u < TPT; ++u) {
-      const int i = tid + u * THREADS;
-      if (i < ncur * NE) {
-        const int j = i / NE, e = i - j * NE;
-        const float v = tv[u];
-        const bool row = e < 3 * PH;
-        const int size = row ? H : W;
-        const int lo = iminr(imaxr((int)floorf(v), 0), size - 1);
-        const int hi = iminr(imaxr((int)ceilf(v), 0), size - 1);
-        const float frac = (lo == hi) ? 0.5f : (v - (float)lo);  // (v - low) / (high - low), high - low == 1
-        unsigned w0 = (unsigned)lo | ((unsigned)hi << 16);
-        if (row) {
-          const unsigned o0 = (lo >= row0 && lo < row1) ? (unsigned)((lo - row0) * W) : 0xffffu;
-          const unsigned o1 = (hi >= row0 && hi < row1) ? (unsigned)((hi - row0) * W) : 0xffffu;
-          w0 = o0 | (o1 << 16);
-        }
-        *reinterpret_cast<float2*>(tab + j * TS + 2 * e) = make_float2(__uint_as_float(w0), frac);
-      }
+  auto stage_tables = [&](int cb, int ncur) {
+    for (int i = tid; i < ncur * (TS / 2); i += THREADS) {
+      const int j = i / (TS / 2), e2 = i - j * (TS / 2);
+      const float2 v = *reinterpret_cast<const float2*>(cob + list[cb + j] * CW + 2 * e2);
+      *reinterpret_cast<float2*>(tab + j * TS + 2 * e2) = v;
     }
   };
 
@@ -1435,9 +1399,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   };
   Item cur;
   load_item(tid, 0, iminr(TCH, nl) * GP, cur);
-  fetch_tables(0, iminr(TCH, nl));
-  put_tables(iminr(TCH, nl));
-  if (nl > TCH) fetch_tables(TCH, iminr(TCH, nl - TCH));
+  stage_tables(0, iminr(TCH, nl));
   float m_all = abs4(cur.g);
   int bad = !(m_all <= FLT_MAX);
   if (use_fx) wave_max_to(m_all, bad, 2);
@@ -1455,11 +1417,9 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
       const int nli = ncur * GP;  // lane items of this chunk
       if (cb > 0 || attempt > 0) {
         load_item(tid, cb, nli, cur);
-        if (cb == 0) fetch_tables(0, ncur);  // (rare second pass: its first chunk was not prefetched)
         __syncthreads();  // the previous chunk's tables are no longer read
-        put_tables(ncur);
+        stage_tables(cb, ncur);
         __syncthreads();
-        if (cb + TCH < nl) fetch_tables(cb + TCH, iminr(TCH, nl - cb - TCH));  // travels under the scatter
       }
       for (int t = tid; t < nli; t += THREADS) {
         Item nxt;
@@ -1519,7 +1479,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
   // LDS with the band, so the band budget is a little smaller
   const bool wide = a.amax8 && tuning("roi_align_bwd_packed", 1) == 1;
   const int tch = tuning("roi_align_bwd_tch", a.PP == 49 ? 32 : 16);
-  const int ts_words = a.PP == 49 ? 2 * 3 * 14 : 2 * 3 * 28;  // an 8-byte tap entry per sample coordinate
+  const int ts_words = a.PP == 49 ? 3 * 14 : 3 * 28;
   const size_t tab_bytes = wide ? (size_t)tch * ts_words * 4 : 0;
   const long budget = (long)tuning("roi_align_bwd_lds_kb", 36) * 1024;
   a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
@@ -1537,7 +1497,6 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
     nb = (a.L.H[l] + rows - 1) / rows;
     a.band_rows[l] = rows;
     a.nbands[l] = nb;
-    if (wide && (long)rows * a.L.W[l] >= 65535) return SD_ERR_UNSUPPORTED;  // 16-bit band offsets
     const size_t lds =
         (size_t)((((long)rows * a.L.W[l] + 3) & ~3L) * 4) + tab_bytes + (size_t)(a.R + 8 + 16) * 4;
     if (lds > 150 * 1024) return SD_ERR_UNSUPPORTED;
