@@ -338,8 +338,10 @@ __device__ void rpn_sample(Mt& m, int n, int keep, int* jrec, int* hp, int* hv, 
     int K = __popcll(bits);
     const int R = i - lo + 1;  // accepts this mask still serves
     int consumed = chunk;
-    if (K > R) {
+    if (K >= R) {
       // the R-th accept ends the segment; later draws of the batch are re-read with the next mask
+      // (also when it is the batch's last accept: the rejected draws behind it were judged with
+      // the old mask, numpy judges them with the halved one -- found by the generator fuzz test)
       unsigned long long b = bits;
       for (int s = 1; s < R; ++s) b &= b - 1;
       const int last = __ffsll((long long)b) - 1;

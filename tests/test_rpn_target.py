@@ -129,3 +129,107 @@ def test_hip_batch_equals_image_by_image_and_flat_layout(ops):
         np.testing.assert_array_equal(tgt[i].cpu().numpy(), t)
         np.testing.assert_array_equal(wgt[i].cpu().numpy(), w)
     assert int(state[624]) == rs.get_state()[2]
+
+
+@pytest.mark.gpu
+def test_hip_generator_replay_fuzz(ops):
+    """160 small random problems through ONE generator state against numpy's RandomState (the oracle
+    restatement, itself pinned to the reference's classes): list lengths from 3 to ~3000 cross every
+    rejection-mask boundary many times, at arbitrary positions of the 64-draw batches and of the
+    624-word state, with fg-only, bg-only and both subsamplings.  Labels and the state position must
+    agree after every image."""
+    import torch
+    from oracle import rpn_target as orc
+    rs_cfg = np.random.RandomState(123)
+    state = ops.mt19937_state(seed=77)
+    rs = np.random.RandomState(77)
+    for it in range(160):
+        short, long_ = int(rs_cfg.randint(3, 26)), int(rs_cfg.randint(26, 40))
+        cfg = dict(stride=16, short=short, long=long_, scales=(2, 4, 8)[:int(rs_cfg.randint(1, 4))],
+                   aspects=(0.5, 1.0, 2.0), allowed_border=int(rs_cfg.choice([0, 16, 64])),
+                   pos_thr=float(rs_cfg.choice([0.5, 0.7])), neg_thr=0.3, min_pos_thr=0.0,
+                   image_anchor=int(rs_cfg.choice([4, 16, 64, 256])), pos_fraction=float(rs_cfg.choice([0.25, 0.5])))
+        h, w = short * 16, long_ * 16
+        ng = int(rs_cfg.randint(0, 12))
+        gt = -np.ones((100, 5), np.float32)
+        if ng:
+            x1 = rs_cfg.rand(ng) * (w - 40)
+            y1 = rs_cfg.rand(ng) * (h - 40)
+            bw = 16 + rs_cfg.rand(ng) * (w - x1 - 17)
+            bh = 16 + rs_cfg.rand(ng) * (h - y1 - 17)
+            gt[:ng] = np.stack([x1, y1, x1 + bw, y1 + bh, np.ones(ng)], 1).astype(np.float32)
+        im_info = np.array([h, w, 1.0], np.float32)
+        p = ops.rpn_target_param(cfg["stride"], cfg["short"], cfg["long"], cfg["scales"], cfg["aspects"],
+                                 cfg["allowed_border"], cfg["pos_thr"], cfg["neg_thr"], cfg["min_pos_thr"],
+                                 cfg["image_anchor"], cfg["pos_fraction"])
+        cls, tgt, wgt = ops.rpn_anchor_target(torch.from_numpy(im_info[None]).cuda(),
+                                              torch.from_numpy(gt[None]).cuda(), p, state, layout=0)
+        c, t, wv, _ = orc.rpn_target_flat(im_info, gt, cfg, rs)
+        np.testing.assert_array_equal(cls[0].cpu().numpy(), c, err_msg="labels, problem %d" % it)
+        np.testing.assert_array_equal(wgt[0].cpu().numpy(), wv, err_msg="weights, problem %d" % it)
+        np.testing.assert_array_equal(tgt[0].cpu().numpy(), t, err_msg="targets, problem %d" % it)
+        assert int(state[624]) == rs.get_state()[2], "generator position, problem %d" % it
+    np.testing.assert_array_equal(state.cpu().numpy()[:624].astype(np.uint32), rs.get_state()[1])
+
+
+def _batched_replay(mt, n, keep, batch=64):
+    """The device's consumption rule (csrc/rpn_target.hip rpn_sample) in plain Python: `batch` outputs
+    at a time, exact acceptance inside the batch, and a batch is CUT at the accept that ends a
+    rejection-mask segment -- the draws behind it are read again with the next (halved) mask."""
+    def temper(y):
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9d2c5680
+        y ^= (y << 15) & 0xefc60000
+        y ^= y >> 18
+        return y & 0xffffffff
+    i, jrec = n - 1, {}
+    while i >= 1:
+        mask = i
+        for s in (1, 2, 4, 8, 16):
+            mask |= mask >> s
+        lo = (mask >> 1) + 1
+        if mt.pos >= 624:
+            mt._twist()
+        chunk = min(624 - mt.pos, batch)
+        v = [temper(int(mt.key[mt.pos + t])) & mask for t in range(chunk)]
+        acc, c = [], 0
+        for t in range(chunk):
+            a = v[t] <= i - c
+            acc.append(a)
+            c += a
+        seg = i - lo + 1
+        consumed = chunk
+        if c >= seg:
+            cnt = 0
+            for t in range(chunk):
+                cnt += acc[t]
+                if cnt == seg:
+                    consumed = t + 1
+                    break
+            acc = [a and t < consumed for t, a in enumerate(acc)]
+            c = seg
+        cnt = 0
+        for t in range(consumed):
+            if acc[t]:
+                if (n - 1) - (i - cnt) < keep:
+                    jrec[(n - 1) - (i - cnt)] = v[t]
+                cnt += 1
+        i -= c
+        mt.pos += consumed
+    return jrec
+
+
+def test_batched_rejection_replay_equals_serial_numpy_walk():
+    """400 permutations of random length through one generator: the batched rule consumes exactly
+    numpy's draws (same swap targets for the kept prefix, same state).  Cutting only when MORE
+    accepts follow the segment's last one (the first version of the kernel) loses ~2 % of them."""
+    from oracle import rpn_target as orc
+    st = np.random.RandomState(9).get_state()
+    a, b = orc.MT19937(st[1], st[2]), orc.MT19937(st[1], st[2])
+    rs = np.random.RandomState(5)
+    for _ in range(400):
+        n, keep = int(rs.randint(3, 3000)), int(rs.randint(1, 64))
+        ja = _batched_replay(a, n, keep)
+        jb = {s: orc.legacy_interval(b, i) for s, i in enumerate(range(n - 1, 0, -1))}
+        assert ja == {s: j for s, j in jb.items() if s < keep}
+        assert a.pos == b.pos and (a.key == b.key).all()
