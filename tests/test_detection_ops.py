@@ -194,6 +194,62 @@ def test_nms_matches_oracle(ops, oracle, cfg):
 
 
 @pytest.mark.gpu
+def test_nms_fuzz(ops, oracle):
+    """100 random problems: 1..2500 boxes, batch 1..3, clustered / disjoint / piled-up boxes, score
+    ties from none to eight distinct values, every pre / post / threshold combination (> and >=)."""
+    rs = np.random.RandomState(31)
+    for it in range(100):
+        n = int(rs.choice([1, 2, 63, 64, 65, 127, 300, 1000, 2047, 2048, 2500]))
+        B = int(rs.randint(1, 4))
+        mode = str(rs.choice(["clustered", "no_overlap", "all_overlap"]))
+        dets = _nms_batch([int(x) for x in rs.randint(0, 10000, B)], n, mode)
+        q = int(rs.choice([0, 0, 8, 64]))
+        if q:
+            dets[:, :, 4] = np.round(dets[:, :, 4] * q) / q
+        pre = int(rs.choice([-1, n, max(1, n // 2), 6000]))
+        post = int(rs.choice([1, max(1, n // 3), n, 3000]))
+        thr = float(rs.choice([0.3, 0.5, 0.7]))
+        ge = bool(rs.randint(0, 2))
+        want = oracle.nms(dets, pre, post, thr) if not ge else None
+        out, score, keep = ops.nms(_t(dets), pre, post, thr, threshold_ge=ge, return_index=True)
+        msg = "problem %d n=%d B=%d %s q=%d pre=%d post=%d thr=%g ge=%d" % (it, n, B, mode, q, pre, post, thr, ge)
+        if want is not None:
+            np.testing.assert_array_equal(keep.cpu().numpy(), want[2], err_msg=msg)
+            np.testing.assert_array_equal(out.cpu().numpy(), want[0], err_msg=msg)
+            np.testing.assert_array_equal(score.cpu().numpy(), want[1], err_msg=msg)
+        else:  # >= variant: a kept box suppresses everything with IoU >= thr that follows it
+            k = keep.cpu().numpy()
+            for b in range(B):
+                kb = k[b][k[b] >= 0]
+                assert len(set(kb.tolist())) == len(kb), msg
+                if len(kb) > 1 and n <= 300:
+                    from oracle import pyoracle
+                    bx = dets[b, kb, :4]
+                    ov = pyoracle.bbox_overlaps(bx, bx)
+                    assert (np.triu(ov, 1) < thr).all(), msg
+
+
+@pytest.mark.gpu
+def test_soft_nms_fuzz(ops, oracle):
+    """60 random batches of problems (0..400 boxes each, all three methods, random sigma / Nt /
+    score threshold, ties and duplicated boxes) against the oracle (pinned to the reference's
+    compiled Cython)."""
+    rs = np.random.RandomState(32)
+    for it in range(60):
+        P, Nmax = int(rs.randint(1, 7)), int(rs.choice([1, 17, 64, 200, 400]))
+        dets = np.stack([synth.nms_dets(int(rs.randint(0, 10000)), Nmax,
+                                        mode=str(rs.choice(["clustered", "no_overlap", "all_overlap"])))
+                         for _ in range(P)])
+        if rs.randint(0, 2):
+            dets[:, :, 4] = np.round(dets[:, :, 4] * 16) / 16
+        if Nmax >= 64 and rs.randint(0, 2):
+            dets[:, Nmax // 2:Nmax // 2 + 20] = dets[:, :20]
+        counts = rs.randint(0, Nmax + 1, P)
+        _soft_check(ops, oracle, dets, counts, float(rs.choice([0.3, 0.5, 0.8])), float(rs.choice([0.3, 0.5])),
+                    float(rs.choice([0.001, 0.05, 0.3])), int(rs.randint(0, 3)))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["no_overlap", "all_overlap"])
 def test_nms_stress_sets_and_ties(ops, oracle, mode):
     dets = _nms_batch([4, 5], 1000, mode)
@@ -340,6 +396,32 @@ def test_proposal_target_baseline_config(ops, oracle):
     want = _pt_check(ops, oracle, rois, gt)
     assert want[6] == 0
     assert (want[1] > 0).sum() > 0
+
+
+@pytest.mark.gpu
+def test_proposal_target_fuzz(ops, oracle):
+    """120 random problems (8..700 proposals, 1..12 gt boxes, batch 1..3, sample sizes from 4 to 256,
+    thresholds that empty or flood the fg / bg lists): every output and the glibc generator state
+    against the oracle (itself pinned to the reference's compiled SampleROI)."""
+    rs = np.random.RandomState(2024)
+    for it in range(120):
+        B = int(rs.randint(1, 4))
+        num = int(rs.choice([8, 20, 64, 150, 333, 700]))
+        ngt = tuple(int(x) for x in rs.randint(1, 13, B))
+        rois, gt = synth.proposal_target_inputs(1000 + it, B, num, 16, n_gt=ngt)
+        kw = dict(image_rois=int(rs.choice([4, 16, 64, 128, 256])),
+                  fg_fraction=float(rs.choice([0.25, 0.5, 0.75])),
+                  fg_thresh=float(rs.choice([0.1, 0.5, 0.7])),
+                  bg_thresh_lo=float(rs.choice([0.0, 0.1])),
+                  proposal_without_gt=bool(rs.randint(0, 2)),
+                  class_agnostic=bool(rs.randint(0, 2)))
+        kw["bg_thresh_hi"] = float(min(kw["fg_thresh"], rs.choice([0.3, 0.5])))
+        if kw["class_agnostic"]:
+            kw["num_classes"] = 2
+        try:
+            _pt_check(ops, oracle, rois, gt, seed=int(rs.randint(1, 1 << 30)), **kw)
+        except AssertionError as e:
+            raise AssertionError("problem %d %r: %s" % (it, kw, e))
 
 
 @pytest.mark.gpu
