@@ -103,3 +103,53 @@ def test_hip_rasteriser_equals_oracle_on_many_polygons(ops, oracle):
                                        proposal_without_gt=True, rng_state=ops.glibc_rand_state(1))
         want = oracle.proposal_mask_target(rois, gt, big, p, ms, rng=oracle.GlibcRand(1))
         np.testing.assert_array_equal(got[5].cpu().numpy(), want[5])
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+def test_proposal_target_v2_and_mask_target_fuzz(ops, oracle):
+    """50 random problems each: ProposalTarget_v2 (valid_ranges, filter_scales on / off) and
+    ProposalMaskTarget (sampling + masks) against the oracle: indices, labels, weights, IoU, masks
+    and the glibc generator state bit for bit, box targets to 1e-6 (device logf)."""
+    rs = np.random.RandomState(77)
+    for it in range(50):
+        B = int(rs.randint(1, 4))
+        N = int(rs.choice([16, 100, 400]))
+        ngt = tuple(int(x) for x in rs.randint(1, 9, B))
+        rois, gt = synth.proposal_target_inputs(3000 + it, B, N, 12, n_gt=ngt)
+        S = int(rs.choice([8, 32, 128]))
+        fgf = float(rs.choice([0.25, 0.5]))
+        lo = float(rs.choice([0, 32, 96]))
+        vr = np.array([[lo, lo + float(rs.choice([64, 256, 2000]))]] * B, np.float32)
+        filt = bool(rs.randint(0, 2))
+        seed = int(rs.randint(1, 1 << 30))
+        p = oracle.make_pt_param(81, B, S, fgf, 0.5, 0.5, 0.0, False)
+        msg = "problem %d B=%d N=%d S=%d fg=%g ranges=%s filter=%d" % (it, B, N, S, fgf, vr[0].tolist(), filt)
+        # --- ProposalTarget_v2
+        rng = oracle.GlibcRand(seed)
+        want = oracle.proposal_target(rois, gt, p, rng=rng, valid_ranges=vr, filter_scales=filt)
+        st = ops.glibc_rand_state(seed)
+        got = [x.cpu().numpy() for x in ops.proposal_target(
+            _t(rois), _t(gt), 81, B, S, fgf, 0.5, 0.5, 0.0, False, False, rng_state=st,
+            valid_ranges=_t(vr), filter_scales=filt, return_index=True)]
+        np.testing.assert_array_equal(got[5], want[5], err_msg=msg)
+        for k in (0, 1, 3, 4):
+            np.testing.assert_array_equal(got[k], want[k], err_msg=msg)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-6, atol=1e-7, err_msg=msg)
+        np.testing.assert_array_equal(st.cpu().numpy(), rng.state_words(), err_msg=msg)
+        # --- ProposalMaskTarget
+        polys = synth.gt_polys(3000 + it, gt)
+        rng = oracle.GlibcRand(seed)
+        wm = oracle.proposal_mask_target(rois, gt, polys, p, 28, rng=rng, valid_ranges=vr, filter_scales=filt)
+        st = ops.glibc_rand_state(seed)
+        gm = [x.cpu().numpy() for x in ops.proposal_mask_target(
+            _t(rois), _t(gt), _t(polys), 81, B, S, 28, fgf, 0.5, 0.5, 0.0, False, rng_state=st,
+            valid_ranges=_t(vr), filter_scales=filt)]
+        for k in (0, 1, 3, 4, 5):
+            np.testing.assert_array_equal(gm[k], wm[k], err_msg=msg + " (mask target, output %d)" % k)
+        np.testing.assert_allclose(gm[2], wm[2], rtol=1e-6, atol=1e-7, err_msg=msg)
+        np.testing.assert_array_equal(st.cpu().numpy(), rng.state_words(), err_msg=msg)
