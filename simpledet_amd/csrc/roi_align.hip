@@ -1390,7 +1390,10 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   };
   auto set_scale = [&](float gmax) {
     const float bound = gmax * (float)nlist[1];  // no pixel of the band can exceed this
-    if (!(bound <= FLT_MAX)) { use_fx = false; return; }
+    // One unit is bound * 2^-30: with a weight bound above 2048 (hundreds of sub-pixel bins piled
+    // onto one pixel of a tiny map -- 20x the baseline's bands) it would exceed max|dY| * 4e-6 and
+    // the rounding of a few hundred adds could reach 1e-4: such a band takes the float adds.
+    if (!(bound <= FLT_MAX) || nlist[1] > 2048) { use_fx = false; return; }
     int e;
     frexpf(bound, &e);  // bound < 2^e
     const int S = iminr(30 - e, 126);

@@ -495,3 +495,51 @@ def test_packed_backward_is_bit_reproducible_and_within_1e4_at_full_size(ops, or
         np.testing.assert_array_equal(np.isfinite(a), np.isfinite(w))
         m = np.isfinite(w)
         assert np.abs(a[m] - w[m]).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_fused_fpn_roi_align_geometry_fuzz(ops, oracle):
+    """40 random geometries: image sizes from 70 to 900 px (feature maps down to 3x3), 1..3 images,
+    channel counts that are not multiples of the slice count (1, 3, 20, 33, 64), 1..77 RoIs incl. the
+    degenerate ones, 7x7 and 14x14: packed and float arg-max forward bit-exact, both backwards
+    within 1e-4, integer-coordinate boxes (coincident taps) included."""
+    rs = np.random.RandomState(4242)
+    for it in range(40):
+        B = int(rs.randint(1, 4))
+        C = int(rs.choice([1, 3, 8, 20, 33, 64]))
+        ih, iw = int(rs.randint(70, 900)), int(rs.randint(70, 900))
+        shapes = [(-(-ih // s), -(-iw // s)) for s in STRIDES]
+        if min(min(s) for s in shapes) < 2:
+            continue
+        R = int(rs.choice([1, 2, 3, 7, 31, 64, 77]))
+        pooled = (14, 14) if it % 5 == 4 else (7, 7)
+        feats = synth.feature_maps(500 + it, batch=B, channels=C, shapes=shapes)
+        rois = synth.random_rois(600 + it, B, R, ih, iw, degenerate=bool(rs.randint(0, 2)), min_size=4.0,
+                                 max_size=float(max(ih, iw)))
+        if rs.randint(0, 2):
+            rois = np.round(rois / 4) * 4  # sample coordinates on integers: left == right taps
+        msg = "problem %d B=%d C=%d image %dx%d R=%d pooled=%s" % (it, B, C, ih, iw, R, pooled)
+        want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, pooled, nthreads=8)
+        tf = [_t(f) for f in feats]
+        got = ops.fpn_roi_align_forward(tf, _t(rois), STRIDES, pooled)
+        for g, w, name in zip(got, want, ("output", "maxidx_x", "maxidx_y")):
+            np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=msg + " " + name)
+        out, am = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, pooled)
+        np.testing.assert_array_equal(out.cpu().numpy(), want[0], err_msg=msg + " packed output")
+        np.testing.assert_array_equal(ops.argmax_codes(am[0], pooled).cpu().numpy() == 255, want[1] == -1,
+                                      err_msg=msg + " packed codes")
+        dy = rs.standard_normal(want[0].shape).astype(np.float32)
+        shp = [f.shape for f in feats]
+        wd = oracle.fpn_roi_align_bwd(dy, rois, want[1], want[2], shp, STRIDES)
+        # 1e-4 absolute where the gradient sums stay in the baseline's range (|dX| <~ 32); where
+        # hundreds of bins pile onto one pixel of a 3x3 map the fp32 sum itself is only defined to
+        # ~|dX| * 1e-6 * sqrt(#adds) (the reference's atomics reorder it from run to run), so the
+        # bar scales with the magnitude there
+        for which, gd in (("float", ops.fpn_roi_align_backward(_t(dy), _t(rois), got[1], got[2], shp, STRIDES)),
+                          ("packed", ops.fpn_roi_align_backward_packed(_t(dy), _t(rois), am, shp, STRIDES))):
+            for g, w in zip(gd, wd):
+                if not w.size:
+                    continue
+                err = float(np.abs(g.cpu().numpy() - w).max())
+                tol = 1e-4 * max(1.0, float(np.abs(w).max()) / 32.0)
+                assert err <= tol, msg + " %s backward max abs err %g (|dX| max %g)" % (which, err, np.abs(w).max())
