@@ -133,3 +133,43 @@ def test_deform_conv_pieces_fuzz(ops, oracle):
         go = ops.deform_col2im_coord(_t(dcol.reshape(gc.shape)), _t(x[None]), _t(off[None]), **a).cpu().numpy()
         assert float(np.abs(go.reshape(wo.shape) - wo).max()) <= 2e-4 * max(1.0, float(np.abs(wo).max())), msg + " col2im_coord"
     assert done >= 30
+
+
+@pytest.mark.gpu
+def test_proposal_v3_fuzz(ops, oracle):
+    """Proposal_v3 (decode -> top-k -> NMS): 40 problems over map sizes 1x1 .. 120x170 (counts
+    below one wave up to the multi-workgroup top-k), 1..15 anchors, pre / post above and below the
+    candidate count, train / test filtering, min_size, tied scores; the three top-k strategies."""
+    from simpledet_amd._lib import lib
+    rs = np.random.RandomState(5)
+    for it in range(40):
+        A = int(rs.choice([1, 3, 9, 15]))
+        scales = {1: (8,), 3: (8,), 9: (4, 8, 16), 15: (2, 4, 8, 16, 32)}[A]
+        ratios = (1.0,) if A == 1 else (0.5, 1.0, 2.0)
+        H, W = [(1, 1), (3, 5), (13, 21), (25, 42), (50, 84), (120, 170)][int(rs.randint(0, 6))]
+        stride = int(rs.choice([8, 16, 32, 64]))
+        B = int(rs.randint(1, 3))
+        cls, bb, info = synth.rpn_outputs(300 + it, B, A, H, W, stride)
+        if rs.randint(0, 3) == 0:
+            cls[:, A:] = np.round(cls[:, A:] * 64) / 64
+        pre = int(rs.choice([-1, 50, 1000, 6000]))
+        post = int(rs.choice([1, 100, 300, 2000]))
+        thr, ms, train = float(rs.choice([0.5, 0.7])), int(rs.choice([0, 16, 64])), bool(rs.randint(0, 2))
+        topk = int(rs.randint(0, 3))
+        msg = "problem %d A=%d %dx%d stride=%d B=%d pre=%d post=%d thr=%g min=%d train=%d topk=%d" % (
+            it, A, H, W, stride, B, pre, post, thr, ms, train, topk)
+        if pre <= 0 and A * H * W > 16384:
+            # "all candidates" beyond the sort capacity is refused, not truncated (the reference's
+            # configs use 2000 .. 12000)
+            with pytest.raises(RuntimeError, match="exceeds 16384"):
+                ops.proposal_v3(_t(cls), _t(bb), _t(info), pre, post, thr, ms, scales, ratios, stride, train)
+            continue
+        want = oracle.proposal_v3(cls, bb, info, pre, post, thr, ms, scales, ratios, stride, train)
+        lib().set_tuning("proposal_topk", topk)
+        try:
+            out, score = ops.proposal_v3(_t(cls), _t(bb), _t(info), pre, post, thr, ms, scales, ratios,
+                                         stride, train)
+        finally:
+            lib().set_tuning("proposal_topk", 0)
+        np.testing.assert_array_equal(score.cpu().numpy(), want[1], err_msg=msg)
+        np.testing.assert_array_equal(out.cpu().numpy(), want[0], err_msg=msg)
