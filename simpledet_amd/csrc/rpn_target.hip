@@ -23,8 +23,10 @@
 //   rpn_sample    ONE wave, images in order (the generator state carries from image to image):
 //                 * MT19937 twist in LDS, 64 outputs per step, tempered on read
 //                 * a batch of 64 outputs is consumed at once: lane t accepts iff
-//                   (out & mask) <= i - #accepts before t, solved by a ballot/popcount fixed point
-//                   (exact, 1-2 rounds), cut at the step where the rejection mask shrinks
+//                   (out & mask) <= i - #accepts before t -- decided by one comparison unless a
+//                   lane sits within 63 of the bound, then by a ballot/popcount fixed point (exact,
+//                   1-2 rounds) --, cut at the accept where the rejection mask shrinks; four
+//                   batches are read and tempered ahead per trip
 //                 * only the last `keep` positions of the permutation survive, and they are final
 //                   after the first `keep` swaps: those swaps are replayed on a sparse array
 //                 so ~200 k dependent draws cost ~3 k wave steps instead of 200 k serial ones
@@ -284,17 +286,33 @@ struct Mt {
   int pos;        // wave uniform
 };
 
+// new[k] = old[k + 397 (mod 624)] ^ twist(old[k], old[k + 1]); for k >= 227 the far word is one this
+// pass has already produced.  Three phases of independent elements -- [0, 227) reads old far words,
+// [227, 454) and [454, 624) read the phase before -- with four elements per lane whose reads are all
+// issued before any write of the phase (a lone wave pays ~12 clocks per dependent instruction:
+// ten batches of 64 in sequence cost 4x as much).
 __device__ __forceinline__ void mt_twist(Mt& m, int lane) {
-  for (int base = 0; base < 624; base += kWave) {
-    const int k = base + lane;
-    unsigned nv = 0;
-    if (k < 624) {
-      const unsigned y = (m.key[k] & 0x80000000u) | (m.key[k + 1 < 624 ? k + 1 : 0] & 0x7fffffffu);
-      const unsigned far = m.key[k + 397 < 624 ? k + 397 : k + 397 - 624];
-      nv = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  constexpr int kBound[4] = {0, 227, 454, 624};
+#pragma unroll
+  for (int ph = 0; ph < 3; ++ph) {
+    unsigned nv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = kBound[ph] + u * kWave + lane;
+      nv[u] = 0;
+      if (k < kBound[ph + 1]) {
+        // (k + 1 == 624 only in the last phase, where word 0 is already new: the reference's wrap)
+        const unsigned y = (m.key[k] & 0x80000000u) | (m.key[k + 1 < 624 ? k + 1 : 0] & 0x7fffffffu);
+        const unsigned far = m.key[k + 397 < 624 ? k + 397 : k - 227];
+        nv[u] = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
     }
-    wave_lds_sync();  // every lane has read its inputs (k+1 of the last lane belongs to the next batch)
-    if (k < 624) m.key[k] = nv;
+    wave_lds_sync();  // every read of the phase precedes its writes
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = kBound[ph] + u * kWave + lane;
+      if (k < kBound[ph + 1]) m.key[k] = nv[u];
+    }
     wave_lds_sync();
   }
   m.pos = 0;
@@ -314,20 +332,52 @@ constexpr int kRpnMaxKeep = 1024;
 // (choice(inds, n - keep, replace=False) disables the FIRST n - keep): fills surv[0..keep) with the
 // list positions that survive and advances the generator by exactly the draws numpy consumes.
 __device__ void rpn_sample(Mt& m, int n, int keep, int* jrec, int* hp, int* hv, int* surv, int lane) {
+  constexpr int NB = 4;  // batches of 64 outputs read (and tempered) ahead per trip
   int i = n - 1;
   const unsigned long long lt = (1ull << lane) - 1;
   while (i >= 1) {
+    if (m.pos >= 624) mt_twist(m, lane);
+    const int avail = 624 - m.pos;
     unsigned mask = (unsigned)i;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
     const int lo = (int)(mask >> 1) + 1;  // steps i in [lo, mask] share this rejection mask
-    if (m.pos >= 624) mt_twist(m, lane);
-    const int chunk = (624 - m.pos) < kWave ? (624 - m.pos) : kWave;
+    unsigned raw[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int idx = m.pos + j * kWave + lane;
+      raw[j] = mt_temper(m.key[idx < 624 ? idx : 623]);
+    }
+    // Fast path, a dozen instructions per batch (a lone wave issues a dependent instruction only
+    // every ~12 clocks, so the count is what matters): lane t accepts iff
+    // v_t <= i - (#accepts among the lanes before it), and that count is at most 63, so when no lane
+    // has i - 63 < v <= i the accepts are simply the lanes with v <= i.  The batch must be whole,
+    // must not reach the end of the mask's segment and must lie past the recorded swaps; anything
+    // else goes through the exact general step below, one batch at a time.
+    int jd = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (avail - j * kWave < kWave) break;
+      const int v = (int)(raw[j] & mask);
+      const unsigned long long sure = __ballot(v <= i - (kWave - 1)), notrej = __ballot(v <= i);
+      const int K = __popcll(sure);
+      if (sure != notrej || K >= i - lo + 1 || (n - 1) - i < keep) break;
+      i -= K;
+      m.pos += kWave;
+      ++jd;
+    }
+    if (jd == NB) continue;
+    // ---- general step for the batch at m.pos (raw[jd] when it was read ahead in full) ----
+    const int left = 624 - m.pos;
+    const int chunk = left < kWave ? left : kWave;
     const bool have = lane < chunk;
-    const unsigned v = have ? (mt_temper(m.key[m.pos + (have ? lane : 0)]) & mask) : 0xffffffffu;
-    // lane t accepts iff v_t <= i - (#accepts among the lanes before it): ballot fixed point
+    unsigned rj = raw[0];
+#pragma unroll
+    for (int j = 1; j < NB; ++j)
+      if (jd == j) rj = raw[j];
+    const unsigned v = have ? (rj & mask) : 0xffffffffu;
     bool acc = have && v <= (unsigned)i;
     unsigned long long bits = __ballot(acc);
-    while (true) {
+    while (true) {  // ballot / popcount fixed point: exact, 1-2 rounds
       const int c = __popcll(bits & lt);
       const bool acc2 = have && (long)v <= (long)i - c;
       const unsigned long long b2 = __ballot(acc2);
