@@ -129,6 +129,16 @@ int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const 
                                 const int* strides_host, int nlvl, int req_data, int B, int C, int R,
                                 int pooled_h, int pooled_w, float roi_canonical_scale,
                                 float roi_canonical_level, void* stream);
+/* The same with a device workspace of sd_fpn_roi_align_bwd_workspace_bytes(): the per-band RoI
+ * lists are then built by one small pre-pass instead of by every channel's workgroup (same
+ * results bit for bit).  workspace may be NULL (= the call above). */
+size_t sd_fpn_roi_align_bwd_workspace_bytes(const int* Hs_host, const int* Ws_host, int nlvl, int B, int R);
+int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float* rois, const uint8_t* argmax,
+                                   const float* coords, float* const* d_feats_host, const int* Hs_host,
+                                   const int* Ws_host, const int* strides_host, int nlvl, int req_data, int B,
+                                   int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
+                                   float roi_canonical_level, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 /* assign_layer_fpn CustomOp (models/FPN/assign_layer_fpn.py:10-73): rois (n_rois,4) ->
  * rois_per_level (nlvl, n_rois, 4) zero-masked, and optionally level (n_rois) int32 (-1 = none) */
 int sd_fpn_roi_assign(const float* rois, int n_rois, const int* strides_host, int nlvl,

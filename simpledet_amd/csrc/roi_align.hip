@@ -967,6 +967,10 @@ struct BwdFusedArgs {
   int filter;  // 1: fused FPN (a RoI contributes to its assigned level only), 0: single level
   int req;
   int ablate;
+  // packed4 with a workspace: the RoI lists of all (level, image, band) units, built once by
+  // roi_align_bwd_lists instead of once per channel: unit u -> [count, weight bound, R indices]
+  int* ws_list;
+  int unit_base[SD_MAX_FPN_LEVELS];  // first unit of launch-order level li
 };
 
 template <int PP, int THREADS, bool PK>
@@ -1177,59 +1181,18 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
 //         pixel of a given column (a bin adds total weight <= 1), ny likewise;
 //     at the baseline that is ~2e-6 * max|dY| per unit.  Non-finite dY (inf / nan must propagate)
 //     switches the workgroup to the float compare-and-swap adds.
-template <int PH, int PW, int THREADS, int TCH>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: four 512-thread workgroups per CU
-void roi_align_bwd_packed4(BwdFusedArgs a) {
-  constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4, TS = 3 * (PH + PW);
-  constexpr int CW = kCoordWords * (PH + PW);  // words per RoI in the forward's table
-  constexpr bool TAIL = (PP % 4) != 0;         // last lane of a RoI owns fewer than four bins
-  static_assert(TS % 2 == 0, "table rows are copied as float2");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  // ---- block -> (level, image, band, channel) ----
-  int li = 0;
-  while (li + 1 < a.nlaunch && (int)blockIdx.x >= a.block_end[li]) ++li;
-  const int lvl = a.order[li];
-  const int b0 = (int)blockIdx.x - (li ? a.block_end[li - 1] : 0);
-  const int H = a.L.H[lvl], W = a.L.W[lvl];
-  const float scale = a.L.scale[lvl];
-  const int nbands = a.nbands[lvl];
-  int u, c;
-  if (a.C % kNumXCD == 0) {  // an XCD keeps a contiguous channel range: dY/argmax lines stay in one L2
-    const int xcd = b0 % kNumXCD, j = b0 / kNumXCD, per = a.C / kNumXCD;
-    c = xcd * per + (j % per);
-    u = j / per;
-  } else {
-    c = b0 % a.C;
-    u = b0 / a.C;
-  }
-  const int img = u / nbands, band = u % nbands;
-  const int row0 = band * a.band_rows[lvl];
-  const int row1 = iminr(row0 + a.band_rows[lvl], H);
-  const int band_elems = (row1 - row0) * W;
-  const int plane_pad = (band_elems + 3) & ~3;
-  float* plane = smem;
-  float* tab = smem + plane_pad;                      // [TCH][TS] sample coordinates
-  int* list = reinterpret_cast<int*>(tab + TCH * TS);  // RoIs of this image on this band
-  int* nlist = list + a.R;  // [0] count [1] bound [2] max|dY| bits, first chunk [3] non-finite [4] max|dY| bits, all
-  int* plane_i = reinterpret_cast<int*>(smem);
-
-  // the RoI boxes are in flight while the band is zeroed
-  const bool has_r0 = tid < a.R;
-  float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (has_r0) rb0 = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + tid) * 4);
-  {
-    float4* p4 = reinterpret_cast<float4*>(smem);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
-  }
-  if (tid < 8) nlist[tid] = 0;
-  // The list is built in RoI order (ballot + prefix over the waves, no atomic slot counter): the
-  // first chunk, whose gradients set the fixed-point scale below, is then a deterministic set and
-  // the whole backward a deterministic function of its inputs.
+// RoIs of image `img` whose taps can fall on rows [row0, row1) of level `lvl`, in RoI order (ballot
+// + prefix over the waves, no atomic slot counter: the list and everything derived from it are a
+// deterministic function of the inputs), and the band's weight bound (see roi_align_bwd_packed4).
+// list[0 .. count), nlist[0] = count, nlist[1] = bound; wcnt: THREADS / 64 words of scratch.
+// Ends with a barrier.
+template <int PH, int PW, int THREADS>
+__device__ __forceinline__ void bwd_band_list(const BwdFusedArgs& a, int lvl, int img, int nbands, int row0,
+                                              int row1, float4 rb0, int* list, int* nlist, int* wcnt) {
   constexpr int NW = THREADS / kWave;
-  int* wcnt = nlist + 8;  // [NW] RoIs taken per wave in the current sweep
-  const int wave = tid / kWave, lane = tid & (kWave - 1);
+  const int tid = threadIdx.x, wave = tid / kWave, lane = tid & (kWave - 1);
+  const int H = a.L.H[lvl];
+  const float scale = a.L.scale[lvl];
   int base = 0, bound_sum = 0;
   for (int r0 = 0; r0 < a.R; r0 += THREADS) {
     const int r = r0 + tid;
@@ -1274,6 +1237,103 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   if (lane == 0) atomicAdd(nlist + 1, bound_sum);
   if (tid == 0) nlist[0] = base;
   __syncthreads();
+}
+
+// One workgroup per (level, image, band) unit: its list into the workspace, read by the 256
+// channel workgroups of roi_align_bwd_packed4 instead of being rebuilt by each of them.
+template <int PH, int PW>
+__global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
+  constexpr int THREADS = 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* list = reinterpret_cast<int*>(smem);
+  int* nlist = list + a.R;
+  const int tid = threadIdx.x;
+  int li = 0;
+  while (li + 1 < a.nlaunch && (int)blockIdx.x >= a.unit_base[li + 1]) ++li;
+  const int lvl = a.order[li];
+  const int u = (int)blockIdx.x - a.unit_base[li];
+  const int nbands = a.nbands[lvl];
+  const int img = u / nbands, band = u % nbands;
+  const int row0 = band * a.band_rows[lvl];
+  const int row1 = iminr(row0 + a.band_rows[lvl], a.L.H[lvl]);
+  float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < a.R) rb0 = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + tid) * 4);
+  if (tid < 8) nlist[tid] = 0;
+  __syncthreads();
+  bwd_band_list<PH, PW, THREADS>(a, lvl, img, nbands, row0, row1, rb0, list, nlist, nlist + 8);
+  int* dst = a.ws_list + (long)blockIdx.x * (a.R + 2);
+  if (tid < 2) dst[tid] = nlist[tid];
+  for (int i = tid; i < nlist[0]; i += THREADS) dst[2 + i] = list[i];
+}
+
+template <int PH, int PW, int THREADS, int TCH>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: four 512-thread workgroups per CU
+void roi_align_bwd_packed4(BwdFusedArgs a) {
+  constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4, TS = 3 * (PH + PW);
+  constexpr int CW = kCoordWords * (PH + PW);  // words per RoI in the forward's table
+  constexpr bool TAIL = (PP % 4) != 0;         // last lane of a RoI owns fewer than four bins
+  static_assert(TS % 2 == 0, "table rows are copied as float2");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  // ---- block -> (level, image, band, channel) ----
+  int li = 0;
+  while (li + 1 < a.nlaunch && (int)blockIdx.x >= a.block_end[li]) ++li;
+  const int lvl = a.order[li];
+  const int b0 = (int)blockIdx.x - (li ? a.block_end[li - 1] : 0);
+  const int H = a.L.H[lvl], W = a.L.W[lvl];
+  const int nbands = a.nbands[lvl];
+  int u, c;
+  if (a.C % kNumXCD == 0) {  // an XCD keeps a contiguous channel range: dY/argmax lines stay in one L2
+    const int xcd = b0 % kNumXCD, j = b0 / kNumXCD, per = a.C / kNumXCD;
+    c = xcd * per + (j % per);
+    u = j / per;
+  } else {
+    c = b0 % a.C;
+    u = b0 / a.C;
+  }
+  const int img = u / nbands, band = u % nbands;
+  const int row0 = band * a.band_rows[lvl];
+  const int row1 = iminr(row0 + a.band_rows[lvl], H);
+  const int band_elems = (row1 - row0) * W;
+  const int plane_pad = (band_elems + 3) & ~3;
+  float* plane = smem;
+  float* tab = smem + plane_pad;                      // [TCH][TS] sample coordinates
+  int* list = reinterpret_cast<int*>(tab + TCH * TS);  // RoIs of this image on this band
+  int* nlist = list + a.R;  // [0] count [1] bound [2] max|dY| bits, first chunk [3] non-finite [4] max|dY| bits, all
+  int* plane_i = reinterpret_cast<int*>(smem);
+
+  // the RoI boxes (or the unit's list) are in flight while the band is zeroed
+  int* wcnt = nlist + 8;  // [THREADS / 64] scratch of the list builder
+  const int* wl = nullptr;
+  int wl_n = 0, wl_bound = 0, wl_first = 0;
+  float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.ws_list) {
+    wl = a.ws_list + (long)(a.unit_base[li] + u) * (a.R + 2);
+    wl_n = wl[0];
+    wl_bound = wl[1];
+    if (tid < wl_n) wl_first = wl[2 + tid];
+  } else if (tid < a.R) {
+    rb0 = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + tid) * 4);
+  }
+  {
+    float4* p4 = reinterpret_cast<float4*>(smem);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
+  }
+  if (tid < 8) nlist[tid] = 0;
+  if (wl) {
+    if (tid < wl_n) list[tid] = wl_first;
+    for (int i = tid + THREADS; i < wl_n; i += THREADS) list[i] = wl[2 + i];
+    __syncthreads();  // (nlist cleared)
+    if (tid == 0) {
+      nlist[0] = wl_n;
+      nlist[1] = wl_bound;
+    }
+    __syncthreads();
+  } else {
+    __syncthreads();
+    bwd_band_list<PH, PW, THREADS>(a, lvl, img, nbands, row0, row1, rb0, list, nlist, wcnt);
+  }
   const int nl = *nlist;
 
   // wave-uniform bases + 32-bit lane offsets (the launcher checks R*C*PP < 2^31)
@@ -1477,7 +1537,8 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
 }
 
 // levels: dx[l] / H / W / scale from a.L; returns SD_ERR_UNSUPPORTED when a level does not fit
-static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
+static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace = nullptr,
+                            size_t workspace_bytes = 0) {
   // packed arg-max: the wide-load kernel (roi_align_bwd_packed4); its coordinate tables share the
   // LDS with the band, so the band budget is a little smaller
   const bool wide = a.amax8 && tuning("roi_align_bwd_packed", 1) == 1;
@@ -1531,6 +1592,21 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st) {
   a.nlaunch = nl;
   if (total == 0) return SD_OK;
   if (total >= (1L << 31)) return SD_ERR_UNSUPPORTED;
+  // RoI lists of the (level, image, band) units, once per launch instead of once per channel
+  a.ws_list = nullptr;
+  long units = 0;
+  for (int i = 0; i < nl; ++i) {
+    a.unit_base[i] = (int)units;
+    units += (long)a.B * a.nbands[a.order[i]];
+  }
+  if (nl < SD_MAX_FPN_LEVELS) a.unit_base[nl] = (int)units;
+  if (wide && workspace && workspace_bytes >= (size_t)units * (a.R + 2) * sizeof(int) &&
+      nl < SD_MAX_FPN_LEVELS && tuning("roi_align_bwd_lists", 1) == 1) {
+    a.ws_list = static_cast<int*>(workspace);
+    const size_t lds = (size_t)(a.R + 8 + 16) * 4;
+    if (a.PP == 49) hipLaunchKernelGGL((roi_align_bwd_lists<7, 7>), dim3((unsigned)units), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((roi_align_bwd_lists<14, 14>), dim3((unsigned)units), dim3(512), lds, st, a);
+  }
   int threads = tuning("roi_align_bwd_threads", 0);
   if (threads != 256 && threads != 512) threads = 512;
   if (wide) {
@@ -1965,6 +2041,20 @@ extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const
   return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+extern "C" size_t sd_fpn_roi_align_bwd_workspace_bytes(const int* Hs_host, const int* Ws_host, int nlvl,
+                                                       int B, int R) {
+  if (!Hs_host || !Ws_host || nlvl <= 0 || B <= 0 || R <= 0) return 0;
+  const long budget = 36 * 1024;  // the smallest band the launcher uses gives the most units
+  long units = 0;
+  for (int l = 0; l < nlvl; ++l) {
+    const long plane_bytes = (long)Hs_host[l] * Ws_host[l] * 4;
+    long nb = (plane_bytes + budget - 1) / budget;
+    if (nb < 1) nb = 1;
+    units += (long)B * (nb + 1);
+  }
+  return (size_t)units * (R + 2) * sizeof(int);
+}
+
 extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois,
                                            const uint8_t* argmax, const float* coords,
                                            float* const* d_feats_host,
@@ -1973,6 +2063,19 @@ extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* r
                                            int C, int R, int pooled_h, int pooled_w,
                                            float roi_canonical_scale, float roi_canonical_level,
                                            void* stream) {
+  return sd_fpn_roi_align_bwd_packed_ws(out_grad, rois, argmax, coords, d_feats_host, Hs_host, Ws_host,
+                                        strides_host, nlvl, req_data, B, C, R, pooled_h, pooled_w,
+                                        roi_canonical_scale, roi_canonical_level, nullptr, 0, stream);
+}
+
+extern "C" int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float* rois,
+                                              const uint8_t* argmax, const float* coords,
+                                              float* const* d_feats_host,
+                                              const int* Hs_host, const int* Ws_host,
+                                              const int* strides_host, int nlvl, int req_data, int B,
+                                              int C, int R, int pooled_h, int pooled_w,
+                                              float roi_canonical_scale, float roi_canonical_level,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
   SD_REQUIRE(d_feats_host && Hs_host && Ws_host && strides_host, "null level description");
   SD_REQUIRE(req_data == SD_REQ_NULL || req_data == SD_REQ_WRITE || req_data == SD_REQ_ADD,
@@ -2004,7 +2107,8 @@ extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* r
   SD_REQUIRE(out_grad && rois && argmax && coords, "null tensor pointer");
   SD_REQUIRE(((uintptr_t)argmax & 3) == 0 && ((uintptr_t)coords & 7) == 0,
              "argmax must be 4-byte and coords 8-byte aligned");
-  const int e = launch_bwd_fused(f, nlvl, (hipStream_t)stream);
+  SD_REQUIRE(!workspace || ((uintptr_t)workspace & 3) == 0, "workspace must be 4-byte aligned");
+  const int e = launch_bwd_fused(f, nlvl, (hipStream_t)stream, workspace, workspace_bytes);
   if (e == SD_ERR_UNSUPPORTED) return fail(e, "packed arg-max backward: a level does not fit LDS");
   return e;
 }

@@ -699,10 +699,19 @@ def _build_ops(mx):
                 raise RuntimeError("fpn_roi_align: all feature gradients must share one req")
             B, C = feats[0].shape[:2]
             ptrs, Hs, Ws = self._levels(in_grad[:-1])
-            lib().call("sd_fpn_roi_align_bwd_packed" if self.packed else "sd_fpn_roi_align_bwd",
-                       _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]), _ptr(out_data[2]), ptrs, Hs,
-                       Ws, _iarr(self.strides), len(feats), rq.pop(), B, C, rois.shape[1],
-                       self.pooled[0], self.pooled[1], float(self.scale0), float(self.lvl0), None)
+            if self.packed:  # with the workspace the per-band RoI lists are built once, not per channel
+                lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
+                wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(Hs, Ws, len(feats), B, rois.shape[1])
+                ws = _scratch(rois, wsb)
+                lib().call("sd_fpn_roi_align_bwd_packed_ws", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                           _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B, C,
+                           rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
+                           float(self.lvl0), _ptr(ws), ctypes.c_size_t(wsb), None)
+            else:
+                lib().call("sd_fpn_roi_align_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                           _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B, C,
+                           rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
+                           float(self.lvl0), None)
             _sync()
             self.assign(in_grad[-1], req[-1], 0)
 

@@ -218,11 +218,14 @@ def fpn_roi_align_backward_packed(out_grad, rois, argmax, feat_shapes, rcnn_stri
                    for s in feat_shapes]
     for i, f in enumerate(d_feats):
         _chk(f, "d_feats[%d]" % i, ndim=4)
-    lib().call("sd_fpn_roi_align_bwd_packed", _p(out_grad), _p(rois), _p(argmax), _p(coords),
-               _parr(d_feats),
-               _iarr([f.shape[2] for f in d_feats]), _iarr([f.shape[3] for f in d_feats]),
+    hs, ws_ = _iarr([f.shape[2] for f in d_feats]), _iarr([f.shape[3] for f in d_feats])
+    lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
+    wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(hs, ws_, len(d_feats), B, R)
+    work = torch.empty((max(int(wsb), 4) + 3) // 4, device=out_grad.device, dtype=torch.int32)
+    lib().call("sd_fpn_roi_align_bwd_packed_ws", _p(out_grad), _p(rois), _p(argmax), _p(coords),
+               _parr(d_feats), hs, ws_,
                _iarr(rcnn_stride), len(d_feats), rd, B, C, R, ph, pw, float(roi_canonical_scale),
-               float(roi_canonical_level), _stream())
+               float(roi_canonical_level), _p(work), ctypes.c_size_t(work.numel() * 4), _stream())
     return d_feats
 
 

@@ -498,6 +498,29 @@ def test_packed_backward_is_bit_reproducible_and_within_1e4_at_full_size(ops, or
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pooled,num", [((7, 7), 512), ((14, 14), 128)])
+def test_packed_backward_list_prepass_equals_per_workgroup_lists(ops, pooled, num):
+    """The per-band RoI lists from the workspace pre-pass (one small kernel) and the lists every
+    channel's workgroup builds for itself (knob roi_align_bwd_lists = 0, also the path without a
+    workspace) give the same gradients bit for bit at the baseline size."""
+    import torch
+    from simpledet_amd._lib import lib
+    feats = [_t(f) for f in synth.feature_maps(8, batch=2, channels=64)]
+    rois = _t(synth.random_rois(8, 2, num))
+    out, am = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, pooled)
+    dy = torch.randn_like(out)
+    shapes = [f.shape for f in feats]
+    g1 = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
+    lib().set_tuning("roi_align_bwd_lists", 0)
+    try:
+        g0 = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
+    finally:
+        lib().set_tuning("roi_align_bwd_lists", 1)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_fused_fpn_roi_align_geometry_fuzz(ops, oracle):
     """40 random geometries: image sizes from 70 to 900 px (feature maps down to 3x3), 1..3 images,
     channel counts that are not multiples of the slice count (1, 3, 20, 33, 64), 1..77 RoIs incl. the
