@@ -299,7 +299,7 @@ def main():
         "algorithmic_bytes": alg,
         "avg_launch_ms": fwd_ms,
         "backward": {
-            "kernel": "sd::roi_align_bwd_packed4<7,7,512,32> (all FPN levels, 1 launch/step) + sd::roi_align_bwd_lists (24 workgroups, ~6 us, inside avg_ms)",
+            "kernel": "sd::roi_align_bwd_packed4<7,7,512,32,true> (all FPN levels, 1 launch/step) + sd::roi_align_bwd_lists (list / tap-table pre-pass, ~6.7 us, inside avg_ms)",
             "achieved": alg / (bwd_ms * 1e-3) / 1e9,
             "frac": alg / (bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "avg_ms": bwd_ms,

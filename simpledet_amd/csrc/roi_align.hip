@@ -970,6 +970,7 @@ struct BwdFusedArgs {
   // packed4 with a workspace: the RoI lists of all (level, image, band) units, built once by
   // roi_align_bwd_lists instead of once per channel: unit u -> [count, weight bound, R indices]
   int* ws_list;
+  float* ws_taps;                    // [unit][R][2 * 3 * (PH + PW)] band-relative tap entries, list order
   int unit_base[SD_MAX_FPN_LEVELS];  // first unit of launch-order level li
 };
 
@@ -1239,8 +1240,9 @@ __device__ __forceinline__ void bwd_band_list(const BwdFusedArgs& a, int lvl, in
   __syncthreads();
 }
 
-// One workgroup per (level, image, band) unit: its list into the workspace, read by the 256
-// channel workgroups of roi_align_bwd_packed4 instead of being rebuilt by each of them.
+// Pre-pass per (level, image, band) unit: its list into the workspace, read by the 256 channel
+// workgroups of roi_align_bwd_packed4 instead of being rebuilt by each of them.
+constexpr int kListSplit = 4;
 template <int PH, int PW>
 __global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
   constexpr int THREADS = 512;
@@ -1248,10 +1250,14 @@ __global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
   int* list = reinterpret_cast<int*>(smem);
   int* nlist = list + a.R;
   const int tid = threadIdx.x;
+  // kListSplit workgroups per unit: each builds the (cheap) list, the first stores it, all share
+  // the tap entries -- the entry loop is a chain of dependent round trips (list -> coordinate ->
+  // entry), so more workgroups shorten the pre-pass
+  const int unit = (int)blockIdx.x / kListSplit, part = (int)blockIdx.x % kListSplit;
   int li = 0;
-  while (li + 1 < a.nlaunch && (int)blockIdx.x >= a.unit_base[li + 1]) ++li;
+  while (li + 1 < a.nlaunch && unit >= a.unit_base[li + 1]) ++li;
   const int lvl = a.order[li];
-  const int u = (int)blockIdx.x - a.unit_base[li];
+  const int u = unit - a.unit_base[li];
   const int nbands = a.nbands[lvl];
   const int img = u / nbands, band = u % nbands;
   const int row0 = band * a.band_rows[lvl];
@@ -1261,17 +1267,49 @@ __global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
   if (tid < 8) nlist[tid] = 0;
   __syncthreads();
   bwd_band_list<PH, PW, THREADS>(a, lvl, img, nbands, row0, row1, rb0, list, nlist, nlist + 8);
-  int* dst = a.ws_list + (long)blockIdx.x * (a.R + 2);
-  if (tid < 2) dst[tid] = nlist[tid];
-  for (int i = tid; i < nlist[0]; i += THREADS) dst[2 + i] = list[i];
+  int* dst = a.ws_list + (long)unit * (a.R + 2);
+  const int nl = nlist[0];
+  if (part == 0) {
+    if (tid < 2) dst[tid] = nlist[tid];
+    for (int i = tid; i < nl; i += THREADS) dst[2 + i] = list[i];
+  }
+  // ... and the tap entries of the listed RoIs (see roi_align_bwd_packed4): per sample coordinate
+  // of the forward's table {neighbours, fraction} with the backward's own expressions, the row
+  // neighbours as offsets inside this band (0xffff: outside), 8 bytes each, in list order
+  if (a.ws_taps) {
+    constexpr int NE = 3 * (PH + PW), CW = kCoordWords * (PH + PW);
+    const int H = a.L.H[lvl], W = a.L.W[lvl];
+    const float* cob = a.coords + (long)img * a.R * CW;
+    float* tdst = a.ws_taps + (long)unit * a.R * (2 * NE);
+    for (int i = part * THREADS + tid; i < nl * NE; i += kListSplit * THREADS) {
+      const int j = i / NE, e = i - j * NE;
+      const float v = cob[list[j] * CW + e];
+      const bool row = e < 3 * PH;
+      const int size = row ? H : W;
+      const int lo = iminr(imaxr((int)floorf(v), 0), size - 1);
+      const int hi = iminr(imaxr((int)ceilf(v), 0), size - 1);
+      const float frac = (lo == hi) ? 0.5f : (v - (float)lo);  // (v - low) / (high - low), high - low == 1
+      unsigned w0 = (unsigned)lo | ((unsigned)hi << 16);
+      if (row) {
+        const unsigned o0 = (lo >= row0 && lo < row1) ? (unsigned)((lo - row0) * W) : 0xffffu;
+        const unsigned o1 = (hi >= row0 && hi < row1) ? (unsigned)((hi - row0) * W) : 0xffffu;
+        w0 = o0 | (o1 << 16);
+      }
+      *reinterpret_cast<float2*>(tdst + (long)j * (2 * NE) + 2 * e) = make_float2(__uint_as_float(w0), frac);
+    }
+  }
 }
 
-template <int PH, int PW, int THREADS, int TCH>
+template <int PH, int PW, int THREADS, int TCH, bool TAPS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: four 512-thread workgroups per CU
 void roi_align_bwd_packed4(BwdFusedArgs a) {
-  constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4, TS = 3 * (PH + PW);
+  // TAPS: the workspace pre-pass has left band-relative tap entries (8 bytes per sample coordinate)
+  // for the listed RoIs; otherwise the table holds the forward's coordinates (4 bytes each)
+  constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4, NE = 3 * (PH + PW);
+  constexpr int TS = TAPS ? 2 * NE : NE;
   constexpr int CW = kCoordWords * (PH + PW);  // words per RoI in the forward's table
   constexpr bool TAIL = (PP % 4) != 0;         // last lane of a RoI owns fewer than four bins
+  static_assert(TS % 4 == 0 || !TAPS, "tap tables are copied as float4");
   static_assert(TS % 2 == 0, "table rows are copied as float2");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -1422,7 +1460,58 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
     }
   };
 
+  // TAPS: a bin reads the two 8-byte tap entries of its winning sample (row entry: band offsets of
+  // the two neighbour rows, 0xffff = outside the band, + fraction; column entry: the two columns +
+  // fraction) and needs no floor / ceil / clamp / row multiply of its own; with fixed point the
+  // gradient is scaled first (a power of two: the products are the same floats times 2^S).
+  auto scatter_taps = [&](const Item& it, int slot) {
+    if (it.code == 0xffffffffu || (SD_ABLATE(a, 1))) return;  // (profiling build, 1: no scatter)
+    const float* tj = tab + slot * TS;
+    const float gg[4] = {it.g.x, it.g.y, it.g.z, it.g.w};
+    int p = it.b0 / PW, q = it.b0 - p * PW;
+#pragma unroll
+    for (int s = 0; s < 4; ++s, ++q) {
+      if (q == PW) { q = 0; ++p; }
+      const int code = (it.code >> (8 * s)) & 0xff;
+      if (code == 255) continue;
+      const int k = (code * 11) >> 5, l = code - 3 * k;  // code = 3k + l, k,l in 0..2
+      const float2 re = *reinterpret_cast<const float2*>(tj + 2 * (p * 3 + k));
+      const float2 ce = *reinterpret_cast<const float2*>(tj + 2 * (3 * PH + q * 3 + l));
+      const unsigned rp = __float_as_uint(re.x), cp = __float_as_uint(ce.x);
+      const int o0 = rp & 0xffffu, o1 = rp >> 16, wleft = cp & 0xffffu, wright = cp >> 16;
+      const float alpha = re.y, beta = ce.y;
+      const float g = use_fx ? gg[s] * fx_scale : gg[s];
+      const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
+      const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
+      if (use_fx) {
+        if (o0 != 0xffff) {
+          lds_add_i32(plane_i + o0 + wleft, w00, 1.f);
+          lds_add_i32(plane_i + o0 + wright, w01, 1.f);
+        }
+        if (o1 != 0xffff) {
+          lds_add_i32(plane_i + o1 + wleft, w10, 1.f);
+          lds_add_i32(plane_i + o1 + wright, w11, 1.f);
+        }
+        continue;
+      }
+      if (o0 != 0xffff) {
+        lds_add_cas(plane + o0 + wleft, w00);
+        lds_add_cas(plane + o0 + wright, w01);
+      }
+      if (o1 != 0xffff) {
+        lds_add_cas(plane + o1 + wleft, w10);
+        lds_add_cas(plane + o1 + wright, w11);
+      }
+    }
+  };
+
   auto stage_tables = [&](int cb, int ncur) {
+    if (TAPS) {  // the chunk's entries are contiguous in the workspace (list order)
+      const float4* src = reinterpret_cast<const float4*>(
+          a.ws_taps + ((long)(a.unit_base[li] + u) * a.R + cb) * TS);
+      for (int i = tid; i < ncur * (TS / 4); i += THREADS) reinterpret_cast<float4*>(tab)[i] = src[i];
+      return;
+    }
     for (int i = tid; i < ncur * (TS / 2); i += THREADS) {
       const int j = i / (TS / 2), e2 = i - j * (TS / 2);
       const float2 v = *reinterpret_cast<const float2*>(cob + list[cb + j] * CW + 2 * e2);
@@ -1490,7 +1579,8 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
         const float ag = abs4(cur.g);
         bad |= !(ag <= FLT_MAX);
         m_all = fmaxr(m_all, ag);
-        scatter_item(cur, cur.j);
+        if (TAPS) scatter_taps(cur, cur.j);
+        else scatter_item(cur, cur.j);
         cur = nxt;
       }
     }
@@ -1543,30 +1633,56 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   // LDS with the band, so the band budget is a little smaller
   const bool wide = a.amax8 && tuning("roi_align_bwd_packed", 1) == 1;
   const int tch = tuning("roi_align_bwd_tch", a.PP == 49 ? 32 : 16);
-  const int ts_words = a.PP == 49 ? 3 * 14 : 3 * 28;
-  const size_t tab_bytes = wide ? (size_t)tch * ts_words * 4 : 0;
-  const long budget = (long)tuning("roi_align_bwd_lds_kb", 36) * 1024;
+  const int ne = a.PP == 49 ? 3 * 14 : 3 * 28;  // sample coordinates per RoI
   a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
+  if ((long)a.R * a.C * a.PP >= (1L << 31)) return SD_ERR_UNSUPPORTED;  // 32-bit lane offsets
   size_t lds_max = 0;
   long work[SD_MAX_FPN_LEVELS];
   int nl = 0;
-  if ((long)a.R * a.C * a.PP >= (1L << 31)) return SD_ERR_UNSUPPORTED;  // 32-bit lane offsets
-  for (int l = 0; l < nlvl; ++l) {
-    if (!a.dx[l]) continue;
-    if (a.L.H[l] > 32767 || a.L.W[l] > 32767) return SD_ERR_UNSUPPORTED;  // packed neighbour pairs
-    const long plane_bytes = (long)a.L.H[l] * a.L.W[l] * 4;
-    int nb = (int)((plane_bytes + budget - 1) / budget);
-    if (nb < 1) nb = 1;
-    int rows = (a.L.H[l] + nb - 1) / nb;
-    nb = (a.L.H[l] + rows - 1) / rows;
-    a.band_rows[l] = rows;
-    a.nbands[l] = nb;
-    const size_t lds =
-        (size_t)((((long)rows * a.L.W[l] + 3) & ~3L) * 4) + tab_bytes + (size_t)(a.R + 8 + 16) * 4;
-    if (lds > 150 * 1024) return SD_ERR_UNSUPPORTED;
-    if (lds > lds_max) lds_max = lds;
-    work[l] = (long)a.B * nb * a.C;
-    a.order[nl++] = l;
+  long units = 0;
+  // bands of every level for a band budget and a table entry size (words per sample coordinate)
+  auto plan = [&](long budget, int entry_words) -> int {
+    const size_t tab_bytes = wide ? (size_t)tch * ne * entry_words * 4 : 0;
+    lds_max = 0;
+    nl = 0;
+    units = 0;
+    for (int l = 0; l < nlvl; ++l) {
+      if (!a.dx[l]) continue;
+      if (a.L.H[l] > 32767 || a.L.W[l] > 32767) return SD_ERR_UNSUPPORTED;  // packed neighbour pairs
+      const long plane_bytes = (long)a.L.H[l] * a.L.W[l] * 4;
+      int nb = (int)((plane_bytes + budget - 1) / budget);
+      if (nb < 1) nb = 1;
+      int rows = (a.L.H[l] + nb - 1) / nb;
+      nb = (a.L.H[l] + rows - 1) / rows;
+      a.band_rows[l] = rows;
+      a.nbands[l] = nb;
+      if (wide && (long)rows * a.L.W[l] >= 65535) return SD_ERR_UNSUPPORTED;  // 16-bit band offsets
+      const size_t lds =
+          (size_t)((((long)rows * a.L.W[l] + 3) & ~3L) * 4) + tab_bytes + (size_t)(a.R + 8 + 16) * 4;
+      if (lds > 150 * 1024) return SD_ERR_UNSUPPORTED;
+      if (lds > lds_max) lds_max = lds;
+      work[l] = (long)a.B * nb * a.C;
+      units += (long)a.B * nb;
+      a.order[nl++] = l;
+    }
+    return SD_OK;
+  };
+  // With the workspace pre-pass providing 8-byte tap entries the tables take twice the LDS; the band
+  // budget drops from 36 to 27 KB so that FOUR workgroups still share a CU (27 + 10.75 + 2.1 KB):
+  // 86.6 us against 98.5 us with 36 KB bands at three per CU.
+  const int lists_mode = tuning("roi_align_bwd_lists", 1);  // 1 lists + taps, 2 lists only, 0 none
+  bool use_taps = false, use_lists = false;
+  size_t list_bytes = 0;
+  if (wide && workspace && ((uintptr_t)workspace & 15) == 0 && lists_mode == 1) {
+    if (int e = plan((long)tuning("roi_align_bwd_lds_kb", 27) * 1024, 2)) return e;
+    list_bytes = (((size_t)units * (a.R + 2) * sizeof(int)) + 15) & ~(size_t)15;
+    use_taps = workspace_bytes >= list_bytes + (size_t)units * a.R * 2 * ne * sizeof(float);
+    use_lists = use_taps;
+  }
+  if (!use_taps) {
+    if (int e = plan((long)tuning("roi_align_bwd_lds_kb", 36) * 1024, 1)) return e;
+    list_bytes = (((size_t)units * (a.R + 2) * sizeof(int)) + 15) & ~(size_t)15;
+    use_lists = wide && workspace && lists_mode >= 1 && workspace_bytes >= list_bytes;
   }
   // Launch order = expected duration of ONE workgroup, longest first: a level that fits in one
   // band sees all of its image's RoIs in every workgroup (2x the items of a P2 band at the
@@ -1592,27 +1708,33 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   a.nlaunch = nl;
   if (total == 0) return SD_OK;
   if (total >= (1L << 31)) return SD_ERR_UNSUPPORTED;
-  // RoI lists of the (level, image, band) units, once per launch instead of once per channel
+  // RoI lists (and tap tables) of the (level, image, band) units, once per launch instead of once
+  // per channel
   a.ws_list = nullptr;
-  long units = 0;
-  for (int i = 0; i < nl; ++i) {
-    a.unit_base[i] = (int)units;
-    units += (long)a.B * a.nbands[a.order[i]];
+  a.ws_taps = nullptr;
+  {
+    long ub = 0;
+    for (int i = 0; i < nl; ++i) {
+      a.unit_base[i] = (int)ub;
+      ub += (long)a.B * a.nbands[a.order[i]];
+    }
+    if (nl < SD_MAX_FPN_LEVELS) a.unit_base[nl] = (int)ub;
   }
-  if (nl < SD_MAX_FPN_LEVELS) a.unit_base[nl] = (int)units;
-  if (wide && workspace && workspace_bytes >= (size_t)units * (a.R + 2) * sizeof(int) &&
-      nl < SD_MAX_FPN_LEVELS && tuning("roi_align_bwd_lists", 1) == 1) {
+  if (use_lists && nl < SD_MAX_FPN_LEVELS) {
     a.ws_list = static_cast<int*>(workspace);
+    if (use_taps) a.ws_taps = reinterpret_cast<float*>(static_cast<char*>(workspace) + list_bytes);
     const size_t lds = (size_t)(a.R + 8 + 16) * 4;
-    if (a.PP == 49) hipLaunchKernelGGL((roi_align_bwd_lists<7, 7>), dim3((unsigned)units), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((roi_align_bwd_lists<14, 14>), dim3((unsigned)units), dim3(512), lds, st, a);
+    const dim3 g((unsigned)units * kListSplit);
+    if (a.PP == 49) hipLaunchKernelGGL((roi_align_bwd_lists<7, 7>), g, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((roi_align_bwd_lists<14, 14>), g, dim3(512), lds, st, a);
   }
   int threads = tuning("roi_align_bwd_threads", 0);
   if (threads != 256 && threads != 512) threads = 512;
   if (wide) {
 #define SD_BWDW(PHv, T, TCHv)                                                                    \
   do {                                                                                           \
-    auto k = roi_align_bwd_packed4<PHv, PHv, T, TCHv>;                                           \
+    auto k = a.ws_taps ? roi_align_bwd_packed4<PHv, PHv, T, TCHv, true>                          \
+                       : roi_align_bwd_packed4<PHv, PHv, T, TCHv, false>;                        \
     if (lds_max > 64 * 1024)                                                                     \
       SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)lds_max));                                           \
@@ -2044,7 +2166,7 @@ extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const
 extern "C" size_t sd_fpn_roi_align_bwd_workspace_bytes(const int* Hs_host, const int* Ws_host, int nlvl,
                                                        int B, int R) {
   if (!Hs_host || !Ws_host || nlvl <= 0 || B <= 0 || R <= 0) return 0;
-  const long budget = 36 * 1024;  // the smallest band the launcher uses gives the most units
+  const long budget = 27 * 1024;  // the smallest band the launcher uses gives the most units
   long units = 0;
   for (int l = 0; l < nlvl; ++l) {
     const long plane_bytes = (long)Hs_host[l] * Ws_host[l] * 4;
@@ -2052,7 +2174,8 @@ extern "C" size_t sd_fpn_roi_align_bwd_workspace_bytes(const int* Hs_host, const
     if (nb < 1) nb = 1;
     units += (long)B * (nb + 1);
   }
-  return (size_t)units * (R + 2) * sizeof(int);
+  // lists + the tap tables of the larger pooled size (14x14: 2 * 3 * 28 words per RoI)
+  return ((((size_t)units * (R + 2) * sizeof(int)) + 15) & ~(size_t)15) + (size_t)units * R * 168 * sizeof(float) + 16;
 }
 
 extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois,

@@ -499,10 +499,12 @@ def test_packed_backward_is_bit_reproducible_and_within_1e4_at_full_size(ops, or
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pooled,num", [((7, 7), 512), ((14, 14), 128)])
-def test_packed_backward_list_prepass_equals_per_workgroup_lists(ops, pooled, num):
-    """The per-band RoI lists from the workspace pre-pass (one small kernel) and the lists every
-    channel's workgroup builds for itself (knob roi_align_bwd_lists = 0, also the path without a
-    workspace) give the same gradients bit for bit at the baseline size."""
+def test_packed_backward_workspace_modes(ops, pooled, num):
+    """The packed backward with the workspace pre-pass (1: per-band RoI lists + tap tables, 27 KB
+    bands; 2: lists only, 36 KB bands) and without (0: every workgroup builds its list).  Lists
+    only == none bit for bit (same bands, same arithmetic); the tap-table mode cuts the planes into
+    different bands, hence other fixed-point scales: each is within ~3e-5 of the exact sum (the
+    oracle comparisons elsewhere), so the two agree within 1e-4; and each mode is bit-reproducible."""
     import torch
     from simpledet_amd._lib import lib
     feats = [_t(f) for f in synth.feature_maps(8, batch=2, channels=64)]
@@ -510,14 +512,20 @@ def test_packed_backward_list_prepass_equals_per_workgroup_lists(ops, pooled, nu
     out, am = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, pooled)
     dy = torch.randn_like(out)
     shapes = [f.shape for f in feats]
-    g1 = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
-    lib().set_tuning("roi_align_bwd_lists", 0)
-    try:
-        g0 = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
-    finally:
-        lib().set_tuning("roi_align_bwd_lists", 1)
-    for a, b in zip(g1, g0):
+    res = {}
+    for mode in (1, 2, 0):
+        lib().set_tuning("roi_align_bwd_lists", mode)
+        try:
+            res[mode] = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
+            again = ops.fpn_roi_align_backward_packed(dy, rois, am, shapes, STRIDES)
+        finally:
+            lib().set_tuning("roi_align_bwd_lists", 1)
+        for a, b in zip(res[mode], again):
+            assert torch.equal(a, b), "mode %d is not bit-reproducible" % mode
+    for a, b in zip(res[2], res[0]):
         assert torch.equal(a, b)
+    for a, b in zip(res[1], res[0]):
+        assert float((a - b).abs().max()) <= 1e-4
 
 
 @pytest.mark.gpu
