@@ -273,10 +273,14 @@ def main():
             # (the per-level kernels of the --extra leg run a handful of times)
             for pat in ("roi_align_fwd", "roi_align_bwd"):
                 cand = [(d.get("n_dispatch", 0), d) for name, d in ks.items()
-                        if pat in name and "fetch_bytes_x2_gfx950" in d]
+                        if pat in name and "bwd_lists" not in name and "fetch_bytes_x2_gfx950" in d]
                 if cand:
                     d = max(cand, key=lambda t: t[0])[1]
                     tot = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
+                    if pat == "roi_align_bwd":  # + the list / tap-table pre-pass of the same step
+                        tot += sum(x["fetch_bytes_x2_gfx950"] + x.get("write_bytes", 0.0)
+                                   for name, x in ks.items()
+                                   if "bwd_lists" in name and "fetch_bytes_x2_gfx950" in x)
                     if pat == "roi_align_fwd":
                         traffic = tot
                     else:
