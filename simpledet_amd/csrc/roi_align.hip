@@ -203,6 +203,7 @@ struct FwdSmem {
     int binflag[PP];         // 1: the bin pools something (reference !is_empty)
     int lvl;                 // assigned level, -1 none, -2 RoI index past the end
     int n;                   // RoI index (through the locality order when one is given)
+    int qr, qc;              // quadrant of the RoI this entry stands for (0, 0 unless POOL > PH)
     int fb_row, fb_col;      // a sample loop ran 3 times -> exact per-element fallback
     int any_valid;
     float box[4];
@@ -312,12 +313,19 @@ __global__ __launch_bounds__(64) void roi_coords_kernel(const float* rois, int n
   }
 }
 
-template <int PH, int PW, int NROI, bool PK, bool LEAN>
+// POOL: the op's pooled size when it is a multiple of the PH x PW tile the kernel works on: a
+// 14x14 RoI is handled as four 7x7 quadrants ("virtual RoIs" with bin rows / columns 7q .. 7q+6 of
+// the 14-bin axes), each with the 7x7 kernel's tile, registers and occupancy; only the axis tables,
+// the coordinate-table indices and the output indices know about the quadrant.
+template <int PH, int PW, int NROI, bool PK, bool LEAN, int POOL = PH>
 __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
+  static_assert(PH == PW && POOL % PH == 0, "square tiles, whole quadrants");
+  constexpr int NQA = POOL / PH, NQ = NQA * NQA;     // quadrants per axis / per RoI
+  constexpr int PPG = POOL * POOL;                    // outputs per (RoI, channel)
+  constexpr int PPSG = amax_stride(PPG);
   constexpr int D = 1;  // channels in flight per wave (deeper batches measured slower)
   using S = FwdSmem<PH, PW, NROI>;
   constexpr int NR = S::NR, NC = S::NC, PP = PH * PW, PPP = S::PPP, CH = S::CH, NWAVE = S::NWAVE;
-  constexpr int PPS = amax_stride(PP);  // bytes per (RoI, channel) row of the packed arg-max
   constexpr int THREADS = NWAVE * kWave;
   static_assert(2 * NROI <= NWAVE, "one wave pair per RoI for the axis tables");
   constexpr int NPAIR = NC / 2;                 // (left,right) column pairs per tile row
@@ -340,7 +348,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
   // its own channel slice.
   const int nslice = a.nslice;
   const int grp = blockIdx.x / nslice, slice = blockIdx.x % nslice;
-  const int nroi_total = a.B * a.R;
+  const int nroi_total = a.B * a.R * NQ;  // (virtual RoIs)
   const int nch = a.C / nslice;  // channels of this workgroup
   const int cbeg = slice * nch;
 
@@ -349,8 +357,9 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
     const int i = wave >> 1, slot = grp * NROI + i;
     typename S::Roi& t = s.roi[i];
     int lvl = -2, cnt = 0, n = 0;
+    const int quad = slot % NQ, qr = quad / NQA, qc = quad % NQA;
     if (slot < nroi_total) {
-      n = a.order ? a.order[slot] : slot;
+      n = a.order ? a.order[slot / NQ] : slot / NQ;
       const float* r = a.rois + (long)n * 4;
       const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
       lvl = 0;
@@ -359,11 +368,11 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
         const int H = a.L.H[lvl], W = a.L.W[lvl];
         const float scale = a.L.scale[lvl];
         if ((wave & 1) == 0 && lane < PH) {
-          cnt = axis_samples(lane, PH, y1, y2, scale, H, W, &t.hval[2 * lane], &t.alpha[2 * lane],
+          cnt = axis_samples(qr * PH + lane, POOL, y1, y2, scale, H, W, &t.hval[2 * lane], &t.alpha[2 * lane],
                              &t.rowoff[4 * lane]);
           t.hcnt[lane] = cnt;
         } else if ((wave & 1) == 1 && lane < PW) {
-          cnt = axis_samples(lane, PW, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
+          cnt = axis_samples(qc * PW + lane, POOL, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
                              &t.coloff[4 * lane]);
           t.wcnt[lane] = cnt;
         }
@@ -376,7 +385,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
     const int fb = __any(cnt >= 3);
     if (lane == 0) {
       if (wave & 1) t.fb_col = fb;
-      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; t.n = n; }
+      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; t.n = n; t.qr = qr; t.qc = qc; }
     }
   }
   __syncthreads();
@@ -407,15 +416,17 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
       const typename S::Roi& t = s.roi[i];
       if (t.lvl < 0) continue;
       const bool row = j < 3 * PH;
-      const int jj = row ? j : j - 3 * PH, p = jj / 3, k = jj % 3;
+      const int jj = row ? j : j - 3 * PH, k = jj % 3;
+      const int p = jj / 3 + (row ? t.qr * PH : t.qc * PW);  // bin row / column of the whole RoI
       // recomputed, not taken from hval / wval: those hold only the samples the loop reached, and
       // the table is written in full so that its content does not depend on LDS leftovers
       const int lv = t.lvl;
-      const float v = row ? sample_coord(p, PH, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
-                          : sample_coord(p, PW, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
-      float* base = a.coords + (long)t.n * kCoordWords * (PH + PW);
-      base[j] = v;
-      store_tap(base + 3 * (PH + PW) + 2 * j, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
+      const float v = row ? sample_coord(p, POOL, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
+                          : sample_coord(p, POOL, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
+      float* base = a.coords + (long)t.n * kCoordWords * (POOL + POOL);
+      const int jg = (row ? 0 : 3 * POOL) + p * 3 + k;  // (quadrants sharing a row / column write the same values)
+      base[jg] = v;
+      store_tap(base + 3 * (POOL + POOL) + 2 * jg, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
     }
   }
 
@@ -447,16 +458,19 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
     const int n = t.n;
     const int lvl = t.lvl;
     if (lvl == -2) break;
-    const long obase = ((long)n * a.C + cbeg) * PP;
-    const long abase = ((long)n * a.C + cbeg) * PPS;
+    const long obase = ((long)n * a.C + cbeg) * PPG;
+    const long abase = ((long)n * a.C + cbeg) * PPSG;
+    // output index of bin (p, q) of this quadrant inside the RoI's POOL x POOL block
+    auto gidx = [&](int bin) { return (t.qr * PH + bin / PW) * POOL + t.qc * PW + bin % PW; };
     if (lvl < 0) {  // every per-level op sees a zero box
       for (int e = tid; e < nch * PP; e += THREADS) {
-        a.out[obase + e] = 0.f;
+        const int c = e / PP, g = gidx(e % PP);
+        a.out[obase + (long)c * PPG + g] = 0.f;
         if (PK) {
-          a.amax8[abase + (e / PP) * PPS + e % PP] = 255;
+          a.amax8[abase + (long)c * PPSG + g] = 255;
         } else {
-          a.ax[obase + e] = -1.f;
-          a.ay[obase + e] = -1.f;
+          a.ax[obase + (long)c * PPG + g] = -1.f;
+          a.ay[obase + (long)c * PPG + g] = -1.f;
         }
       }
     } else if (t.fb_row || t.fb_col) {
@@ -465,16 +479,16 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
       const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
       const float scale = a.L.scale[lvl];
       for (int e = tid; e < nch * PP; e += THREADS) {
-        const int c = e / PP, bin = e % PP;
+        const int c = e / PP, bin = e % PP, g = gidx(bin);
         FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, t.box[0], t.box[1], t.box[2],
-                                      t.box[3], scale, bin / PW, bin % PW, PH, PW);
+                                      t.box[3], scale, t.qr * PH + bin / PW, t.qc * PW + bin % PW, POOL, POOL);
         if (a.L.nlvl > 1) o.val = o.val + 0.0f;
-        a.out[obase + e] = o.val;
+        a.out[obase + (long)c * PPG + g] = o.val;
         if (PK) {
-          a.amax8[abase + c * PPS + bin] = (unsigned char)o.code;
+          a.amax8[abase + (long)c * PPSG + g] = (unsigned char)o.code;
         } else {
-          a.ax[obase + e] = o.ax;
-          a.ay[obase + e] = o.ay;
+          a.ax[obase + (long)c * PPG + g] = o.ax;
+          a.ay[obase + (long)c * PPG + g] = o.ay;
         }
       }
     }
@@ -489,8 +503,11 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
     const int lvl = __builtin_amdgcn_readfirstlane(t.lvl);
     if (lvl == -2) break;
     if (lvl < 0 || __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col)) continue;
-    const long obase = ((long)n * a.C + cbeg) * PP;
-    const long abase = ((long)n * a.C + cbeg) * PPS;
+    const long obase = ((long)n * a.C + cbeg) * PPG;
+    const long abase = ((long)n * a.C + cbeg) * PPSG;
+    const int qr = __builtin_amdgcn_readfirstlane(t.qr), qc = __builtin_amdgcn_readfirstlane(t.qc);
+    // output index of bin (p, q) of this quadrant inside the RoI's POOL x POOL block
+    auto gidx = [&](int bin) { return POOL == PH ? bin : (qr * PH + bin / PW) * POOL + qc * PW + bin % PW; };
     const int W = a.L.W[lvl];
     const long plane = (long)a.L.H[lvl] * W;
     const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
@@ -498,17 +515,18 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
 
     if (!__builtin_amdgcn_readfirstlane(t.any_valid)) {  // nothing to pool anywhere in the RoI
       for (int c = wave; c < nch; c += NWAVE) {
-        const long ob = obase + (long)c * PP;
+        const long ob = obase + (long)c * PPG;
 #pragma unroll
         for (int b = 0; b < NI; ++b) {
           const int bin = lane + b * kWave;
           if (bin < PP) {
-            a.out[ob + bin] = 0.f;
+            const int g = gidx(bin);
+            a.out[ob + g] = 0.f;
             if (PK) {
-              a.amax8[abase + (long)c * PPS + bin] = 255;
+              a.amax8[abase + (long)c * PPSG + g] = 255;
             } else {
-              a.ax[ob + bin] = -1.f;
-              a.ay[ob + bin] = -1.f;
+              a.ax[ob + g] = -1.f;
+              a.ay[ob + g] = -1.f;
             }
           }
         }
@@ -594,10 +612,15 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
     // that the (rare) coincident-column patch costs nothing on the common path.
     auto channel_loop = [&](auto dup_tag) {
       const char* pl = reinterpret_cast<const char*>(base + (long)wave * plane);
-      float* po = a.out + obase + (long)wave * PP;
-      float* px = PK ? nullptr : a.ax + obase + (long)wave * PP;
-      float* py = PK ? nullptr : a.ay + obase + (long)wave * PP;
-      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPS : nullptr;
+      float* po = a.out + obase + (long)wave * PPG;
+      float* px = PK ? nullptr : a.ax + obase + (long)wave * PPG;
+      float* py = PK ? nullptr : a.ay + obase + (long)wave * PPG;
+      unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPSG : nullptr;
+      int gi[POOL == PH ? 1 : NI];  // quadrants: output index of this lane's bins
+      if (POOL != PH) {
+#pragma unroll
+        for (int b = 0; b < NI; ++b) gi[b] = gidx(lane + b * kWave < PP ? lane + b * kWave : 0);
+      }
       for (int c0 = wave; c0 < nch; c0 += D * NWAVE) {
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -636,12 +659,13 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
                   }
                 }
                 if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-                po[bin + d * NWAVE * PP] = maxval;
+                const int g = POOL == PH ? bin : gi[POOL == PH ? 0 : b];
+                po[g + d * NWAVE * PPG] = maxval;
                 if (PK) {
-                  if (!(SD_ABLATE(a, 4))) pk[bin + d * NWAVE * PPS] = (unsigned char)(bk < 0 ? 255 : bk);
+                  if (!(SD_ABLATE(a, 4))) pk[g + d * NWAVE * PPSG] = (unsigned char)(bk < 0 ? 255 : bk);
                 } else {
-                  px[bin + d * NWAVE * PP] = bx;
-                  py[bin + d * NWAVE * PP] = by;
+                  px[g + d * NWAVE * PPG] = bx;
+                  py[g + d * NWAVE * PPG] = by;
                 }
               }
             }
@@ -649,12 +673,12 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a) {
           }
         }
         pl += D * pstep;
-        po += D * NWAVE * PP;
+        po += D * NWAVE * PPG;
         if (PK) {
-          pk += D * NWAVE * PPS;
+          pk += D * NWAVE * PPSG;
         } else {
-          px += D * NWAVE * PP;
-          py += D * NWAVE * PP;
+          px += D * NWAVE * PPG;
+          py += D * NWAVE * PPG;
         }
       }
     };
@@ -683,6 +707,21 @@ template <int NROI, bool PK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_tiled_lean(
     FwdArgs a) {
   fwd_tiled_body<7, 7, NROI, PK, true>(a);
+}
+
+// 14x14 pooling (mask head) as four 7x7 quadrants per RoI on the same 64-VGPR / 34 KB build
+// (the 14x14 tile kernel needs 169 VGPRs and 114 KB of LDS: one workgroup per CU).
+template <int NROI, bool PK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_quad14(
+    FwdArgs a) {
+  fwd_tiled_body<7, 7, NROI, PK, true, 14>(a);
+}
+
+// ... and with the float arg-max planes (the drop-in ROIAlign_v2 outputs): the 7x7 build at three
+// workgroups per CU (it needs more registers than 64)
+template <int NROI>
+__global__ __launch_bounds__(512) void roi_align_fwd_quad14_float(FwdArgs a) {
+  fwd_tiled_body<7, 7, NROI, false, false, 14>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1941,6 +1980,12 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   } while (0)
     if (rpw >= 4) SD_FWD77(4); else if (rpw >= 2) SD_FWD77(2); else SD_FWD77(1);
 #undef SD_FWD77
+  } else if (variant == 1 && a.amax8 && wide && a.PH == 14 && a.PW == 14 && !a.order) {
+    hipLaunchKernelGGL((roi_align_fwd_quad14<2, true>), dim3(cdiv(nroi * 4, 2) * a.nslice), dim3(512), padlds,
+                       st, a);
+  } else if (variant == 1 && !a.amax8 && wide && a.PH == 14 && a.PW == 14 && !a.order && rpw >= 4) {
+    hipLaunchKernelGGL((roi_align_fwd_quad14_float<4>), dim3(cdiv(nroi * 4, 4) * a.nslice), dim3(512), padlds,
+                       st, a);
   } else if (variant >= 1 && wide && a.PH == 14 && a.PW == 14) {
     if (a.amax8)
       hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1, true>), dim3(nroi * a.nslice), dim3(512), 0,
