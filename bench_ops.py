@@ -183,6 +183,23 @@ def run(seed=0, cpu=True, only=None):
                                   "config": "P2-P5 256ch 800x1333, N=2, 128 RoIs/img, 14x14, packed arg-max"}
         del feats, o14, am14, dy14, grads
 
+    # ---- single-level ROIAlign_v2, the C4 family (config/faster_r50v1c4_c5_512roi_1x.py:90-94):
+    # data (2,1024,50,84), stride 16, 512 RoIs / image, 7x7, the reference's three fp32 outputs ----
+    if want("roi_align_c4"):
+        data = torch.randn((2, 1024, 50, 84), device="cuda")
+        rc4 = T(synth.random_rois(seed, 2, 512))
+        o, mx, my = ops.roi_align_v2_forward(data, rc4, (7, 7), 1 / 16.0)
+        dyc = torch.randn_like(o)
+        dxc = torch.empty_like(data)
+        ms_f = _time_gpu(lambda: ops.roi_align_v2_forward(data, rc4, (7, 7), 1 / 16.0))
+        ms_b = _time_gpu(lambda: ops.roi_align_v2_backward(dyc, rc4, mx, my, data.shape, 1 / 16.0, d_data=dxc))
+        alg = 4 * data.numel() + 16 * rc4.shape[0] * rc4.shape[1] + 3 * 4 * o.numel()
+        res["roi_align_c4"] = {"fwd_ms": ms_f, "bwd_ms": ms_b, "algorithmic_bytes": alg,
+                               "fwd_frac": alg / ms_f / 1e6 / PEAK_HBM_GBS,
+                               "bwd_frac": alg / ms_b / 1e6 / PEAK_HBM_GBS,
+                               "config": "C4 (2,1024,50,84) stride 16, 512 RoIs/img, 7x7, float arg-max planes"}
+        del data, o, mx, my, dyc, dxc
+
     # ---- ROIPooling_v1: C4 map (2,1024,50,84), 1024 rois, 7x7 ----
     if want("roi_pool_v1"):
         rs = np.random.RandomState(seed)
