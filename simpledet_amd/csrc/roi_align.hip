@@ -1339,11 +1339,14 @@ __global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
   }
 }
 
-template <int PH, int PW, int THREADS, int TCH, bool TAPS>
+template <int PH, int PW, int THREADS, int TCH, int MODE>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: four 512-thread workgroups per CU
 void roi_align_bwd_packed4(BwdFusedArgs a) {
-  // TAPS: the workspace pre-pass has left band-relative tap entries (8 bytes per sample coordinate)
-  // for the listed RoIs; otherwise the table holds the forward's coordinates (4 bytes each)
+  // MODE 0: one-byte arg-max codes + the forward's coordinate table (4 bytes per sample coordinate);
+  // MODE 1 (TAPS): the workspace pre-pass has left band-relative tap entries (8 bytes each) for the
+  // listed RoIs; MODE 2 (FLT): the reference's float arg-max planes (the drop-in ROIAlign_v2 op and
+  // the three-output fused op): an item carries its four (x, y) coordinates, no table
+  constexpr bool TAPS = MODE == 1, FLT = MODE == 2;
   constexpr int PP = PH * PW, PPS = amax_stride(PP), GP = (PP + 3) / 4, NE = 3 * (PH + PW);
   constexpr int TS = TAPS ? 2 * NE : NE;
   constexpr int CW = kCoordWords * (PH + PW);  // words per RoI in the forward's table
@@ -1375,7 +1378,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   const int plane_pad = (band_elems + 3) & ~3;
   float* plane = smem;
   float* tab = smem + plane_pad;                      // [TCH][TS] sample coordinates
-  int* list = reinterpret_cast<int*>(tab + TCH * TS);  // RoIs of this image on this band
+  int* list = reinterpret_cast<int*>(tab + (FLT ? 0 : TCH * TS));  // RoIs of this image on this band
   int* nlist = list + a.R;  // [0] count [1] bound [2] max|dY| bits, first chunk [3] non-finite [4] max|dY| bits, all
   int* plane_i = reinterpret_cast<int*>(smem);
 
@@ -1416,7 +1419,9 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   // wave-uniform bases + 32-bit lane offsets (the launcher checks R*C*PP < 2^31)
   const int roi_stride = a.C * PP;
   const float* dyb = a.dy + (long)img * a.R * roi_stride + (long)c * PP;
-  const unsigned char* amb = a.amax8 + ((long)img * a.R * a.C + c) * PPS;
+  const float* axb = FLT ? a.ax + (long)img * a.R * roi_stride + (long)c * PP : nullptr;
+  const float* ayb = FLT ? a.ay + (long)img * a.R * roi_stride + (long)c * PP : nullptr;
+  const unsigned char* amb = FLT ? nullptr : a.amax8 + ((long)img * a.R * a.C + c) * PPS;
   const int am_stride = a.C * PPS;
   const float* cob = a.coords + (long)img * a.R * CW;
 
@@ -1424,7 +1429,8 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   float fx_scale = 1.f, fx_inv = 1.f;
   struct Item {
     float4 g;       // gradients of bins b0 .. b0+3
-    unsigned code;  // their four arg-max codes, one per byte (255: nothing pooled)
+    float4 x, y;    // FLT: their arg-max coordinates (-1: nothing pooled)
+    unsigned code;  // their four arg-max codes, one per byte (255: nothing pooled); FLT: 0 = item present
     int j, b0;      // RoI slot (in the list / in the streamed chunk), first bin
   };
   auto load_item = [&](int t, int cb, int nli, Item& it) {
@@ -1432,23 +1438,37 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
     it.j = 0;
     it.b0 = 0;
     it.g = make_float4(0.f, 0.f, 0.f, 0.f);
+    it.x = it.y = make_float4(-1.f, -1.f, -1.f, -1.f);
     if (t < nli) {
       const int j = t / GP, g = t - j * GP;
       const int r = list[cb + j];
       it.j = j;
       it.b0 = 4 * g;
-      unsigned code = *reinterpret_cast<const unsigned*>(amb + r * am_stride + 4 * g);
+      unsigned code = FLT ? 0u : *reinterpret_cast<const unsigned*>(amb + r * am_stride + 4 * g);
+      // bins PP-4 .. PP-1 are fetched by the last lane of a RoI, only the last PP % 4 belong to it
+      constexpr int KEEP = TAIL ? PP % 4 : 1;
+      auto tail4 = [](const F4u& v, float fill) {
+        const float gg[4] = {v.x, v.y, v.z, v.w};
+        return make_float4(gg[4 - KEEP], KEEP > 1 ? gg[KEEP > 1 ? 5 - KEEP : 0] : fill,
+                           KEEP > 2 ? gg[KEEP > 2 ? 6 - KEEP : 0] : fill, fill);
+      };
       if (TAIL && g == GP - 1) {
-        // bins PP-4 .. PP-1 are fetched, only the last PP % 4 of them belong to this lane
-        constexpr int KEEP = TAIL ? PP % 4 : 1;
-        const F4u v = *reinterpret_cast<const F4u*>(dyb + r * roi_stride + (PP - 4));
-        float gg[4] = {v.x, v.y, v.z, v.w};
-        it.g = make_float4(gg[4 - KEEP], KEEP > 1 ? gg[KEEP > 1 ? 5 - KEEP : 0] : 0.f,
-                           KEEP > 2 ? gg[KEEP > 2 ? 6 - KEEP : 0] : 0.f, 0.f);
-        code |= 0xffffffffu << (8 * KEEP);  // the padding bytes of the row are not codes
+        const int o = r * roi_stride + (PP - 4);
+        it.g = tail4(*reinterpret_cast<const F4u*>(dyb + o), 0.f);
+        if (FLT) {
+          it.x = tail4(*reinterpret_cast<const F4u*>(axb + o), -1.f);
+          it.y = tail4(*reinterpret_cast<const F4u*>(ayb + o), -1.f);
+        }
+        code |= FLT ? 0u : 0xffffffffu << (8 * KEEP);  // the padding bytes of the row are not codes
       } else {
-        const F4u v = *reinterpret_cast<const F4u*>(dyb + r * roi_stride + 4 * g);
+        const int o = r * roi_stride + 4 * g;
+        const F4u v = *reinterpret_cast<const F4u*>(dyb + o);
         it.g = make_float4(v.x, v.y, v.z, v.w);
+        if (FLT) {
+          const F4u vx = *reinterpret_cast<const F4u*>(axb + o), vy = *reinterpret_cast<const F4u*>(ayb + o);
+          it.x = make_float4(vx.x, vx.y, vx.z, vx.w);
+          it.y = make_float4(vy.x, vy.y, vy.z, vy.w);
+        }
       }
       it.code = code;
     }
@@ -1457,15 +1477,23 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
     if (it.code == 0xffffffffu || (SD_ABLATE(a, 1))) return;  // (profiling build, 1: no scatter)
     const float* tj = tab + slot * TS;
     const float gg[4] = {it.g.x, it.g.y, it.g.z, it.g.w};
+    const float xx[4] = {it.x.x, it.x.y, it.x.z, it.x.w}, yy[4] = {it.y.x, it.y.y, it.y.z, it.y.w};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int code = (it.code >> (8 * s)) & 0xff;
-      if (code == 255) continue;
-      const int bin = it.b0 + s;
-      const int p = bin / PW, q = bin - p * PW;
-      const int k = (code * 11) >> 5, l = code - 3 * k;  // code = 3k + l, k,l in 0..2
-      const float a_y = tj[p * 3 + k];
-      const float a_x = tj[3 * PH + q * 3 + l];
+      float a_x, a_y;
+      if (FLT) {
+        a_x = xx[s];
+        a_y = yy[s];
+        if (a_x == -1.f || a_y == -1.f) continue;  // roi_align_v2.cu:53: nothing was pooled
+      } else {
+        const int code = (it.code >> (8 * s)) & 0xff;
+        if (code == 255) continue;
+        const int bin = it.b0 + s;
+        const int p = bin / PW, q = bin - p * PW;
+        const int k = (code * 11) >> 5, l = code - 3 * k;  // code = 3k + l, k,l in 0..2
+        a_y = tj[p * 3 + k];
+        a_x = tj[3 * PH + q * 3 + l];
+      }
       const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
       const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
       const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
@@ -1545,6 +1573,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   };
 
   auto stage_tables = [&](int cb, int ncur) {
+    if (FLT) return;
     if (TAPS) {  // the chunk's entries are contiguous in the workspace (list order)
       const float4* src = reinterpret_cast<const float4*>(
           a.ws_taps + ((long)(a.unit_base[li] + u) * a.R + cb) * TS);
@@ -1670,7 +1699,8 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
                             size_t workspace_bytes = 0) {
   // packed arg-max: the wide-load kernel (roi_align_bwd_packed4); its coordinate tables share the
   // LDS with the band, so the band budget is a little smaller
-  const bool wide = a.amax8 && tuning("roi_align_bwd_packed", 1) == 1;
+  const bool flt = !a.amax8 && a.ax && a.ay;  // float arg-max planes: the same kernel without tables
+  const bool wide = (a.amax8 || flt) && tuning("roi_align_bwd_packed", 1) == 1;
   const int tch = tuning("roi_align_bwd_tch", a.PP == 49 ? 32 : 16);
   const int ne = a.PP == 49 ? 3 * 14 : 3 * 28;  // sample coordinates per RoI
   a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
@@ -1681,7 +1711,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   long units = 0;
   // bands of every level for a band budget and a table entry size (words per sample coordinate)
   auto plan = [&](long budget, int entry_words) -> int {
-    const size_t tab_bytes = wide ? (size_t)tch * ne * entry_words * 4 : 0;
+    const size_t tab_bytes = (wide && !flt) ? (size_t)tch * ne * entry_words * 4 : 0;
     lds_max = 0;
     nl = 0;
     units = 0;
@@ -1712,7 +1742,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   const int lists_mode = tuning("roi_align_bwd_lists", 1);  // 1 lists + taps, 2 lists only, 0 none
   bool use_taps = false, use_lists = false;
   size_t list_bytes = 0;
-  if (wide && workspace && ((uintptr_t)workspace & 15) == 0 && lists_mode == 1) {
+  if (wide && !flt && workspace && ((uintptr_t)workspace & 15) == 0 && lists_mode == 1) {
     if (int e = plan((long)tuning("roi_align_bwd_lds_kb", 27) * 1024, 2)) return e;
     list_bytes = (((size_t)units * (a.R + 2) * sizeof(int)) + 15) & ~(size_t)15;
     use_taps = workspace_bytes >= list_bytes + (size_t)units * a.R * 2 * ne * sizeof(float);
@@ -1772,8 +1802,9 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   if (wide) {
 #define SD_BWDW(PHv, T, TCHv)                                                                    \
   do {                                                                                           \
-    auto k = a.ws_taps ? roi_align_bwd_packed4<PHv, PHv, T, TCHv, true>                          \
-                       : roi_align_bwd_packed4<PHv, PHv, T, TCHv, false>;                        \
+    auto k = flt ? roi_align_bwd_packed4<PHv, PHv, T, TCHv, 2>                                   \
+                 : a.ws_taps ? roi_align_bwd_packed4<PHv, PHv, T, TCHv, 1>                       \
+                             : roi_align_bwd_packed4<PHv, PHv, T, TCHv, 0>;                      \
     if (lds_max > 64 * 1024)                                                                     \
       SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)lds_max));                                           \
