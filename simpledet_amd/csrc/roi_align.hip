@@ -1618,8 +1618,9 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
     fx_inv = ldexpf(1.f, -S);
   };
   Item cur;
-  load_item(tid, 0, iminr(TCH, nl) * GP, cur);
-  stage_tables(0, iminr(TCH, nl));
+  const int tch = FLT ? (nl > 0 ? nl : 1) : TCH;  // no tables to stage: the whole list is one chunk
+  load_item(tid, 0, iminr(tch, nl) * GP, cur);
+  stage_tables(0, iminr(tch, nl));
   float m_all = abs4(cur.g);
   int bad = !(m_all <= FLT_MAX);
   if (use_fx) wave_max_to(m_all, bad, 2);
@@ -1632,8 +1633,8 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   }
   bool synced = false;  // the scatter is already fenced by a barrier
   for (int attempt = 0; attempt < 2; ++attempt) {
-    for (int cb = 0; cb < nl; cb += TCH) {
-      const int ncur = iminr(TCH, nl - cb);
+    for (int cb = 0; cb < nl; cb += tch) {
+      const int ncur = iminr(tch, nl - cb);
       const int nli = ncur * GP;  // lane items of this chunk
       if (cb > 0 || attempt > 0) {
         load_item(tid, cb, nli, cur);
