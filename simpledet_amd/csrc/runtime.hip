@@ -33,10 +33,15 @@ Knob g_knobs[] = {
     {"roi_align_fwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
     {"roi_align_bwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
     {"roi_align_fwd_padlds", 0, false},  // profiling build only: extra dynamic LDS bytes (occupancy sweep)
+    {"roi_align_dbg_lo", 0, false},      // profiling build only: device buffer for per-wave phase clocks
+    {"roi_align_dbg_hi", 0, false},
 #endif
     {"roi_align_fwd_order", 0, false},   // 1: locality order of the RoIs (-25% L2-miss reads, same time; default 0)
     {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)
     {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
+    {"roi_align_fwd_res", 0, false},     // 1 hybrid launch: whole planes resident in LDS for the levels that fit + tiled workgroups for the rest (measured slower: VALU bound on per-workgroup tables), 0 off (default)
+    {"roi_align_fwd_res_levels", 0, false},  // bit mask of the levels allowed to be resident (default all)
+    {"roi_align_fwd_res_g", 0, false},   // most channels per resident workgroup (1, 2, 4 or 8; default 8)
     {"roi_align_bwd", 0, false},         // 0 global atomics, 1 per-level LDS planes, 2 fused (default)
     {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 36
     {"roi_align_bwd_accum", 0, false},   // per-level plane path only: 1 int64 fixed point, 0 float CAS
