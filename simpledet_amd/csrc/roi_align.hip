@@ -928,6 +928,7 @@ __device__ __forceinline__ void fwd_resident_body(const FwdArgs& a, float* smem,
       list[base + pre + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
           (unsigned short)t;
     base += tot;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's global_load_lds pieces have landed
     __syncthreads();
   }
   const int count = base;
@@ -1133,6 +1134,660 @@ __global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 
     fwd_tiled_body<7, 7, 4, PK, true, POOL, kResThreads / kWave, true>(
         a, *reinterpret_cast<HybSmem<POOL>*>(hyb_smem), (int)blockIdx.x - a.nres);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Band-resident forward (round 3, the default).  The dual of the backward: the feature planes are
+// streamed through LDS by dense 16-byte loads (every byte read from HBM once, plus a halo), and
+// the RoI bins read their taps out of LDS -- no per-RoI global gathers at all.
+//   unit        (level, image, row band): the band's rows [r0, r0 + owned) plus kBandHalo rows
+//               below it; a level whose plane fits one buffer is a single band holding G planes
+//   item        (RoI, bin row p) -- assigned to the band that holds the first tap row of the bin
+//               row; a RoI is eligible when every bin row's taps span <= halo + 1 rows (all RoIs
+//               on their FPN level are; the others -- and 3-iteration sample loops, and RoIs of no
+//               level -- go to a few exact per-element workgroups at the end of the launch)
+//   pre-pass    one launch: per unit the item list (RoI | p << 16), per RoI and axis bin a
+//               16-byte entry {neighbour offsets, validity flags, interpolation fractions}
+//   workgroup   (unit, chunk of `steps` fills): 16 waves, one per CU (2 x 66 KB buffers).  Every
+//               wave keeps the addresses / fractions of its passes (9 items x 7 bins = 63 lanes
+//               each) in registers across the whole channel loop, so the per-channel work is
+//               eight ds_read2_b32 + the reference's arithmetic + two stores per pass; the next
+//               channel's band is already on its way into the other buffer (global_load_lds).
+// Same float expressions in the same order as roi_align_fwd_elem: bit-equal results.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBandThreads = 1024, kBandWaves = kBandThreads / kWave;
+constexpr int kBandBufFloats = 16896;   // 66 KB per buffer, two buffers per workgroup
+constexpr int kBandHalo = 8;            // rows below a band that its items may still tap
+constexpr int kBandMaxBands = 16;
+constexpr int kBandNP = 4;              // passes a wave keeps in registers (one round)
+constexpr int kBandMaxVisits = 8;       // virtual units one workgroup works on, at most
+constexpr int kBandMaxUnits = 256;      // (level, image, band) units of one launch
+constexpr int kBandFillCost = 140, kBandPlaneCost = 60, kBandSetupCost = 1500;  // cost model, in item times
+constexpr int kBandSub = 4;             // list segments per unit (pre-pass workgroups per (level, image))
+constexpr int kBandFallbackWGs = 256;  // (a multiple of 8: the XCD phase of the band workgroups)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct BandPlan {
+  int owned[SD_MAX_FPN_LEVELS];      // rows a band owns (H: the whole plane is one band)
+  int rows[SD_MAX_FPN_LEVELS];       // rows a band loads (owned + halo; H for whole planes)
+  int nbands[SD_MAX_FPN_LEVELS];
+  int g[SD_MAX_FPN_LEVELS];          // planes per fill (1 for banded levels)
+  int unit_base[SD_MAX_FPN_LEVELS];  // first unit of the level; unit = base + img * nbands + band
+  int wg_end[SD_MAX_FPN_LEVELS];     // exclusive prefix of workgroups over the launch slots
+  int slot_lvl[SD_MAX_FPN_LEVELS];   // level of launch slot i (longest workgroups first)
+  int nslot;
+  int steps[SD_MAX_FPN_LEVELS];      // fills per workgroup
+  int nwg;                           // band workgroups (after the fallback workgroups)
+  int nunits;
+  int grab;                          // channels a workgroup reserves at a time
+  int pool;
+  uint4* rowent;    // [B*R][pool]  {lo0 | step0 << 20 | empty << 31, lo1 | step1 << 20, a0, a1}
+  uint4* colent;    // [B*R][pool]  {left0 | dup0 << 12 | left1 << 13 | dup1 << 25 | empty << 26, -, b0, b1}
+  float2* rowval;   // [B*R][pool]  sample coordinates (float arg-max outputs only)
+  float2* colval;
+  unsigned* items;  // [B][SD_MAX_FPN_LEVELS][kBandSub][ceil(R / kBandSub) * pool]  RoI | p << 16, by band
+  int2* seg;        // [unit][kBandSub] {first item of the segment, items}
+  unsigned char* fbflag;  // [B*R] 1: handled by the exact per-element workgroups
+  int* chan_ctr;    // [kBandMaxUnits] next channel of every virtual unit (zeroed by the pre-pass)
+};
+
+struct BandArgs {
+  FwdArgs f;
+  BandPlan p;
+};
+
+// ---- pre-pass ----
+// blocks [0, B * nlvl): item lists of (level, image); then entries; then (packed) the coordinate table
+template <int POOL>
+__global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A, int nlist, int nent) {
+  const FwdArgs& a = A.f;
+  const BandPlan& P = A.p;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  constexpr int LPR = POOL <= 8 ? 8 : 16;            // lanes per RoI in the list pass
+  constexpr int RPP = kBandThreads / LPR;             // RoIs per pass
+  if ((int)blockIdx.x < nlist) {
+    // one workgroup per (level, image, quarter of the image's RoIs): every quarter writes its own
+    // segment of every band's list, so no workgroup waits for another and a list is the
+    // concatenation of kBandSub segments
+    __shared__ int hist[kBandMaxBands], cursor[kBandMaxBands];
+    const int sub = blockIdx.x % kBandSub, lvl = (blockIdx.x / kBandSub) % a.L.nlvl;
+    const int img = blockIdx.x / (kBandSub * a.L.nlvl);
+    if (a.L.stride[lvl] < 0) return;
+    int first_valid = 0;
+    while (a.L.stride[first_valid] < 0) ++first_valid;
+    const int H = a.L.H[lvl], W = a.L.W[lvl], nb = P.nbands[lvl], owned = P.owned[lvl];
+    const float scale = a.L.scale[lvl];
+    const int rsub = (a.R + kBandSub - 1) / kBandSub;
+    const int rbeg = sub * rsub, rend = rbeg + rsub < a.R ? rbeg + rsub : a.R;
+    if (tid < kBandMaxBands) hist[tid] = 0;
+    __syncthreads();
+    const int rr = tid / LPR, p = tid % LPR;
+    unsigned* items = P.items + (((long)img * SD_MAX_FPN_LEVELS + lvl) * kBandSub + sub) * rsub * POOL;
+    // band of item (n, p): -1 none (not this level / idle lane), -2 the RoI goes to the exact path
+    auto classify = [&](int n) -> int {
+      int band = -1;
+      bool bad = false, mine = false;
+      int lv = -2;
+      if (n < rend) {
+        const float4 bx = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + n) * 4);
+        lv = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
+        mine = lv == lvl;
+        if (mine && p < POOL) {
+          float val[2], frac[2];
+          int offr[4], offc[4];
+          const int cr = axis_samples(p, POOL, bx.y, bx.w, scale, H, 1, val, frac, offr);
+          const int cc = axis_samples(p, POOL, bx.x, bx.z, scale, W, 1, val, frac, offc);
+          bad = cr >= 3 || cc >= 3;
+          band = 0;
+          if (cr >= 1) {
+            const int first = offr[0], last = cr >= 2 ? offr[3] : offr[1];
+            if (nb > 1 && last - first > kBandHalo) bad = true;
+            band = first / owned;
+          }
+        }
+      }
+      // RoI-wide verdict: any bad bin row / column sends the whole RoI to the exact path
+      const unsigned long long bm = __ballot(bad);
+      const int sh = (lane / LPR) * LPR;
+      const bool roi_bad = ((bm >> sh) & ((1ull << LPR) - 1)) != 0;
+      if (n < rend && p == 0) {  // (rewritten with the same value when classify runs twice)
+        if (mine) P.fbflag[(long)img * a.R + n] = roi_bad ? 1 : 0;
+        else if (lv < 0 && lvl == first_valid) P.fbflag[(long)img * a.R + n] = 1;
+      }
+      return roi_bad ? -2 : band;
+    };
+    constexpr int KP = 4;  // passes whose verdicts stay in registers between the two phases
+    int keep[KP];
+    const int npass = (rend - rbeg + RPP - 1) / RPP;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      keep[k] = -1;
+      if (k < npass) {
+        keep[k] = classify(rbeg + k * RPP + rr);
+        if (keep[k] >= 0) atomicAdd(&hist[keep[k]], 1);
+      }
+    }
+    for (int k = KP; k < npass; ++k) {
+      const int band = classify(rbeg + k * RPP + rr);
+      if (band >= 0) atomicAdd(&hist[band], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int b = 0; b < nb; ++b) {
+        cursor[b] = run;
+        P.seg[(P.unit_base[lvl] + img * nb + b) * kBandSub + sub] = make_int2(run, hist[b]);
+        run += hist[b];
+      }
+    }
+    __syncthreads();
+    // ordered inside a wave (a RoI's bin rows stay adjacent), waves reserve ranges atomically
+    auto emit = [&](int n, int band) {
+      unsigned long long todo = __ballot(band >= 0);
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        const int bb = __builtin_amdgcn_readlane(band, src);
+        const unsigned long long m = __ballot(band == bb);
+        int base = 0;
+        if (lane == src) base = atomicAdd(&cursor[bb], __popcll(m));
+        base = __builtin_amdgcn_readlane(base, src);
+        if (band == bb)
+          items[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
+              (unsigned)n | ((unsigned)p << 16);
+        todo &= ~m;
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      if (k < npass) emit(rbeg + k * RPP + rr, keep[k]);
+    for (int k = KP; k < npass; ++k) {
+      const int n = rbeg + k * RPP + rr;
+      emit(n, classify(n));
+    }
+    return;
+  }
+  if (blockIdx.x == (unsigned)nlist && tid < kBandMaxUnits) P.chan_ctr[tid] = 0;
+  const int eb = (int)blockIdx.x - nlist;
+  const int nroi = a.B * a.R;
+  if (eb < nent) {
+    // ---- entries: one thread per (RoI, axis, bin) ----
+    const long e = (long)eb * kBandThreads + tid;
+    if (e >= (long)nroi * 2 * POOL) return;
+    const int p = (int)(e % POOL), ax = (int)((e / POOL) % 2), n = (int)(e / (2 * POOL));
+    const float4 bx = *reinterpret_cast<const float4*>(a.rois + (long)n * 4);
+    const int lvl = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
+    if (lvl < 0) return;
+    const int H = a.L.H[lvl], W = a.L.W[lvl];
+    float val[2] = {0.f, 0.f}, frac[2] = {0.f, 0.f};
+    int off[4];
+    const int cnt = ax == 0 ? axis_samples(p, POOL, bx.y, bx.w, a.L.scale[lvl], H, W, val, frac, off)
+                            : axis_samples(p, POOL, bx.x, bx.z, a.L.scale[lvl], W, 1, val, frac, off);
+    const float qnan = __int_as_float(0x7fc00000);
+    const bool v0 = cnt >= 1, v1 = cnt >= 2;
+    uint4 en;
+    if (ax == 0) {
+      en.x = (v0 ? (unsigned)off[0] | (off[1] != off[0] ? 1u << 20 : 0u) : 0u) | (cnt < 0 ? 1u << 31 : 0u);
+      en.y = v1 ? (unsigned)off[2] | (off[3] != off[2] ? 1u << 20 : 0u) : 0u;
+    } else {
+      en.x = (v0 ? (unsigned)off[0] | (off[1] == off[0] ? 1u << 12 : 0u) : 0u) |
+             (v1 ? (unsigned)off[2] << 13 | (off[3] == off[2] ? 1u << 25 : 0u) : 0u) | (cnt < 0 ? 1u << 26 : 0u);
+      en.y = 0u;
+    }
+    en.z = __float_as_uint(v0 ? frac[0] : qnan);
+    en.w = __float_as_uint(v1 ? frac[1] : qnan);
+    (ax == 0 ? P.rowent : P.colent)[(long)n * POOL + p] = en;
+    if (P.rowval) (ax == 0 ? P.rowval : P.colval)[(long)n * POOL + p] = make_float2(val[0], val[1]);
+    return;
+  }
+  // ---- packed arg-max: the per-RoI sample-coordinate table (what roi_coords_kernel writes) ----
+  if (a.amax8) {
+    const long e = (long)(eb - nent) * kBandThreads + tid;
+    if (e >= (long)nroi * 6 * POOL) return;
+    const int j = (int)(e % (6 * POOL)), n = (int)(e / (6 * POOL));
+    const float4 bx = *reinterpret_cast<const float4*>(a.rois + (long)n * 4);
+    const int lvl = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
+    if (lvl < 0) return;
+    const bool row = j < 3 * POOL;
+    const int jj = row ? j : j - 3 * POOL;
+    const float v = row ? sample_coord(jj / 3, POOL, bx.y, bx.w, a.L.scale[lvl], a.L.H[lvl], jj % 3)
+                        : sample_coord(jj / 3, POOL, bx.x, bx.z, a.L.scale[lvl], a.L.W[lvl], jj % 3);
+    float* cb = a.coords + (long)n * kCoordWords * (POOL + POOL);
+    cb[j] = v;
+    store_tap(cb + 3 * (POOL + POOL) + 2 * j, v, row ? a.L.H[lvl] : a.L.W[lvl]);
+  }
+}
+
+// dense copy of `len` floats at gsrc into LDS at buf (+ shift floats: the 16-byte misalignment of
+// gsrc), by global_load_lds_dwordx4 (LDS destination = wave-uniform base + lane * 16).  Returns the
+// shift.  The (at most two) partial 16-byte words at the ends are fetched as single floats.
+__device__ __forceinline__ int band_fill(const float* gsrc, int len, float* buf, int wave, int lane) {
+  const int shift = (int)(((uintptr_t)gsrc >> 2) & 3);
+  const float* a0 = gsrc - shift;                        // 16-byte aligned
+  const int n4 = (shift + len + 3) >> 2;                 // 16-byte words that hold the band
+  const int first_full = shift ? 1 : 0;
+  const int last_full = ((shift + len) >> 2);            // exclusive
+  const float4* s4 = reinterpret_cast<const float4*>(a0);
+  float4* d4 = reinterpret_cast<float4*>(buf);
+  for (int w4 = wave * kWave; w4 < last_full; w4 += kBandWaves * kWave) {
+    const int i = w4 + lane;
+    if (i >= first_full && i < last_full) __builtin_amdgcn_global_load_lds(s4 + i, d4 + w4, 16, 0, 0);
+  }
+  if (wave == 0) {
+    if (shift && lane < 4 && lane >= shift && lane < shift + len)
+      __builtin_amdgcn_global_load_lds(a0 + lane, buf, 4, 0, 0);
+    if (last_full < n4 && last_full >= first_full && (last_full > 0 || !shift)) {
+      const int j = last_full * 4 + lane;
+      if (lane < 4 && j < shift + len) __builtin_amdgcn_global_load_lds(a0 + j, buf + last_full * 4, 4, 0, 0);
+    }
+  }
+  return shift;
+}
+
+template <int POOL, bool PK>
+__global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
+  const FwdArgs& a = A.f;
+  const BandPlan& P = A.p;
+  constexpr int QL = POOL, IPP = kWave / QL;             // lanes per item, items per pass
+  // passes per wave and round (the float arg-max form carries four sample coordinates more per pass)
+  constexpr int NP = PK ? kBandNP : kBandNP - 1, CAP = NP * kBandWaves * IPP;
+  constexpr int PPG = POOL * POOL, PPSG = amax_stride(PPG);
+  extern __shared__ __attribute__((aligned(16))) float band_smem[];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+
+  if ((int)blockIdx.x < kBandFallbackWGs) {
+    // ---- exact per-element path for the few RoIs the bands do not take: the first workgroups of
+    // the launch (they run beside the band workgroups), workgroup = (RoI slot, channel slice) ----
+    const int nroi = a.B * a.R;
+    const int nsl = a.nslice, csl = a.C / nsl, slice = (int)blockIdx.x % nsl;
+    if ((int)blockIdx.x / nsl >= kBandFallbackWGs / nsl) return;
+    for (int n = (int)blockIdx.x / nsl; n < nroi; n += kBandFallbackWGs / nsl) {
+      if (!P.fbflag[n]) continue;
+      const float4 bx = *reinterpret_cast<const float4*>(a.rois + (long)n * 4);
+      const int lvl = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
+      for (int e = tid; e < csl * PPG; e += kBandThreads) {
+        const int c = slice * csl + e / PPG, g = e % PPG;
+        FwdOut o{0.f, -1.f, -1.f, 255};
+        if (lvl >= 0) {
+          const int H = a.L.H[lvl], W = a.L.W[lvl];
+          o = roi_align_fwd_elem(a.L.data[lvl] + ((long)(n / a.R) * a.C + c) * H * W, H, W, bx.x, bx.y,
+                                 bx.z, bx.w, a.L.scale[lvl], g / POOL, g % POOL, POOL, POOL);
+        }
+        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
+        a.out[((long)n * a.C + c) * PPG + g] = o.val;
+        if (PK) {
+          a.amax8[((long)n * a.C + c) * PPSG + g] = (unsigned char)o.code;
+        } else {
+          a.ax[((long)n * a.C + c) * PPG + g] = o.ax;
+          a.ay[((long)n * a.C + c) * PPG + g] = o.ay;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- persistent workgroups, one per CU.  Work = (virtual unit, channel): a virtual unit is a
+  // unit's items cut into rounds of CAP (what one workgroup keeps in registers).  A workgroup
+  // starts on the virtual unit its share of the estimated cost falls in, takes the unit's
+  // channels G at a time from a per-unit counter (so the workgroups of a unit finish together
+  // whatever the estimate was worth), and when the unit runs dry moves to the unit with the most
+  // work left ----
+  __shared__ int v_unit[kBandMaxUnits], v_first[kBandMaxUnits], v_items[kBandMaxUnits];
+  __shared__ int v_cost[kBandMaxUnits], v_start[kBandMaxUnits + 1], s_wsum[kBandWaves];
+  __shared__ int s_grab[2], s_pick, s_pickval;
+  const int wg = (int)blockIdx.x - kBandFallbackWGs, nwg = (int)gridDim.x - kBandFallbackWGs;
+  const int rsub = (a.R + kBandSub - 1) / kBandSub;
+  auto level_of = [&](int u) {
+    int l = 0;
+    for (int k = 0; k < a.L.nlvl; ++k)
+      if (a.L.stride[k] >= 0 && u >= P.unit_base[k]) l = k;
+    return l;
+  };
+  // exclusive block scan (16 waves): returns the prefix of v, the total through *tot
+  auto block_scan = [&](int v, int* tot) {
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();  // (s_wsum may still be read from the previous scan)
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    int pre = 0, all = 0;
+    for (int w = 0; w < kBandWaves; ++w) {
+      const int c = s_wsum[w];
+      pre += w < wave ? c : 0;
+      all += c;
+    }
+    *tot = all;
+    return pre + incl - v;
+  };
+  int nvu = 0;
+  {
+    int cnt = 0, rounds = 0, lv = 0;
+    if (tid < P.nunits) {
+      lv = level_of(tid);
+#pragma unroll
+      for (int j = 0; j < kBandSub; ++j) cnt += P.seg[tid * kBandSub + j].y;
+      rounds = (cnt + CAP - 1) / CAP;
+    }
+    const int vb = block_scan(rounds, &nvu);
+    if (nvu > kBandMaxUnits) nvu = kBandMaxUnits;  // (the launcher keeps the rounds of a level small)
+    for (int r = 0; r < rounds && vb + r < kBandMaxUnits; ++r) {
+      const int it = cnt - r * CAP < CAP ? cnt - r * CAP : CAP;
+      v_unit[vb + r] = tid;
+      v_first[vb + r] = r * CAP;
+      v_items[vb + r] = it;
+      // measured (profiles/r03_fwd_cost_model.txt): a fill takes ~ F0 + G * (F1 + k * items) ticks,
+      // linear in the items (the waves of a SIMD share the LDS and VALU rate); per channel, in units of k:
+      v_cost[vb + r] = kBandFillCost / P.g[lv] + kBandPlaneCost + it;
+    }
+    __syncthreads();
+    int tot = 0;
+    const int mine = tid < nvu ? kBandSetupCost + v_cost[tid] * a.C : 0;
+    const int pre = block_scan(mine, &tot);
+    if (tid < nvu) v_start[tid] = pre;
+    if (tid == 0) v_start[nvu] = tot;
+    __syncthreads();
+  }
+  if (nvu == 0) return;
+  int vu = 0;
+  {
+    const long pos = (long)v_start[nvu] * (2 * wg + 1) / (2 * nwg);
+    for (int k = 0; k < nvu; ++k)
+      if (v_start[k] <= pos) vu = k;
+  }
+  float* buf0 = band_smem;
+  float* buf1 = band_smem + kBandBufFloats;
+#ifdef SD_PROFILING
+  const long long t_begin = __builtin_readcyclecounter();
+  long long t_setup = 0, t_wait = 0, t_comp = 0, t_mark = t_begin;
+  int dbg_count = 0, dbg_units = 0, dbg_fills = 0;
+#endif
+  // takes the next (up to) G channels of virtual unit v: first channel, or >= C when it has run dry
+  auto grab = [&](int v, int G) {
+    int k = 0;
+    if (tid == 0) k = atomicAdd(&P.chan_ctr[v], G);
+    return k;  // (valid in thread 0 only)
+  };
+
+  for (int visit = 0; visit < kBandMaxVisits; ++visit) {
+  if (visit) {
+    // the unit ran dry: move to the virtual unit with the most estimated work left (if any)
+    int left = 0;
+    if (tid < nvu) {
+      const int done = P.chan_ctr[tid];
+      // (joining costs a set-up: only worth it for a few fills)
+      left = a.C - done >= 3 * P.g[level_of(v_unit[tid])] ? (a.C - done) * v_cost[tid] : 0;
+    }
+    if (tid == 0) { s_pick = -1; s_pickval = 0; }
+    __syncthreads();
+    if (left > 0) atomicMax(&s_pickval, left);
+    __syncthreads();
+    if (left > 0 && left == s_pickval) s_pick = tid;  // (any of the equals)
+    __syncthreads();
+    vu = s_pick;
+    if (vu < 0) break;
+  }
+  const int unit = v_unit[vu];
+  const int lvl = level_of(unit);
+  const int G = P.g[lvl], nb = P.nbands[lvl];
+  // channels are reserved GR at a time (a run of consecutive channels: the (RoI, channel) rows of the
+  // outputs are 196 bytes, neighbours share cache lines, and a run written by one CU merges in its L2)
+  const int GR = ((P.grab + G - 1) / G) * G;
+  {
+    const int k = grab(vu, GR);
+    if (tid == 0) s_grab[0] = k;
+    __syncthreads();
+  }
+  int kcur = s_grab[0];
+  if (kcur >= a.C) continue;  // (uniform) dry already
+  int ck = kcur + G, cend = kcur + GR < a.C ? kcur + GR : a.C;   // rest of the current reservation
+  int slot = 1;                                                  // where the next reservation is parked
+  const int ul = unit - P.unit_base[lvl];
+  const int img = ul / nb, band = ul % nb;
+  const int H = a.L.H[lvl], W = a.L.W[lvl], HW = H * W;
+  const int r0 = band * P.owned[lvl];
+  const int nrows = H - r0 < P.rows[lvl] ? H - r0 : P.rows[lvl];
+  const int blen = nrows * W;                            // floats of one plane's band
+  const int bstride = (blen + 4 + 3) & ~3;               // LDS floats between the G planes of a fill
+  // the unit's list = kBandSub segments, one per quarter of the image's RoIs
+  const unsigned* items = P.items + ((long)img * SD_MAX_FPN_LEVELS + lvl) * kBandSub * rsub * POOL;
+  int sgs[kBandSub], sgc[kBandSub], count = 0;
+#pragma unroll
+  for (int j = 0; j < kBandSub; ++j) {
+    const int2 sg = P.seg[unit * kBandSub + j];
+    sgs[j] = j * rsub * POOL + sg.x - count;   // items[sgs[j] + t] for list positions t of segment j
+    sgc[j] = count + sg.y;                     // (exclusive end of segment j in list positions)
+    count += sg.y;
+  }
+  const int round0 = v_first[vu], nitems = v_items[vu];
+#ifdef SD_PROFILING
+  dbg_count += nitems;
+  ++dbg_units;
+  dbg_fills = 0;
+  t_mark = __builtin_readcyclecounter();
+  if (a.dbg && lane == 0 && wave == 0 && dbg_units <= 3) {  // per visit: level, fills, items, start tick
+    long long* d = a.dbg + ((long)gridDim.x * kBandWaves + (long)blockIdx.x * 4 + (dbg_units - 1)) * 8;
+    d[0] = lvl; d[2] = nitems; d[3] = t_mark; d[4] = 1;
+  }
+#endif
+  const float* gbase = a.L.data[lvl] + (long)img * a.C * HW + (long)r0 * W;  // channel 0 of the band
+  {
+    // one fill = the band rows of G consecutive planes; plane g lands at g * bstride (+ its shift)
+    auto fill = [&](const float* src, float* dst, int gcount) {
+      int sh0 = 0;
+      for (int g = 0; g < gcount; ++g) {
+        const int sh = band_fill(src + (long)g * HW, blen, dst + g * bstride, wave, lane);
+        if (g == 0) sh0 = sh;
+      }
+      return sh0;
+    };
+    // ---- per-pass state, in registers across the channel loop.  The table loads go out before
+    // the first fill (loads return in order: behind the fill they would wait for all of it), the
+    // arithmetic on them runs while the fill lands ----
+    int A0[NP], A1[NP], A2[NP], A3[NP], A4[NP], A5[NP], A6[NP], A7[NP];
+    float al0[NP], al1[NP], be0[NP], be1[NP], cx0[NP], cx1[NP], cy0[NP], cy1[NP];
+    int ooff[NP];       // element index of the bin in out (first channel of the chunk)
+    unsigned aoff[NP];  // byte index of its arg-max code
+    int flags[NP];      // bit 0 valid lane, 1 dup0, 2 dup1, 3 empty
+    bool anyd[NP];
+    unsigned words[NP];
+    uint4 res[NP], ces[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int it = (wave + kBandWaves * i) * IPP + lane / QL;
+      const bool valid = lane < IPP * QL && it < nitems;
+      words[i] = 0;
+      if (valid) {
+        const int t = round0 + it;
+        int o = sgs[kBandSub - 1];
+#pragma unroll
+        for (int j = kBandSub - 2; j >= 0; --j) o = t < sgc[j] ? sgs[j] : o;
+        words[i] = items[o + t];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int it = (wave + kBandWaves * i) * IPP + lane / QL;
+      const bool valid = lane < IPP * QL && it < nitems;
+      const int n = words[i] & 0xffff, pp = words[i] >> 16, q = lane % QL;
+      res[i] = make_uint4(0, 0, 0x7fc00000u, 0x7fc00000u);
+      ces[i] = res[i];
+      if (valid) {
+        res[i] = P.rowent[((long)img * a.R + n) * POOL + pp];
+        ces[i] = P.colent[((long)img * a.R + n) * POOL + q];
+      }
+    }
+    int shift_next = fill(gbase + (long)kcur * HW, buf0, a.C - kcur < G ? a.C - kcur : G);
+    if (tid == 0) s_grab[1] = grab(vu, GR);  // the reservation after this one (read past the next barrier)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int it = (wave + kBandWaves * i) * IPP + lane / QL;
+      const bool valid = lane < IPP * QL && it < nitems;
+      const unsigned word = words[i];
+      const int n = word & 0xffff, pp = word >> 16, q = lane % QL;
+      const uint4 re = res[i], ce = ces[i];
+      if (!PK) {
+        float2 rv = make_float2(0.f, 0.f), cv = rv;
+        if (valid) {
+          rv = P.rowval[((long)img * a.R + n) * POOL + pp];
+          cv = P.colval[((long)img * a.R + n) * POOL + q];
+        }
+        cy0[i] = rv.x; cy1[i] = rv.y; cx0[i] = cv.x; cx1[i] = cv.y;
+      }
+      const int r0w = r0 * W;
+      int lo0 = (int)(re.x & 0xfffff) - r0w, lo1 = (int)(re.y & 0xfffff) - r0w;
+      lo0 = lo0 < 0 ? 0 : lo0;   // (an absent sample has offset 0: keep its unused address in range)
+      lo1 = lo1 < 0 ? 0 : lo1;
+      const int hi0 = lo0 + ((re.x >> 20) & 1 ? W : 0), hi1 = lo1 + ((re.y >> 20) & 1 ? W : 0);
+      const int left0 = ce.x & 0xfff, left1 = (ce.x >> 13) & 0xfff;
+      A0[i] = (lo0 + left0) * 4; A1[i] = (lo0 + left1) * 4; A2[i] = (hi0 + left0) * 4; A3[i] = (hi0 + left1) * 4;
+      A4[i] = (lo1 + left0) * 4; A5[i] = (lo1 + left1) * 4; A6[i] = (hi1 + left0) * 4; A7[i] = (hi1 + left1) * 4;
+      al0[i] = __uint_as_float(re.z); al1[i] = __uint_as_float(re.w);
+      be0[i] = __uint_as_float(ce.z); be1[i] = __uint_as_float(ce.w);
+      const int d0 = (ce.x >> 12) & 1, d1 = (ce.x >> 25) & 1;
+      const int empty = (int)(re.x >> 31) | (int)((ce.x >> 26) & 1);
+      flags[i] = (valid ? 1 : 0) | d0 << 1 | d1 << 2 | empty << 3;
+      anyd[i] = __ballot(valid && (d0 | d1)) != 0;
+      ooff[i] = (int)((((long)img * a.R + n) * a.C) * PPG + pp * POOL + q);   // (channel 0)
+      aoff[i] = (unsigned)((((long)img * a.R + n) * a.C) * PPSG + pp * POOL + q);
+    }
+
+    for (int s = 0;; ++s) {
+      // this wave's share of fill s has landed (hipcc does not count global_load_lds against the
+      // barrier by itself); after the barrier everyone's has, and everyone is done with the other buffer
+#ifdef SD_PROFILING
+      {
+        const long long now = __builtin_readcyclecounter();
+        if (s == 0) t_setup += now - t_mark; else t_comp += now - t_mark;
+        t_mark = now;
+      }
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#ifdef SD_PROFILING
+      {
+        const long long now = __builtin_readcyclecounter();
+        t_wait += now - t_mark;
+        t_mark = now;
+      }
+#endif
+      const int shift = shift_next;
+      const int gcount = a.C - kcur < G ? a.C - kcur : G;
+      // next fill: the rest of this reservation, else the parked one (and a new one is requested;
+      // the counter's answer stays in a register while the step computes)
+      int knext = a.C, grabbed = 0;
+      bool regrab = false;
+      if (ck < cend) {
+        knext = ck;
+        ck += G;
+      } else {
+        const int b = s_grab[slot];
+        if (b < a.C) {
+          knext = b;
+          ck = b + G;
+          cend = b + GR < a.C ? b + GR : a.C;
+          slot ^= 1;
+          regrab = true;
+        }
+      }
+      if (knext < a.C)
+        shift_next = fill(gbase + (long)knext * HW, (s & 1) ? buf0 : buf1, a.C - knext < G ? a.C - knext : G);
+      if (regrab) grabbed = grab(vu, GR);
+      const char* base = reinterpret_cast<const char*>((s & 1) ? buf1 : buf0);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if ((wave + kBandWaves * i) * IPP >= nitems) break;   // (wave-uniform)
+        const float init = (flags[i] & 8) ? 0.f : -FLT_MAX;
+        // weight products, the reference's expressions (roi_align_v2-inl.h:131-134)
+        // (recomputed per step from opaque copies of the fractions: hoisted out of the channel loop
+        // the 16 products of every pass would occupy 16 * NP registers)
+        float fa0 = al0[i], fa1 = al1[i], fb0 = be0[i], fb1 = be1[i];
+        asm volatile("" : "+v"(fa0), "+v"(fa1), "+v"(fb0), "+v"(fb1));
+        // products paired the way the taps arrive: ds_read2_b32 delivers (left, right) of one row,
+        // so {(1-a)(1-b), (1-a)b} multiplies the low row's pair and {a(1-b), ab} the high row's in
+        // one v_pk_mul_f32 each, no register shuffling
+        const v2f b0 = {1 - fb0, fb0}, b1 = {1 - fb1, fb1};
+        const v2f wl00 = (1 - fa0) * b0, wh00 = fa0 * b0, wl01 = (1 - fa0) * b1, wh01 = fa0 * b1;
+        const v2f wl10 = (1 - fa1) * b0, wh10 = fa1 * b0, wl11 = (1 - fa1) * b1, wh11 = fa1 * b1;
+        int oo = ooff[i] + kcur * PPG;
+        unsigned ao = aoff[i] + (unsigned)(kcur * PPSG);
+        for (int g = 0; g < gcount; ++g) {
+          // plane g of the fill; its 16-byte misalignment follows from plane 0's (HW floats apart)
+          const char* pl = base + ((long)g * bstride + ((shift + g * (HW & 3)) & 3)) * 4;
+          auto rd = [&](int off) {
+            const F2u t = *reinterpret_cast<const F2u*>(pl + off);
+            return v2f{t.x, t.y};
+          };
+          v2f t000 = rd(A0[i]), t001 = rd(A1[i]), t010 = rd(A2[i]), t011 = rd(A3[i]);
+          v2f t100 = rd(A4[i]), t101 = rd(A5[i]), t110 = rd(A6[i]), t111 = rd(A7[i]);
+          if (anyd[i]) {  // coincident (left, right) columns: both taps are the left pixel
+            if (flags[i] & 2) { t000.y = t000.x; t010.y = t010.x; t100.y = t100.x; t110.y = t110.x; }
+            if (flags[i] & 4) { t001.y = t001.x; t011.y = t011.x; t101.y = t101.x; t111.y = t111.x; }
+          }
+          float maxval = init, bx_ = -1.f, by_ = -1.f;
+          int bk = 255;
+          // value = w1*TL + w2*BL + w3*TR + w4*BR, summed left to right (roi_align_v2-inl.h:135-138)
+          auto val4 = [](v2f wl, v2f wh, v2f lo, v2f hi) {
+            const v2f ml = wl * lo, mh = wh * hi;
+            return ((ml.x + mh.x) + ml.y) + mh.y;
+          };
+          float value;
+          value = val4(wl00, wh00, t000, t010);
+          if (value > maxval) { maxval = value; bk = 0; if (!PK) { bx_ = cx0[i]; by_ = cy0[i]; } }
+          value = val4(wl01, wh01, t001, t011);
+          if (value > maxval) { maxval = value; bk = 1; if (!PK) { bx_ = cx1[i]; by_ = cy0[i]; } }
+          value = val4(wl10, wh10, t100, t110);
+          if (value > maxval) { maxval = value; bk = 3; if (!PK) { bx_ = cx0[i]; by_ = cy1[i]; } }
+          value = val4(wl11, wh11, t101, t111);
+          if (value > maxval) { maxval = value; bk = 4; if (!PK) { bx_ = cx1[i]; by_ = cy1[i]; } }
+          if (a.L.nlvl > 1) maxval = maxval + 0.0f;
+          if (flags[i] & 1) {
+            a.out[oo] = maxval;
+            if (PK) {
+              a.amax8[ao] = (unsigned char)bk;
+            } else {
+              a.ax[oo] = bx_;
+              a.ay[oo] = by_;
+            }
+          }
+          oo += PPG;
+          ao += PPSG;
+        }
+      }
+#ifdef SD_PROFILING
+      ++dbg_fills;
+#endif
+      if (tid == 0 && regrab) s_grab[slot] = grabbed;
+      kcur = knext;
+      if (kcur >= a.C) break;  // (uniform) the unit has no fill left for this workgroup
+    }
+#ifdef SD_PROFILING
+    {
+      const long long now = __builtin_readcyclecounter();
+      t_comp += now - t_mark;
+      t_mark = now;
+    }
+#endif
+    __syncthreads();  // the next visit refills buf0 and reuses s_grab
+  }
+#ifdef SD_PROFILING
+  if (a.dbg && lane == 0 && wave == 0 && dbg_units <= 3) {
+    long long* d = a.dbg + ((long)gridDim.x * kBandWaves + (long)blockIdx.x * 4 + (dbg_units - 1)) * 8;
+    d[1] = dbg_fills; d[5] = __builtin_readcyclecounter();
+  }
+#endif
+  }  // visits
+#ifdef SD_PROFILING
+  if (a.dbg && lane == 0) {
+    long long* d = a.dbg + ((long)blockIdx.x * kBandWaves + wave) * 8;
+    d[0] = t_setup; d[1] = t_wait; d[2] = t_comp; d[3] = dbg_count;
+    d[4] = __builtin_readcyclecounter() - t_begin; d[5] = 0; d[6] = dbg_units; d[7] = t_begin;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2410,6 +3065,120 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
   const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
   const int padlds = SD_PROF_TUNING("roi_align_fwd_padlds", 0);  // profiling build: occupancy sweep
+  // ---- band-resident forward (default): pre-pass + one launch; needs the workspace ----
+  if (variant == 1 && wide && !a.order && ((a.PH == 7 && a.PW == 7) || (a.PH == 14 && a.PW == 14)) &&
+      a.R <= 65535 && workspace && tuning("roi_align_fwd_band", 1)) {
+    BandArgs A{};
+    BandPlan& P = A.p;
+    const int POOL = a.PH;
+    bool ok = true;
+    int wg = 0, units = 0;
+    const int want_steps = tuning("roi_align_fwd_steps", 8), gmax = tuning("roi_align_fwd_res_g", 8);
+    int nvalid_lv = 0;
+    for (int l = 0; l < a.L.nlvl; ++l) nvalid_lv += a.L.stride[l] >= 0;
+    for (int l = 0; l < a.L.nlvl; ++l) {
+      if (a.L.stride[l] < 0) continue;
+      const int H = a.L.H[l], W = a.L.W[l];
+      const long HW = (long)H * W;
+      if (W > 4095 || HW >= (1 << 20)) { ok = false; break; }
+      // bands: as few as LDS allows, but enough that a unit's expected items (an even share of the
+      // image's R * POOL bin rows per level) fit one round of the workgroup
+      const int rb = (kBandBufFloats - 8) / W;   // rows one buffer holds
+      if (rb < kBandHalo + 4) { ok = false; break; }
+      int nbn = H <= rb ? 1 : (H + (rb - kBandHalo) - 1) / (rb - kBandHalo);
+      const int cap = kBandNP * kBandWaves * (kWave / POOL);
+      const long est = (long)a.R * POOL / (nvalid_lv > 0 ? nvalid_lv : 1);
+      const int by_items = (int)((est * 5 + 4L * cap - 1) / (4L * cap));   // est / (0.8 cap)
+      if (by_items > nbn && tuning("roi_align_fwd_split", 1)) nbn = by_items;
+      if (nbn > H) nbn = H;
+      if (nbn > kBandMaxBands) { ok = false; break; }
+      int owned = (H + nbn - 1) / nbn;
+      if (nbn > 1)
+        for (int o = owned; o < owned + 4 && o + kBandHalo <= rb; ++o)
+          if (((long)o * W) % 4 == 0) { owned = o; break; }  // 16-byte aligned band starts
+      nbn = (H + owned - 1) / owned;
+      P.nbands[l] = nbn;
+      P.owned[l] = nbn == 1 ? H : owned;
+      P.rows[l] = nbn == 1 ? H : (owned + kBandHalo < H ? owned + kBandHalo : H);
+      const long bstride = (((long)P.rows[l] * W + 4 + 3) & ~3L);
+      int g = 1;
+      for (int c = 2; c <= 8 && c <= gmax; c *= 2)
+        if (a.C % c == 0 && c * bstride <= kBandBufFloats) g = c;
+      if (bstride > kBandBufFloats) { ok = false; break; }
+      P.g[l] = g;
+      const int nfill = a.C / g;
+      int st = 1;  // about want_steps channels per workgroup, whatever G is
+      for (int d = 1; d * g <= want_steps && d <= nfill; ++d)
+        if (nfill % d == 0) st = d;
+      P.steps[l] = st;
+      P.unit_base[l] = units;
+      units += a.B * P.nbands[l];
+      P.slot_lvl[P.nslot++] = l;
+    }
+    // launch order: the longest workgroups first (items per unit ~ 1 / bands, channels = G * steps)
+    for (int i = 0; ok && i < P.nslot; ++i)
+      for (int j = i + 1; j < P.nslot; ++j) {
+        const int li = P.slot_lvl[i], lj = P.slot_lvl[j];
+        const long wi = (long)P.g[li] * P.steps[li] * kBandMaxBands / P.nbands[li];
+        const long wj = (long)P.g[lj] * P.steps[lj] * kBandMaxBands / P.nbands[lj];
+        if (wj > wi) { P.slot_lvl[i] = lj; P.slot_lvl[j] = li; }
+      }
+    for (int i = 0; ok && i < P.nslot; ++i) {
+      const int l = P.slot_lvl[i];
+      wg += a.B * P.nbands[l] * (a.C / (P.g[l] * P.steps[l]));
+      P.wg_end[i] = wg;
+    }
+    // workspace carve-up
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t ent = al16((size_t)nroi * POOL * sizeof(uint4));
+    const size_t valb = a.amax8 ? 0 : al16((size_t)nroi * POOL * sizeof(float2));
+    const size_t itemb = al16((size_t)a.B * SD_MAX_FPN_LEVELS * kBandSub * ((a.R + kBandSub - 1) / kBandSub) *
+                              POOL * sizeof(unsigned));
+    const size_t segb = al16((size_t)units * kBandSub * sizeof(int2));
+    const size_t need = 16 + 2 * ent + 2 * valb + itemb + segb + al16(nroi) + kBandMaxUnits * sizeof(int);
+    P.nunits = units;
+    P.grab = tuning("roi_align_fwd_grab", 4);
+    if (P.grab < 1) P.grab = 1;
+    if (units > kBandMaxUnits) ok = false;
+    wg = tuning("roi_align_fwd_wgs", kNumCU);  // persistent workgroups, one per CU
+    if (wg < 1) wg = 1;
+    if (ok && need <= workspace_bytes) {
+      char* w = reinterpret_cast<char*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+      P.rowent = reinterpret_cast<uint4*>(w); w += ent;
+      P.colent = reinterpret_cast<uint4*>(w); w += ent;
+      if (valb) {
+        P.rowval = reinterpret_cast<float2*>(w); w += valb;
+        P.colval = reinterpret_cast<float2*>(w); w += valb;
+      }
+      P.items = reinterpret_cast<unsigned*>(w); w += itemb;
+      P.seg = reinterpret_cast<int2*>(w); w += segb;
+      P.fbflag = reinterpret_cast<unsigned char*>(w); w += al16(nroi);
+      P.chan_ctr = reinterpret_cast<int*>(w);
+      P.nwg = wg;
+      P.pool = POOL;
+      A.f = a;
+      const int nlist = a.B * a.L.nlvl * kBandSub, nent = cdiv((long)nroi * 2 * POOL, kBandThreads);
+      const int ncoord = a.amax8 ? cdiv((long)nroi * 6 * POOL, kBandThreads) : 0;
+      const int smem = 2 * kBandBufFloats * (int)sizeof(float);
+#define SD_FWD_BAND(POOLV, PK)                                                                    \
+  do {                                                                                            \
+    hipLaunchKernelGGL((roi_fwd_prep_kernel<POOLV>), dim3(nlist + nent + ncoord), dim3(kBandThreads), 0, \
+                       st, A, nlist, nent);                                                       \
+    auto k = roi_align_fwd_band<POOLV, PK>;                                                       \
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                     smem));                                                      \
+    hipLaunchKernelGGL(k, dim3(wg + kBandFallbackWGs), dim3(kBandThreads), smem, st, A);          \
+  } while (0)
+      if (POOL == 7) {
+        if (a.amax8) SD_FWD_BAND(7, true); else SD_FWD_BAND(7, false);
+      } else {
+        if (a.amax8) SD_FWD_BAND(14, true); else SD_FWD_BAND(14, false);
+      }
+#undef SD_FWD_BAND
+      SD_LAUNCH_CHECK();
+      return SD_OK;
+    }
+  }
   // ---- hybrid launch: LDS-resident workgroups for the levels whose planes fit, tiled (gather)
   // workgroups for the rest (knob roi_align_fwd_res = 0: tiled kernels only) ----
   if (variant == 1 && wide && !a.order && ((a.PH == 7 && a.PW == 7) || (a.PH == 14 && a.PW == 14)) &&
@@ -2798,7 +3567,12 @@ extern "C" int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float
 }
 
 extern "C" size_t sd_fpn_roi_align_workspace_bytes(int B, int R) {
-  return (size_t)(B > 0 ? B : 0) * (size_t)(R > 0 ? R : 0) * sizeof(int) + 64;
+  // band-resident forward: two 16-byte entries + two 8-byte coordinate pairs per (RoI, axis bin) of
+  // the larger pooled size (14), the item lists of up to SD_MAX_FPN_LEVELS levels, unit segments
+  // (<= kBandMaxBands bands per level), one flag byte per RoI
+  const size_t b = B > 0 ? B : 0, r = R > 0 ? R : 0, nroi = b * r;
+  return nroi * 14 * (2 * 16 + 2 * 8) + b * SD_MAX_FPN_LEVELS * (r + kBandSub) * 14 * 4 +
+         b * SD_MAX_FPN_LEVELS * kBandMaxBands * kBandSub * 8 + nroi + kBandMaxUnits * 4 + 256;
 }
 
 extern "C" int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois,

@@ -39,6 +39,11 @@ Knob g_knobs[] = {
     {"roi_align_fwd_order", 0, false},   // 1: locality order of the RoIs (-25% L2-miss reads, same time; default 0)
     {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)
     {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
+    {"roi_align_fwd_band", 0, false},    // 1 band-resident forward: planes streamed through LDS, no gathers (default), 0 tiled kernels
+    {"roi_align_fwd_steps", 0, false},   // channels per band workgroup (fills x planes per fill), default 8
+    {"roi_align_fwd_grab", 0, false},    // channels a band workgroup reserves at a time (default 4)
+    {"roi_align_fwd_wgs", 0, false},     // persistent band workgroups (default 256 = one per CU)
+    {"roi_align_fwd_split", 0, false},   // 1 more bands than LDS needs when a unit's expected items exceed a round (default)
     {"roi_align_fwd_res", 0, false},     // 1 hybrid launch: whole planes resident in LDS for the levels that fit + tiled workgroups for the rest (measured slower: VALU bound on per-workgroup tables), 0 off (default)
     {"roi_align_fwd_res_levels", 0, false},  // bit mask of the levels allowed to be resident (default all)
     {"roi_align_fwd_res_g", 0, false},   // most channels per resident workgroup (1, 2, 4 or 8; default 8)
