@@ -44,7 +44,13 @@ extern "C" {
 #define SD_MAX_FPN_LEVELS 8
 
 const char* sd_last_error(void);
-/* ABI version of this header (bumped on any signature change) */
+/* ABI version of this header: bumped on any signature change AND on any change of a buffer layout
+ * or size contract (a caller built against an older header must not pass it buffers of the old
+ * size).  History: 1 round 1; 2 packed arg-max rows padded to whole dwords (7x7: 49 -> 52 bytes)
+ * and 4-byte aligned; 3 sd_fpn_roi_align_workspace_bytes grew (the forward's band lists / tap
+ * entries live in the workspace; with a smaller or NULL workspace the forward still runs, on the
+ * slower tiled kernels).  sd_abi_version() returns the library's value; compare with this macro. */
+#define SD_ABI_VERSION 3
 int sd_abi_version(void);
 /* kernel-variant knobs for A/B measurements (bench.py, tests); every variant computes the same
  * result.  Unknown keys are an error.  Knobs that disable parts of a kernel for profiling exist

@@ -56,6 +56,13 @@ def parse_header(path=HEADER):
     return protos
 
 
+def header_abi_version(path=HEADER):
+    m = re.search(r"^\s*#define\s+SD_ABI_VERSION\s+(\d+)", open(path).read(), flags=re.M)
+    if not m:
+        raise ImportError("SD_ABI_VERSION missing from %s" % path)
+    return int(m.group(1))
+
+
 class SimpleDetOpsError(RuntimeError):
     pass
 
@@ -83,6 +90,13 @@ class _Lib:
                                   % (LIB_PATH, name)) from e
             fn.restype = restype
             fn.argtypes = [t for _, t in args]
+        # buffer layouts and size contracts are part of the ABI: a library older or newer than the
+        # header this wrapper marshals for is refused
+        want = header_abi_version()
+        got = int(self.cdll.sd_abi_version())
+        if got != want:
+            raise ImportError("simpledet_amd: %s has ABI version %d, include/simpledet_ops.h %d: rebuild "
+                              "(`make -C simpledet_amd/csrc`)" % (LIB_PATH, got, want))
 
     def call(self, name, *args):
         """Call an int-returning entry point; raise SimpleDetOpsError on a non-zero code."""
@@ -94,6 +108,12 @@ class _Lib:
 
     def set_tuning(self, key, value):
         self.call("sd_set_tuning", key.encode(), int(value))
+
+    def get_tuning(self, key):
+        """value of a kernel-variant knob, -1 when it was never set (= the library's default)."""
+        v = ctypes.c_int(-1)
+        self.call("sd_get_tuning", key.encode(), ctypes.byref(v))
+        return int(v.value)
 
 
 _lib = None

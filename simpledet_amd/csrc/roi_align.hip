@@ -139,13 +139,6 @@ struct FwdArgs {
   int nslice;  // channel slices per RoI (one workgroup each)
   const int* order;  // optional locality order of the RoIs (a permutation of [0, B*R)), or null
   int ablate;  // profiling only: 1 stop after the tables
-  // hybrid launch (roi_align_fwd_hybrid): levels whose planes are kept resident in LDS
-  unsigned res_mask;                  // bit l: level l is handled by the resident workgroups
-  int nres_lv;                        // resident levels, in launch order (longest workgroups first)
-  int res_lvl[SD_MAX_FPN_LEVELS];     // level of launch slot i
-  int res_g[SD_MAX_FPN_LEVELS];       // channels per resident workgroup of launch slot i
-  int res_end[SD_MAX_FPN_LEVELS];     // exclusive prefix of resident workgroups over the slots
-  int nres;                           // resident workgroups, padded to a multiple of 8 (XCD phase)
   long long* dbg;                     // profiling build only: per-wave phase clocks (or null)
 };
 
@@ -216,8 +209,6 @@ struct FwdSmem {
     int any_valid;
     float box[4];
   } roi[NROI];
-  int sel[NROI];     // hybrid launch: RoI index of each slot after compaction (-2: none)
-  int wcnt[NWAVE];   // hybrid launch: per-wave counts of the compaction scan
 };
 
 // sample table of one axis bin; returns the number of loop iterations (reference loop, capped at 3)
@@ -327,7 +318,7 @@ __global__ __launch_bounds__(64) void roi_coords_kernel(const float* rois, int n
 // 14x14 RoI is handled as four 7x7 quadrants ("virtual RoIs" with bin rows / columns 7q .. 7q+6 of
 // the 14-bin axes), each with the 7x7 kernel's tile, registers and occupancy; only the axis tables,
 // the coordinate-table indices and the output indices know about the quadrant.
-template <int PH, int PW, int NROI, bool PK, bool LEAN, int POOL = PH, int NWAVE_ = 8, bool HYB = false>
+template <int PH, int PW, int NROI, bool PK, bool LEAN, int POOL = PH, int NWAVE_ = 8>
 __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW, NROI, NWAVE_>& s,
                                                const int bid) {
   static_assert(PH == PW && POOL % PH == 0, "square tiles, whole quadrants");
@@ -362,54 +353,14 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
   const int nch = a.C / nslice;  // channels of this workgroup
   const int cbeg = slice * nch;
 
-  // ---- hybrid launch: this workgroup's slots index the RoIs the LDS-resident workgroups do NOT
-  // handle (no level, or a level whose plane is not resident), in RoI order.  Every workgroup
-  // scans the boxes (one per thread), an ordered ballot / prefix compaction finds its slots; a
-  // workgroup past the end of the compacted list exits.
-  if (HYB) {
-    const int nreal = a.B * a.R;
-    const int w0 = grp * NROI;  // first (virtual) slot of this workgroup
-    if (tid < NROI) s.sel[tid] = -2;
-    int base = 0;
-    for (int r0 = 0; r0 < nreal; r0 += THREADS) {
-      const int tq = r0 + tid;
-      bool f = false;
-      if (tq < nreal) {
-        const float4 bx = *reinterpret_cast<const float4*>(a.rois + (long)tq * 4);
-        const int lv = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
-        f = !(lv >= 0 && ((a.res_mask >> lv) & 1));
-      }
-      const unsigned long long m = __ballot(f);
-      if (lane == 0) s.wcnt[wave] = __popcll(m);
-      __syncthreads();
-      int pre = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < NWAVE; ++w) {
-        const int c = s.wcnt[w];
-        pre += w < wave ? c : 0;
-        tot += c;
-      }
-      if (f) {
-        const int pos = base + pre + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-#pragma unroll
-        for (int i = 0; i < NROI; ++i)
-          if (pos == (w0 + i) / NQ) s.sel[i] = tq;
-      }
-      base += tot;
-      __syncthreads();
-      if (base > (w0 + NROI - 1) / NQ) break;
-    }
-    if (base <= w0 / NQ) return;  // (uniform) nothing left for this workgroup
-  }
-
   // ---- per-RoI sample tables: wave 2i rows, wave 2i+1 columns of RoI i ----
   if (wave < 2 * NROI) {
     const int i = wave >> 1, slot = grp * NROI + i;
     typename S::Roi& t = s.roi[i];
     int lvl = -2, cnt = 0, n = 0;
     const int quad = slot % NQ, qr = quad / NQA, qc = quad % NQA;
-    if (HYB ? s.sel[i] >= 0 : slot < nroi_total) {
-      n = HYB ? s.sel[i] : (a.order ? a.order[slot / NQ] : slot / NQ);
+    if (slot < nroi_total) {
+      n = a.order ? a.order[slot / NQ] : slot / NQ;
       const float* r = a.rois + (long)n * 4;
       const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
       lvl = 0;
@@ -779,361 +730,6 @@ template <int NROI>
 __global__ __launch_bounds__(512) void roi_align_fwd_quad14_float(FwdArgs a) {
   __shared__ FwdSmem<7, 7, NROI> s;
   fwd_tiled_body<7, 7, NROI, false, false, 14>(a, s, blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-resident forward (round 3): the per-RoI tap gathers of the tiled kernel are what bounds it
-// (texture-address unit 75-85 % busy, every feature byte fetched ~2x).  For a level whose channel
-// plane fits in LDS the gathers disappear: a workgroup = (level, image, G consecutive channels)
-// copies its G planes into LDS with dense 16-byte loads (each feature byte is read from HBM once,
-// fully coalesced), builds the ordered list of the image's RoIs on that level, and its waves then
-// take RoIs from the list: the axis tables of four RoIs are computed in one pass (lane 16r + p:
-// bin row p of RoI r, lane 16r + 8 + q: bin column q), handed to the bin lanes with ds_bpermute,
-// and every bin reads its 16 taps straight from the plane (eight ds_read2_b32: the (left, right)
-// pair of a column sample is adjacent) for each of the G channels.  Same float expressions in the
-// same order as roi_align_fwd_elem, so the result is bit-equal.
-// The hybrid kernel runs these workgroups and, behind them in the same launch, the tiled
-// (gather) workgroups for the RoIs of the levels that do not fit (P2 at the baseline).
-// ------------------------------------------------------------------------------------------------
-constexpr int kResThreads = 1024;          // workgroup size of the hybrid launch
-constexpr int kResMaxLoads = 5;            // 16-byte loads per thread that fill the planes
-
-
-struct ResSmemTail {
-  int wcnt[kResThreads / kWave];
-  int next;   // next unit of the RoI list (dynamic distribution over the waves)
-  int count;
-};
-
-// rare paths of the resident forward, kept out of line so that their temporaries do not count
-// against the 64-VGPR budget of the bin loop
-template <int POOL>
-__device__ __attribute__((noinline)) void res_write_coords(float* cb, float4 b, float scale, int H, int W,
-                                                           int lane) {
-  for (int e = lane; e < 3 * (POOL + POOL); e += kWave) {
-    const bool row = e < 3 * POOL;
-    const int jj = row ? e : e - 3 * POOL;
-    const float v = row ? sample_coord(jj / 3, POOL, b.y, b.w, scale, H, jj % 3)
-                        : sample_coord(jj / 3, POOL, b.x, b.z, scale, W, jj % 3);
-    cb[e] = v;
-    store_tap(cb + 3 * (POOL + POOL) + 2 * e, v, row ? H : W);
-  }
-}
-
-template <int POOL, bool PK>
-__device__ __attribute__((noinline)) void res_fallback(float* out, float* ax, float* ay,
-                                                       unsigned char* amax8, bool addz, const float* gp,
-                                                       float4 b, float scale, int H, int W, int G,
-                                                       long orow, int lane) {
-  constexpr int PPG = POOL * POOL, PPSG = amax_stride(PPG);
-  const long HW = (long)H * W;
-  for (int e = lane; e < G * PPG; e += kWave) {
-    const int c = e / PPG, g = e % PPG;
-    FwdOut o = roi_align_fwd_elem(gp + (long)c * HW, H, W, b.x, b.y, b.z, b.w, scale, g / POOL, g % POOL,
-                                  POOL, POOL);
-    if (addz) o.val = o.val + 0.0f;
-    out[(orow + c) * PPG + g] = o.val;
-    if (PK) {
-      amax8[(orow + c) * PPSG + g] = (unsigned char)o.code;
-    } else {
-      ax[(orow + c) * PPG + g] = o.ax;
-      ay[(orow + c) * PPG + g] = o.ay;
-    }
-  }
-}
-
-template <int POOL, bool PK>
-__device__ __forceinline__ void fwd_resident_body(const FwdArgs& a, float* smem, const int rb) {
-  constexpr int TP = 7;                                // bins per axis of one lane pass
-  static_assert(POOL % TP == 0 && POOL <= 16 * 2, "7x7 lane passes");
-  constexpr int NQA = POOL / TP;                        // lane passes per axis
-  constexpr int HALF = POOL <= 8 ? 8 : 16;              // lanes of one axis in the table pass
-  constexpr int LPR = 2 * HALF, NRP = kWave / LPR;      // lanes per RoI, RoIs per table pass
-  constexpr int PPG = POOL * POOL, PPSG = amax_stride(PPG);
-  constexpr int NW = kResThreads / kWave;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-
-  // ---- block -> (level, image, channel group); consecutive groups of an XCD are adjacent ----
-  int li = 0;
-  while (li + 1 < a.nres_lv && rb >= a.res_end[li]) ++li;
-  if (rb >= a.res_end[li]) return;  // padding block
-  const int lvl = a.res_lvl[li];
-  const int idx = rb - (li ? a.res_end[li - 1] : 0);
-  const int G = a.res_g[li], ngroups = a.C / G;
-  int img, cg;
-  if (ngroups % kNumXCD == 0) {
-    const int gpx = ngroups / kNumXCD, x = idx % kNumXCD, j = idx / kNumXCD;
-    img = j / gpx;
-    cg = x * gpx + j % gpx;
-  } else {
-    img = idx / ngroups;
-    cg = idx % ngroups;
-  }
-  const int H = a.L.H[lvl], W = a.L.W[lvl], HW = H * W;
-  const float scale = a.L.scale[lvl];
-  const int c0 = cg * G;
-  const int n4 = (G * HW) >> 2;  // the launcher guarantees G*HW % 4 == 0 and 16-byte alignment
-  float* plane = smem;
-  float4* boxes = reinterpret_cast<float4*>(smem + ((G * HW + 4 + 3) & ~3));  // the image's RoIs
-  unsigned short* list = reinterpret_cast<unsigned short*>(boxes + a.R);
-  ResSmemTail* tail = reinterpret_cast<ResSmemTail*>(list + ((a.R + 7) & ~7));
-
-#ifdef SD_PROFILING
-  const long long t_begin = __builtin_readcyclecounter();
-#endif
-  // ---- RoI boxes, then the planes straight into LDS (global_load_lds_dwordx4: no staging
-  // registers, wave-uniform LDS base + lane * 16), then the list while the planes are in flight
-  // (the first barrier of the list phase is where the compiler's vmcnt(0) waits for them) ----
-  const float4* rois4 = reinterpret_cast<const float4*>(a.rois) + (long)img * a.R;
-  float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid < a.R) box = rois4[tid];
-  int lv0 = -1;
-  if (tid < a.R) lv0 = a.L.nlvl > 1 ? fpn_level(box.x, box.y, box.z, box.w, a.L) : 0;
-  {
-    const float4* src = reinterpret_cast<const float4*>(a.L.data[lvl] + ((long)img * a.C + c0) * HW);
-    float4* dst = reinterpret_cast<float4*>(plane);
-#pragma unroll
-    for (int k = 0; k < kResMaxLoads; ++k) {
-      const int w4 = (k * NW + wave) * kWave;  // first 16-byte word of this wave's piece
-      if (w4 + lane < n4)
-        __builtin_amdgcn_global_load_lds(src + w4 + lane, dst + w4, 16, 0, 0);
-    }
-  }
-  if (tid == 0) tail->next = 0;
-  int base = 0;
-  for (int r0 = 0; r0 < a.R; r0 += kResThreads) {
-    const int t = r0 + tid;
-    bool f = false;
-    if (t < a.R) {
-      int lv = lv0;
-      if (r0) {
-        box = rois4[t];
-        lv = a.L.nlvl > 1 ? fpn_level(box.x, box.y, box.z, box.w, a.L) : 0;
-      }
-      f = lv == lvl;
-      boxes[t] = box;  // no global load (and so no wait behind the output stores) after this phase
-    }
-    const unsigned long long m = __ballot(f);
-    if (lane == 0) tail->wcnt[wave] = __popcll(m);
-    __syncthreads();
-    int pre = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const int c = tail->wcnt[w];
-      pre += w < wave ? c : 0;
-      tot += c;
-    }
-    if (f)
-      list[base + pre + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
-          (unsigned short)t;
-    base += tot;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's global_load_lds pieces have landed
-    __syncthreads();
-  }
-  const int count = base;
-  if (count == 0) return;  // (uniform) no RoI of this image on this level
-
-  if (SD_ABLATE(a, 128)) return;  // profiling build: plane fill + list only
-#ifdef SD_PROFILING
-  long long t_fill = __builtin_readcyclecounter() - t_begin, t_tab = 0, t_bin = 0, n_unit = 0;
-  long long t_mark = __builtin_readcyclecounter();
-#endif
-  // ===== from here on every wave runs on its own =====
-  const int nunits = (count + NRP - 1) / NRP;
-  const long obase_img = (long)img * a.R;
-  while (true) {
-    int j = 0;
-    if (lane == 0) j = atomicAdd(&tail->next, 1);
-    j = __builtin_amdgcn_readfirstlane(j);
-    if (j >= nunits) break;
-#ifdef SD_PROFILING
-    t_mark = __builtin_readcyclecounter();
-    ++n_unit;
-#endif
-    // lane-derived values are recomputed per unit from an opaque copy of the lane id: hoisted out
-    // of the loops they would be live across the bin loop, which has no registers to spare
-    int lane_t = lane;
-    asm volatile("" : "+v"(lane_t));
-    const int tr = lane_t / LPR, ta = lane_t % LPR;     // table pass: RoI of the unit, axis lane
-    const bool trow = ta < HALF;
-    const int tp = trow ? ta : ta - HALF;                 // bin row / column
-    // ---- axis tables of the unit's RoIs, one lane per (RoI, axis, bin) ----
-    const int le = j * NRP + tr;
-    int n = 0;
-    float val[2] = {0.f, 0.f}, frac[2], pk_lo = 0.f;
-    int off[4] = {-1, -1, -1, -1}, cnt = -1;
-    (void)pk_lo;
-    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (le < count) {
-      n = list[le];
-      bx = boxes[n];
-    }
-    frac[0] = frac[1] = 0.f;
-    if (le < count && tp < POOL)
-      cnt = axis_samples(tp, POOL, trow ? bx.y : bx.x, trow ? bx.w : bx.z, scale, trow ? H : W,
-                         trow ? W : 1, val, frac, off);
-    // entries handed to the bin lanes.  rows: {lo0 | hi0 << 16 | empty << 31, lo1 | hi1 << 16, a0, a1}
-    // (offsets in floats), columns: {left0 | dup0 << 10 | left1 << 11 | dup1 << 21 | empty << 22, b0, b1};
-    // a sample the loop did not reach has a NaN fraction: its value is NaN and never wins
-    const float qnan = __int_as_float(0x7fc00000);
-    const int o0 = cnt > 0 ? off[0] : 0, o1 = cnt > 0 ? off[1] : 0;
-    const int o2 = cnt > 1 ? off[2] : 0, o3 = cnt > 1 ? off[3] : 0;
-    int e0, e1;
-    if (trow) {
-      e0 = o0 | (o1 << 16) | (cnt < 0 ? (int)0x80000000 : 0);
-      e1 = o2 | (o3 << 16);
-    } else {
-      e0 = o0 | ((cnt > 0 && o0 == o1) ? 1 << 10 : 0) | (o2 << 11) |
-           ((cnt > 1 && o2 == o3) ? 1 << 21 : 0) | (cnt < 0 ? 1 << 22 : 0);
-      e1 = 0;
-    }
-    const float f0 = cnt > 0 ? frac[0] : qnan, f1 = cnt > 1 ? frac[1] : qnan;
-    const unsigned long long fbm = __ballot(cnt >= 3);
-    const unsigned long long dupm = __ballot(!trow && (e0 & ((1 << 10) | (1 << 21))) != 0);
-
-#ifdef SD_PROFILING
-    {
-      const long long now = __builtin_readcyclecounter();
-      t_tab += now - t_mark;
-      t_mark = now;
-    }
-#endif
-#pragma unroll 1
-    for (int r = 0; r < NRP; ++r) {
-      if (j * NRP + r >= count) break;
-      const int rn = __builtin_amdgcn_readlane(n, r * LPR);
-      const unsigned long long rmask = (LPR == 64 ? ~0ull : ((1ull << LPR) - 1)) << (r * LPR);
-      const long orow = (obase_img + rn) * a.C + c0;  // (RoI, first channel) row of the outputs
-      if (PK && c0 == 0)  // the sample coordinates the packed arg-max indexes, once per RoI
-        res_write_coords<POOL>(a.coords + (obase_img + rn) * kCoordWords * (POOL + POOL), boxes[rn],
-                               scale, H, W, lane);
-      if (fbm & rmask) {
-        // a 3-iteration sample loop (stride within an ulp of 0.01): exact per-element path
-        res_fallback<POOL, PK>(a.out, a.ax, a.ay, a.amax8, a.L.nlvl > 1,
-                               a.L.data[lvl] + ((long)img * a.C + c0) * HW, boxes[rn], scale, H, W, G,
-                               orow, lane);
-        continue;
-      }
-      if (SD_ABLATE(a, 256)) continue;  // profiling build: table pass only
-      const bool any_dup = (dupm & rmask) != 0;
-#pragma unroll 1
-      for (int quad = 0; quad < NQA * NQA; ++quad) {
-        const int qr = quad / NQA, qc = quad % NQA;
-        int lane_b = lane;
-        asm volatile("" : "+v"(lane_b));
-        const int bin = lane_b < TP * TP ? lane_b : 0;
-        const int p = qr * TP + bin / TP, q = qc * TP + bin % TP;
-        const int rl = (r * LPR + p) << 2, cl = (r * LPR + HALF + q) << 2;
-        const int re0 = __builtin_amdgcn_ds_bpermute(rl, e0);
-        const int re1 = __builtin_amdgcn_ds_bpermute(rl, e1);
-        const float al0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rl, __float_as_int(f0)));
-        const float al1 = __int_as_float(__builtin_amdgcn_ds_bpermute(rl, __float_as_int(f1)));
-        const int ce0 = __builtin_amdgcn_ds_bpermute(cl, e0);
-        const float be0 = __int_as_float(__builtin_amdgcn_ds_bpermute(cl, __float_as_int(f0)));
-        const float be1 = __int_as_float(__builtin_amdgcn_ds_bpermute(cl, __float_as_int(f1)));
-        float cy0 = 0.f, cy1 = 0.f, cx0 = 0.f, cx1 = 0.f;
-        if (!PK) {
-          cy0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rl, __float_as_int(val[0])));
-          cy1 = __int_as_float(__builtin_amdgcn_ds_bpermute(rl, __float_as_int(val[1])));
-          cx0 = __int_as_float(__builtin_amdgcn_ds_bpermute(cl, __float_as_int(val[0])));
-          cx1 = __int_as_float(__builtin_amdgcn_ds_bpermute(cl, __float_as_int(val[1])));
-        }
-        const bool empty = (re0 < 0) || ((ce0 >> 22) & 1);
-        const float init = empty ? 0.f : -FLT_MAX;
-        const int left0 = ce0 & 1023, left1 = (ce0 >> 11) & 1023;
-        const bool dup0 = (ce0 >> 10) & 1, dup1 = (ce0 >> 21) & 1;
-        // tap addresses (floats) [k][dh][l]
-        const int r00 = re0 & 0x7fff, r01 = (re0 >> 16) & 0x7fff;
-        const int r10 = re1 & 0x7fff, r11 = (re1 >> 16) & 0x7fff;
-        const int A000 = r00 + left0, A001 = r00 + left1, A010 = r01 + left0, A011 = r01 + left1;
-        const int A100 = r10 + left0, A101 = r10 + left1, A110 = r11 + left0, A111 = r11 + left1;
-        // weight products, the reference's expressions (roi_align_v2-inl.h:131-134)
-        float4 w00, w01, w10, w11;
-        w00.x = (1 - al0) * (1 - be0); w00.y = al0 * (1 - be0); w00.z = (1 - al0) * be0; w00.w = al0 * be0;
-        w01.x = (1 - al0) * (1 - be1); w01.y = al0 * (1 - be1); w01.z = (1 - al0) * be1; w01.w = al0 * be1;
-        w10.x = (1 - al1) * (1 - be0); w10.y = al1 * (1 - be0); w10.z = (1 - al1) * be0; w10.w = al1 * be0;
-        w11.x = (1 - al1) * (1 - be1); w11.y = al1 * (1 - be1); w11.z = (1 - al1) * be1; w11.w = al1 * be1;
-        const int g0 = (qr * TP + bin / TP) * POOL + qc * TP + bin % TP;  // output index of the bin
-        const float* pl = plane;
-        float* po = a.out + orow * PPG;  // wave-uniform bases, the lane adds its bin
-        float* px = PK ? nullptr : a.ax + orow * PPG;
-        float* py = PK ? nullptr : a.ay + orow * PPG;
-        unsigned char* pk = PK ? a.amax8 + orow * PPSG : nullptr;
-        for (int g = 0; g < G; ++g) {
-          float2 t000 = make_float2(pl[A000], pl[A000 + 1]), t010 = make_float2(pl[A010], pl[A010 + 1]);
-          float2 t001 = make_float2(pl[A001], pl[A001 + 1]), t011 = make_float2(pl[A011], pl[A011 + 1]);
-          float2 t100 = make_float2(pl[A100], pl[A100 + 1]), t110 = make_float2(pl[A110], pl[A110 + 1]);
-          float2 t101 = make_float2(pl[A101], pl[A101 + 1]), t111 = make_float2(pl[A111], pl[A111 + 1]);
-          if (any_dup) {  // coincident (left, right) columns: both taps are the left pixel
-            if (dup0) { t000.y = t000.x; t010.y = t010.x; t100.y = t100.x; t110.y = t110.x; }
-            if (dup1) { t001.y = t001.x; t011.y = t011.x; t101.y = t101.x; t111.y = t111.x; }
-          }
-          float maxval = init, bx_ = -1.f, by_ = -1.f;
-          int bk = 255;
-          float value;
-          value = w00.x * t000.x + w00.y * t010.x + w00.z * t000.y + w00.w * t010.y;
-          if (value > maxval) { maxval = value; bk = 0; bx_ = cx0; by_ = cy0; }
-          value = w01.x * t001.x + w01.y * t011.x + w01.z * t001.y + w01.w * t011.y;
-          if (value > maxval) { maxval = value; bk = 1; bx_ = cx1; by_ = cy0; }
-          value = w10.x * t100.x + w10.y * t110.x + w10.z * t100.y + w10.w * t110.y;
-          if (value > maxval) { maxval = value; bk = 3; bx_ = cx0; by_ = cy1; }
-          value = w11.x * t101.x + w11.y * t111.x + w11.z * t101.y + w11.w * t111.y;
-          if (value > maxval) { maxval = value; bk = 4; bx_ = cx1; by_ = cy1; }
-          if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-          if (lane_b < TP * TP) {
-            po[g0] = maxval;
-            if (PK) {
-              pk[g0] = (unsigned char)bk;
-            } else {
-              px[g0] = bx_;
-              py[g0] = by_;
-            }
-          }
-          pl += HW;
-          po += PPG;
-          if (PK) {
-            pk += PPSG;
-          } else {
-            px += PPG;
-            py += PPG;
-          }
-        }
-      }
-    }
-#ifdef SD_PROFILING
-    {
-      const long long now = __builtin_readcyclecounter();
-      t_bin += now - t_mark;
-      t_mark = now;
-    }
-#endif
-  }
-#ifdef SD_PROFILING
-  if (a.dbg && lane == 0) {
-    long long* d = a.dbg + ((long)rb * NW + wave) * 8;
-    d[0] = t_fill; d[1] = t_tab; d[2] = t_bin; d[3] = n_unit;
-    d[4] = __builtin_readcyclecounter() - t_begin; d[5] = lvl; d[6] = count; d[7] = G;
-  }
-#endif
-}
-
-// tiled (gather) workgroups of the hybrid launch: 16 waves, four RoIs of tables
-template <int POOL>
-using HybSmem = FwdSmem<7, 7, 4, kResThreads / kWave>;
-
-template <int POOL, bool PK>
-__global__ __launch_bounds__(kResThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_hybrid(
-    FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float hyb_smem[];
-  if ((int)blockIdx.x < a.nres) {
-    if (SD_ABLATE(a, 8)) return;   // profiling build: tiled part alone
-    fwd_resident_body<POOL, PK>(a, hyb_smem, blockIdx.x);
-  } else {
-    if (SD_ABLATE(a, 16)) return;  // profiling build: resident part alone
-    fwd_tiled_body<7, 7, 4, PK, true, POOL, kResThreads / kWave, true>(
-        a, *reinterpret_cast<HybSmem<POOL>*>(hyb_smem), (int)blockIdx.x - a.nres);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3073,7 +2669,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     const int POOL = a.PH;
     bool ok = true;
     int wg = 0, units = 0;
-    const int want_steps = tuning("roi_align_fwd_steps", 8), gmax = tuning("roi_align_fwd_res_g", 8);
+    const int want_steps = tuning("roi_align_fwd_steps", 8), gmax = tuning("roi_align_fwd_g", 8);
     int nvalid_lv = 0;
     for (int l = 0; l < a.L.nlvl; ++l) nvalid_lv += a.L.stride[l] >= 0;
     for (int l = 0; l < a.L.nlvl; ++l) {
@@ -3175,77 +2771,6 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
         if (a.amax8) SD_FWD_BAND(14, true); else SD_FWD_BAND(14, false);
       }
 #undef SD_FWD_BAND
-      SD_LAUNCH_CHECK();
-      return SD_OK;
-    }
-  }
-  // ---- hybrid launch: LDS-resident workgroups for the levels whose planes fit, tiled (gather)
-  // workgroups for the rest (knob roi_align_fwd_res = 0: tiled kernels only) ----
-  if (variant == 1 && wide && !a.order && ((a.PH == 7 && a.PW == 7) || (a.PH == 14 && a.PW == 14)) &&
-      a.R <= 16384 && tuning("roi_align_fwd_res", 0)) {
-    const int gmax = tuning("roi_align_fwd_res_g", 8);
-    const int lvmask = tuning("roi_align_fwd_res_levels", 0xff);  // levels allowed to be resident
-    const size_t cap = 80 * 1024;  // two workgroups per CU
-    const size_t fixed = 16 + (size_t)a.R * 16 + (size_t)((a.R + 7) & ~7) * 2 + sizeof(ResSmemTail);
-    int lv[SD_MAX_FPN_LEVELS], g_of[SD_MAX_FPN_LEVELS], nl = 0;
-    size_t need = 0;
-    int nvalid = 0;
-    for (int l = 0; l < a.L.nlvl; ++l) {
-      if (a.L.stride[l] < 0) continue;
-      ++nvalid;
-      const long HW = (long)a.L.H[l] * a.L.W[l];
-      if (a.L.W[l] > 1023 || HW >= 32768 || ((uintptr_t)a.L.data[l] & 15)) continue;
-      if (!((lvmask >> l) & 1)) continue;
-      int g = 0;
-      for (int c = 1; c <= gmax && c <= 8; c *= 2)
-        if (a.C % c == 0 && (c * HW) % 4 == 0 && (size_t)c * HW * 4 + fixed <= cap) g = c;
-      if (!g) continue;
-      lv[nl] = l;
-      g_of[nl] = g;
-      ++nl;
-      const size_t nd = (size_t)g * HW * 4 + fixed;
-      if (nd > need) need = nd;
-    }
-    if (nl > 0) {
-      // launch order: most channels per workgroup first (the longest workgroups), then larger planes
-      for (int i = 0; i < nl; ++i)
-        for (int j = i + 1; j < nl; ++j) {
-          const long wi = (long)a.L.H[lv[i]] * a.L.W[lv[i]], wj = (long)a.L.H[lv[j]] * a.L.W[lv[j]];
-          if (g_of[j] > g_of[i] || (g_of[j] == g_of[i] && wj > wi)) {
-            int t = lv[i]; lv[i] = lv[j]; lv[j] = t;
-            t = g_of[i]; g_of[i] = g_of[j]; g_of[j] = t;
-          }
-        }
-      a.res_mask = 0;
-      a.nres_lv = nl;
-      int end = 0;
-      for (int i = 0; i < nl; ++i) {
-        a.res_lvl[i] = lv[i];
-        a.res_g[i] = g_of[i];
-        a.res_mask |= 1u << lv[i];
-        end += a.B * (a.C / g_of[i]);
-        a.res_end[i] = end;
-      }
-      a.nres = (end + kNumXCD - 1) / kNumXCD * kNumXCD;
-      // single-level op with its level resident: no RoI is left for the tiled workgroups
-      const bool all_res = a.L.nlvl == 1 && nl == nvalid;
-      const int NQ = a.PH == 14 ? 4 : 1;
-      const int ngather = all_res ? 0 : cdiv((long)nroi * NQ, 4) * a.nslice;
-      size_t smem = need > sizeof(HybSmem<7>) ? need : sizeof(HybSmem<7>);
-      smem = (smem + 15) & ~(size_t)15;
-#define SD_FWD_HYB(POOL, PK)                                                                      \
-  do {                                                                                            \
-    auto k = roi_align_fwd_hybrid<POOL, PK>;                                                      \
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                     (int)smem));                                                 \
-    hipLaunchKernelGGL(k, dim3(a.nres + ngather), dim3(kResThreads), smem, st, a);                \
-  } while (0)
-      if (a.PH == 7) {
-        if (a.amax8) SD_FWD_HYB(7, true); else SD_FWD_HYB(7, false);
-      } else {
-        if (a.amax8) SD_FWD_HYB(14, true); else SD_FWD_HYB(14, false);
-      }
-#undef SD_FWD_HYB
       SD_LAUNCH_CHECK();
       return SD_OK;
     }

@@ -103,7 +103,10 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
   const int ES = 4 + PH + PW;  // table words per RoI: index, valid, max extents, row / column pairs
   float* plane = smem;
   int* tab = reinterpret_cast<int*>(smem + ((HW + 3) & ~3));
-  __shared__ int cnt;
+  // chunk counters, one per chunk parity: the counter of the NEXT chunk is reset after this
+  // chunk's listing barrier, when no wave can still be reading it (a single counter reset at the
+  // top of the loop raced with slow waves reading the previous chunk's count)
+  __shared__ int cnt[2];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   // Workgroup i runs on XCD i % 8, and the 196-byte output rows of neighbouring channels share
@@ -114,8 +117,8 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
   const float* src = a.data + ((long)b * a.C + c) * HW;
   for (int i = tid; i < HW; i += T) plane[i] = src[i];
 
-  for (int k0 = 0; k0 < a.K; k0 += CHUNK) {
-    if (tid == 0) cnt = 0;
+  if (tid == 0) cnt[0] = 0;
+  for (int k0 = 0, par = 0; k0 < a.K; k0 += CHUNK, par ^= 1) {
     __syncthreads();  // (also: plane complete, previous chunk's items done)
     // two threads per RoI: the first lists it and does the rows, the second the columns
     const int k = k0 + (tid >> 1), axis = tid & 1;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
       // a RoI whose batch index names no image pools nothing; image 0's workgroups write its zeros
       const bool mine = batch_ok ? ind == b : b == 0;
       int slot = 0;
-      if (mine && axis == 0) slot = atomicAdd(&cnt, 1);
+      if (mine && axis == 0) slot = atomicAdd(&cnt[par], 1);
       slot = __shfl(slot, (tid & 63) & ~1);
       if (mine) {
         int* e = tab + ES * slot;
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
       }
     }
     __syncthreads();
-    const int n = cnt;
+    const int n = cnt[par];
+    if (tid == 0) cnt[par ^ 1] = 0;
     for (int ri = wave; ri < n; ri += NWAVE) {
       const int* e = tab + ES * ri;
       const long obase = ((long)__builtin_amdgcn_readfirstlane(e[0]) * a.C + c) * PP;

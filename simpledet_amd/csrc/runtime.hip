@@ -44,9 +44,7 @@ Knob g_knobs[] = {
     {"roi_align_fwd_grab", 0, false},    // channels a band workgroup reserves at a time (default 4)
     {"roi_align_fwd_wgs", 0, false},     // persistent band workgroups (default 256 = one per CU)
     {"roi_align_fwd_split", 0, false},   // 1 more bands than LDS needs when a unit's expected items exceed a round (default)
-    {"roi_align_fwd_res", 0, false},     // 1 hybrid launch: whole planes resident in LDS for the levels that fit + tiled workgroups for the rest (measured slower: VALU bound on per-workgroup tables), 0 off (default)
-    {"roi_align_fwd_res_levels", 0, false},  // bit mask of the levels allowed to be resident (default all)
-    {"roi_align_fwd_res_g", 0, false},   // most channels per resident workgroup (1, 2, 4 or 8; default 8)
+    {"roi_align_fwd_g", 0, false},       // most planes per fill of the band-resident forward (1, 2, 4 or 8; default 8)
     {"roi_align_bwd", 0, false},         // 0 global atomics, 1 per-level LDS planes, 2 fused (default)
     {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 36
     {"roi_align_bwd_accum", 0, false},   // per-level plane path only: 1 int64 fixed point, 0 float CAS
@@ -115,7 +113,7 @@ extern "C" int sd_stream_synchronize(void* stream) {
 }
 
 extern "C" const char* sd_last_error(void) { return sd::err_buf(); }
-extern "C" int sd_abi_version(void) { return 1; }
+extern "C" int sd_abi_version(void) { return SD_ABI_VERSION; }
 
 extern "C" int sd_set_tuning(const char* key, int value) {
   if (!key) return sd::fail(SD_ERR_INVALID_ARG, "null tuning key");

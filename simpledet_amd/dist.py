@@ -94,7 +94,11 @@ class GradBucketReducer:
                 p.grad = view
                 off += n
                 self._bucket_of[id(p)] = len(self.buckets)
-            self.buckets.append({"flat": flat, "params": g, "pending": len(g), "handle": None})
+            # only parameters that receive gradients count a bucket down (a frozen BN / stem
+            # parameter has no hook: with it in the count the bucket would never launch early)
+            live = sum(1 for p in g if p.requires_grad)
+            self.buckets.append({"flat": flat, "params": g, "pending": live, "live": live, "handle": None,
+                                 "seen": set()})
         cuda = bool(self.params) and self.params[0].is_cuda
         self.stream = torch.cuda.Stream() if cuda else None
         self._hooks = []
@@ -108,9 +112,11 @@ class GradBucketReducer:
         for b in self.buckets:
             b["flat"].zero_()
 
-    def _launch(self, b):
+    def _launch(self, b, producer=None):
+        """all-reduce bucket b on the side stream, ordered after `producer` (the stream the
+        gradients were written on: the CURRENT stream at the time of the call unless given)."""
         if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            self.stream.wait_stream(producer if producer is not None else torch.cuda.current_stream())
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
         with ctx:
             b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
@@ -121,6 +127,7 @@ class GradBucketReducer:
             # autograd replaced the view (first accumulation into a None grad): fold it back
             self._view(b, p).copy_(p.grad)
             p.grad = self._view(b, p)
+        b["seen"].add(id(p))
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -142,17 +149,29 @@ class GradBucketReducer:
         the current stream, re-arm the per-bucket counters."""
         if self.world == 1:
             return
+        # the compute stream, captured BEFORE entering the side-stream context: inside it the
+        # "current stream" is the side stream itself and waiting on it would order nothing
+        producer = torch.cuda.current_stream() if self.stream is not None else None
+        for b in self.buckets:
+            if b["handle"] is None:   # a bucket some gradient never arrived for
+                if self._hooks:
+                    # a parameter that got no gradient this step takes part with zeros, not with the
+                    # averaged value its slot still holds from the previous step
+                    for p in b["params"]:
+                        if p.requires_grad and id(p) not in b["seen"]:
+                            self._view(b, p).zero_()
+                            if p.grad is None:
+                                p.grad = self._view(b, p)
+                self._launch(b, producer)
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
         with ctx:
-            for b in self.buckets:
-                if b["handle"] is None:   # a bucket some gradient never arrived for
-                    self._launch(b)
             for b in self.buckets:
                 b["handle"].wait()
                 if self.average:
                     b["flat"].div_(self.world)
                 b["handle"] = None
-                b["pending"] = len(b["params"])
+                b["pending"] = b["live"]
+                b["seen"] = set()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 

@@ -387,11 +387,14 @@ def _build_ops(mx):
                 self.assign(in_grad[i], req[i], 0)
 
     class ProposalMaskTargetProp(ProposalTargetProp):
-        def __init__(self, num_args, num_classes, batch_images, image_rois, mask_size, fg_thresh,
+        def __init__(self, num_classes, batch_images, image_rois, mask_size, fg_thresh,
                      bg_thresh_hi, bg_thresh_lo, proposal_without_gt, fg_fraction="0.25",
                      class_agnostic="False", ohem="False", output_ratio="False", output_iou="False",
                      filter_scales="False", bbox_mean="(0,0,0,0)", bbox_std="(0.1,0.1,0.2,0.2)",
-                     bbox_weight="(1,1,1,1)"):
+                     bbox_weight="(1,1,1,1)", num_args=None):
+            # num_args is the reference op's key_var_num_args (proposal_mask_target.cc:485): MXNet's
+            # front end fills it in from the number of symbol inputs and no call site passes it
+            # (models/maskrcnn/builder.py:115,184), so it defaults to what filter_scales implies
             super().__init__(num_classes, batch_images, image_rois, fg_thresh, bg_thresh_hi,
                              bg_thresh_lo, fg_fraction, proposal_without_gt, class_agnostic,
                              output_iou, bbox_mean, bbox_std, bbox_weight)
@@ -403,9 +406,11 @@ def _build_ops(mx):
                 raise ValueError("ProposalMaskTarget: image_rois=-1 is undefined in the reference")
             self.p["filter_scales"] = _bool(filter_scales)
             self.p["mask_size"] = int(mask_size)
-            self.num_args = int(num_args)
-            if self.num_args not in (3, 4):
-                raise ValueError("num_args must be 3 or 4")
+            want = 4 if self.p["filter_scales"] else 3
+            self.num_args = want if num_args is None else int(num_args)
+            if self.num_args != want:
+                raise ValueError("num_args=%d but filter_scales=%s takes %d inputs"
+                                 % (self.num_args, self.p["filter_scales"], want))
             self.num_visible_outputs = 6  # proposal_mask_target-inl.h:387-395 without output_ratio
 
         def list_arguments(self):

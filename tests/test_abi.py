@@ -14,7 +14,8 @@ def test_header_parses_and_library_exports_every_symbol():
     l = _lib.lib()
     for name in protos:
         assert hasattr(l.cdll, name), name
-    assert l.cdll.sd_abi_version() >= 1
+    # layout / size contracts are versioned too: library and header must agree exactly
+    assert l.cdll.sd_abi_version() == _lib.header_abi_version() >= 3
 
 
 def test_argument_validation_needs_no_gpu():

@@ -62,6 +62,26 @@ def _worker(rank, world, port, q):
                 a += p2.grad / world
         ok = ok and all(torch.allclose(p.grad, a, atol=1e-5) for p, a in zip(net.parameters(), ref))
     ok = ok and len(red2.buckets) >= 2
+    # 2c. a frozen parameter shares a bucket with trained ones (frozen BN / stem in detection nets):
+    # the bucket still launches from its last hook; a parameter that gets no gradient in a step
+    # (set_to_none) contributes zeros, not the averaged value of the step before
+    torch.manual_seed(2)
+    a_, b_, c_ = (torch.nn.Parameter(torch.randn(6)) for _ in range(3))
+    b_.requires_grad_(False)
+    red3 = sdd.GradBucketReducer([a_, b_, c_], bucket_mb=1.0)
+    ok = ok and len(red3.buckets) == 1 and red3.buckets[0]["pending"] == 2
+    (a_ * float(rank + 1)).sum().backward()
+    (c_ * 2.0).sum().backward()
+    ok = ok and red3.buckets[0]["handle"] is not None      # launched by the hooks, not by finish()
+    red3.finish()
+    ok = ok and bool(torch.allclose(a_.grad, torch.full((6,), (world + 1) / 2.0)))
+    ok = ok and bool(torch.allclose(c_.grad, torch.full((6,), 2.0)))
+    a_.grad = None                                           # optimizer.zero_grad(set_to_none=True)
+    c_.grad = None
+    (a_ * float(rank + 1)).sum().backward()                  # c_ gets no gradient in this step
+    red3.finish()
+    ok = ok and bool(torch.allclose(a_.grad, torch.full((6,), (world + 1) / 2.0)))
+    ok = ok and c_.grad is not None and bool(torch.all(c_.grad == 0))
     ar = sdd.OverlappedAllReduce(4 * 100)
     ar.buf.fill_(float(rank + 1))
     ar.start()
@@ -123,4 +143,11 @@ def test_bench_self_launch_two_ranks_gloo():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["allreduce_correct"] is True
+    # the N > 1 line says what it is made of: the N = 1 figure of the same invocation, the ops-only
+    # loop, the all-reduce alone and what of it stays exposed in the timed loop
+    for k in ("n1_ms_per_step_same_invocation", "ops_only_ms_per_step", "value_ops_only",
+              "weak_scaling_eff_ops_only", "weak_scaling_eff_with_allreduce", "allreduce_alone_ms",
+              "allreduce_busbw_GBs", "allreduce_ms_exposed"):
+        assert k in d and d[k] is not None and d[k] >= 0, k
+    assert 0 < d["weak_scaling_eff_ops_only"] < 10 and 0 < d["weak_scaling_eff_with_allreduce"] < 10
     assert d["grad_allreduce_mb_per_step"] == 2 and len(d["per_rank_ms_per_step"]) == 2

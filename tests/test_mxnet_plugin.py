@@ -132,6 +132,27 @@ def test_symbol_alias_builds_custom_node_with_visible_outputs(plugin):
     assert s[1].params == {"pooled_size": "(7, 7)", "spatial_scale": "0.25"}
 
 
+def test_proposal_mask_target_alias_as_the_reference_graph_calls_it(plugin):
+    """models/maskrcnn/builder.py:115-134 calls mx.sym.ProposalMaskTarget with three positional
+    symbols and never passes num_args (MXNet's front end derives key_var_num_args from the inputs,
+    proposal_mask_target.cc:485): the alias must build the node, and the six visible outputs."""
+    mx, props, _ = plugin
+    proposal, gt_bbox, gt_poly = (mx.sym.Variable(n) for n in ("proposal", "gt_bbox", "gt_poly"))
+    outs = mx.sym.ProposalMaskTarget(
+        proposal, gt_bbox, gt_poly, mask_size=28, num_classes=81, class_agnostic=False, batch_images=2,
+        proposal_without_gt=False, image_rois=512, fg_fraction=0.25, fg_thresh=0.5, bg_thresh_hi=0.5,
+        bg_thresh_lo=0.0, bbox_weight=(1.0, 1.0, 1.0, 1.0), bbox_mean=(0.0, 0.0, 0.0, 0.0),
+        bbox_std=(0.1, 0.1, 0.2, 0.2), output_iou=True, name="subsample_proposal")
+    node = outs if not isinstance(outs, list) else outs[0][1]
+    assert node.op_type == "sd_ProposalMaskTarget" and len(node.inputs) == 3
+    assert "num_args" not in node.params
+    p = props["ProposalMaskTarget"](**node.params)
+    assert p.num_args == 3 and p.list_arguments() == ["rois", "gt_boxes", "gt_polys"]
+    assert len(p.list_outputs()) == 6
+    with pytest.raises(ValueError):
+        props["ProposalMaskTarget"](num_args="4", **node.params)
+
+
 def test_install_routes_fpn_extractor_to_the_fused_op_without_editing_the_reference(plugin):
     """models/FPN/builder.py:567-610 builds assign + 4 x roi_align + add_n; install() rebinds
     FPNRoiAlign.get_roi_feature so the same call emits one sd_fpn_roi_align node."""
