@@ -79,6 +79,15 @@ int sd_roi_align_v2_fwd(const float* data, const float* rois, float* out, float*
                         float* maxidx_y, int B, int C, int H, int W, int R, int pooled_h,
                         int pooled_w, float spatial_scale, void* stream);
 
+/* The same with DEVICE scratch of sd_roi_align_v2_workspace_bytes(B, R) bytes: the forward then runs
+ * on the band-resident kernel (feature planes streamed through LDS once, no per-RoI gathers; same
+ * bits).  workspace may be NULL (= the call above, the tiled kernels). */
+size_t sd_roi_align_v2_workspace_bytes(int B, int R);
+int sd_roi_align_v2_fwd_ws(const float* data, const float* rois, float* out, float* maxidx_x,
+                           float* maxidx_y, int B, int C, int H, int W, int R, int pooled_h,
+                           int pooled_w, float spatial_scale, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /*   replaces ROIAlignBackward_v2<gpu>  operator_cxx/contrib/roi_align_v2.cu:87-143
  *            (kernel ROIAlignBackwardKernelGPU_v2::Map :35-84; inputs per ROIAlignGrad_v2
  *            roi_align_v2-inl.h:206-218: [dY, rois, maxidx_x, maxidx_y] -> [dX, d_rois])
@@ -102,8 +111,9 @@ int sd_fpn_roi_align_fwd(const float* const* feats_host, const int* Hs_host, con
                          float* maxidx_x, float* maxidx_y, int B, int C, int R, int pooled_h,
                          int pooled_w, float roi_canonical_scale, float roi_canonical_level,
                          void* workspace, size_t workspace_bytes, void* stream);
-/* optional DEVICE scratch for the forward (a locality order of the RoIs: level-major, so the
- * small P4/P5 slices stay in an XCD's L2); with workspace == NULL the RoIs run in input order */
+/* DEVICE scratch for the forward: the band-resident kernel (the default: planes streamed through
+ * LDS once, no per-RoI gathers) keeps its per-band item lists and per-RoI tap entries there; with
+ * workspace == NULL (or too small) the forward runs on the tiled kernels instead -- same bits */
 size_t sd_fpn_roi_align_workspace_bytes(int B, int R);
 int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois, const float* maxidx_x,
                          const float* maxidx_y, float* const* d_feats_host, const int* Hs_host,

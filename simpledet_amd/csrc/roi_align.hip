@@ -760,7 +760,7 @@ constexpr int kBandMaxVisits = 8;       // virtual units one workgroup works on,
 constexpr int kBandMaxUnits = 256;      // (level, image, band) units of one launch
 constexpr int kBandFillCost = 140, kBandPlaneCost = 60, kBandSetupCost = 1500;  // cost model, in item times
 constexpr int kBandSub = 4;             // list segments per unit (pre-pass workgroups per (level, image))
-constexpr int kBandFallbackWGs = 256;  // (a multiple of 8: the XCD phase of the band workgroups)
+constexpr int kBandFallbackWGs = 0;    // (no separate exact-path blocks: the band workgroups do that work last)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -770,10 +770,7 @@ struct BandPlan {
   int nbands[SD_MAX_FPN_LEVELS];
   int g[SD_MAX_FPN_LEVELS];          // planes per fill (1 for banded levels)
   int unit_base[SD_MAX_FPN_LEVELS];  // first unit of the level; unit = base + img * nbands + band
-  int wg_end[SD_MAX_FPN_LEVELS];     // exclusive prefix of workgroups over the launch slots
-  int slot_lvl[SD_MAX_FPN_LEVELS];   // level of launch slot i (longest workgroups first)
-  int nslot;
-  int steps[SD_MAX_FPN_LEVELS];      // fills per workgroup
+  int halo[SD_MAX_FPN_LEVELS];       // rows below a band its items may still tap
   int nwg;                           // band workgroups (after the fallback workgroups)
   int nunits;
   int grab;                          // channels a workgroup reserves at a time
@@ -784,8 +781,9 @@ struct BandPlan {
   float2* colval;
   unsigned* items;  // [B][SD_MAX_FPN_LEVELS][kBandSub][ceil(R / kBandSub) * pool]  RoI | p << 16, by band
   int2* seg;        // [unit][kBandSub] {first item of the segment, items}
-  unsigned char* fbflag;  // [B*R] 1: handled by the exact per-element workgroups
+  unsigned char* fbflag;  // [B*R] 1: handled by the exact per-element workgroups, 2: constant output (nothing pooled)
   int* chan_ctr;    // [kBandMaxUnits] next channel of every virtual unit (zeroed by the pre-pass)
+  int nlist, nent;  // pre-pass blocks: lists, entries (then, packed, the coordinate table)
 };
 
 struct BandArgs {
@@ -796,19 +794,19 @@ struct BandArgs {
 // ---- pre-pass ----
 // blocks [0, B * nlvl): item lists of (level, image); then entries; then (packed) the coordinate table
 template <int POOL>
-__global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A, int nlist, int nent) {
+__device__ __forceinline__ void band_prep_block(const BandArgs& A, const int pblock, int nlist, int nent) {
   const FwdArgs& a = A.f;
   const BandPlan& P = A.p;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   constexpr int LPR = POOL <= 8 ? 8 : 16;            // lanes per RoI in the list pass
   constexpr int RPP = kBandThreads / LPR;             // RoIs per pass
-  if ((int)blockIdx.x < nlist) {
+  if (pblock < nlist) {
     // one workgroup per (level, image, quarter of the image's RoIs): every quarter writes its own
     // segment of every band's list, so no workgroup waits for another and a list is the
     // concatenation of kBandSub segments
     __shared__ int hist[kBandMaxBands], cursor[kBandMaxBands];
-    const int sub = blockIdx.x % kBandSub, lvl = (blockIdx.x / kBandSub) % a.L.nlvl;
-    const int img = blockIdx.x / (kBandSub * a.L.nlvl);
+    const int sub = pblock % kBandSub, lvl = (pblock / kBandSub) % a.L.nlvl;
+    const int img = pblock / (kBandSub * a.L.nlvl);
     if (a.L.stride[lvl] < 0) return;
     int first_valid = 0;
     while (a.L.stride[first_valid] < 0) ++first_valid;
@@ -823,7 +821,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A, 
     // band of item (n, p): -1 none (not this level / idle lane), -2 the RoI goes to the exact path
     auto classify = [&](int n) -> int {
       int band = -1;
-      bool bad = false, mine = false;
+      bool bad = false, mine = false, emp_r = true, emp_c = true;
       int lv = -2;
       if (n < rend) {
         const float4 bx = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + n) * 4);
@@ -835,10 +833,12 @@ __global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A, 
           const int cr = axis_samples(p, POOL, bx.y, bx.w, scale, H, 1, val, frac, offr);
           const int cc = axis_samples(p, POOL, bx.x, bx.z, scale, W, 1, val, frac, offc);
           bad = cr >= 3 || cc >= 3;
+          emp_r = cr < 0;
+          emp_c = cc < 0;
           band = 0;
           if (cr >= 1) {
             const int first = offr[0], last = cr >= 2 ? offr[3] : offr[1];
-            if (nb > 1 && last - first > kBandHalo) bad = true;
+            if (nb > 1 && last - first > P.halo[lvl]) bad = true;
             band = first / owned;
           }
         }
@@ -846,10 +846,17 @@ __global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A, 
       // RoI-wide verdict: any bad bin row / column sends the whole RoI to the exact path
       const unsigned long long bm = __ballot(bad);
       const int sh = (lane / LPR) * LPR;
-      const bool roi_bad = ((bm >> sh) & ((1ull << LPR) - 1)) != 0;
+      const unsigned long long rmask = (1ull << LPR) - 1;
+      bool roi_bad = ((bm >> sh) & rmask) != 0;
+      // a RoI that pools nothing anywhere (every bin row or every bin column empty: the zero boxes
+      // fpn_roi_assign hands the per-level ops, padding rows) is constant output: flag 2, the
+      // exact-path workgroups just store it
+      const bool all_r = ((__ballot(!emp_r) >> sh) & rmask) == 0, all_c = ((__ballot(!emp_c) >> sh) & rmask) == 0;
+      const bool roi_void = mine && (all_r || all_c);
+      roi_bad = roi_bad || roi_void;
       if (n < rend && p == 0) {  // (rewritten with the same value when classify runs twice)
-        if (mine) P.fbflag[(long)img * a.R + n] = roi_bad ? 1 : 0;
-        else if (lv < 0 && lvl == first_valid) P.fbflag[(long)img * a.R + n] = 1;
+        if (mine) P.fbflag[(long)img * a.R + n] = roi_void ? 2 : (roi_bad ? 1 : 0);
+        else if (lv < 0 && lvl == first_valid) P.fbflag[(long)img * a.R + n] = 2;
       }
       return roi_bad ? -2 : band;
     };
@@ -903,8 +910,8 @@ __global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A, 
     }
     return;
   }
-  if (blockIdx.x == (unsigned)nlist && tid < kBandMaxUnits) P.chan_ctr[tid] = 0;
-  const int eb = (int)blockIdx.x - nlist;
+  if (pblock == nlist && tid < kBandMaxUnits) P.chan_ctr[tid] = 0;
+  const int eb = pblock - nlist;
   const int nroi = a.B * a.R;
   if (eb < nent) {
     // ---- entries: one thread per (RoI, axis, bin) ----
@@ -954,6 +961,15 @@ __global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A, 
   }
 }
 
+// The pre-pass is its own launch.  (Fusing it into the band kernel -- the first blocks build the
+// tables and publish a per-launch tag, the band workgroups poll for it -- was built and measured:
+// 168-190 us against 100; the agent-scope release / acquire traffic of a few hundred 1024-thread
+// blocks costs far more than the ~10 us of a second launch.)
+template <int POOL>
+__global__ __launch_bounds__(kBandThreads) void roi_fwd_prep_kernel(BandArgs A) {
+  band_prep_block<POOL>(A, (int)blockIdx.x, A.p.nlist, A.p.nent);
+}
+
 // dense copy of `len` floats at gsrc into LDS at buf (+ shift floats: the 16-byte misalignment of
 // gsrc), by global_load_lds_dwordx4 (LDS destination = wave-uniform base + lane * 16).  Returns the
 // shift.  The (at most two) partial 16-byte words at the ends are fetched as single floats.
@@ -991,37 +1007,6 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
   extern __shared__ __attribute__((aligned(16))) float band_smem[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-
-  if ((int)blockIdx.x < kBandFallbackWGs) {
-    // ---- exact per-element path for the few RoIs the bands do not take: the first workgroups of
-    // the launch (they run beside the band workgroups), workgroup = (RoI slot, channel slice) ----
-    const int nroi = a.B * a.R;
-    const int nsl = a.nslice, csl = a.C / nsl, slice = (int)blockIdx.x % nsl;
-    if ((int)blockIdx.x / nsl >= kBandFallbackWGs / nsl) return;
-    for (int n = (int)blockIdx.x / nsl; n < nroi; n += kBandFallbackWGs / nsl) {
-      if (!P.fbflag[n]) continue;
-      const float4 bx = *reinterpret_cast<const float4*>(a.rois + (long)n * 4);
-      const int lvl = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
-      for (int e = tid; e < csl * PPG; e += kBandThreads) {
-        const int c = slice * csl + e / PPG, g = e % PPG;
-        FwdOut o{0.f, -1.f, -1.f, 255};
-        if (lvl >= 0) {
-          const int H = a.L.H[lvl], W = a.L.W[lvl];
-          o = roi_align_fwd_elem(a.L.data[lvl] + ((long)(n / a.R) * a.C + c) * H * W, H, W, bx.x, bx.y,
-                                 bx.z, bx.w, a.L.scale[lvl], g / POOL, g % POOL, POOL, POOL);
-        }
-        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
-        a.out[((long)n * a.C + c) * PPG + g] = o.val;
-        if (PK) {
-          a.amax8[((long)n * a.C + c) * PPSG + g] = (unsigned char)o.code;
-        } else {
-          a.ax[((long)n * a.C + c) * PPG + g] = o.ax;
-          a.ay[((long)n * a.C + c) * PPG + g] = o.ay;
-        }
-      }
-    }
-    return;
-  }
 
   // ---- persistent workgroups, one per CU.  Work = (virtual unit, channel): a virtual unit is a
   // unit's items cut into rounds of CAP (what one workgroup keeps in registers).  A workgroup
@@ -1088,7 +1073,6 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     if (tid == 0) v_start[nvu] = tot;
     __syncthreads();
   }
-  if (nvu == 0) return;
   int vu = 0;
   {
     const long pos = (long)v_start[nvu] * (2 * wg + 1) / (2 * nwg);
@@ -1109,7 +1093,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     return k;  // (valid in thread 0 only)
   };
 
-  for (int visit = 0; visit < kBandMaxVisits; ++visit) {
+  for (int visit = 0; visit < kBandMaxVisits && nvu > 0; ++visit) {
   if (visit) {
     // the unit ran dry: move to the virtual unit with the most estimated work left (if any)
     int left = 0;
@@ -1377,6 +1361,37 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
   }
 #endif
   }  // visits
+  {
+    // ---- exact per-element path for the few RoIs the bands do not take (and the constant output
+    // of the RoIs that pool nothing), after the band work: workgroup = (RoI slot, channel slice).
+    // (As blocks of their own in front of the launch they delayed every band workgroup's start.) ----
+    const int nroi = a.B * a.R;
+    const int nsl = nwg >= a.nslice ? a.nslice : 1, csl = a.C / nsl, slice = wg % nsl;
+    const int nslots = nwg / nsl;
+    for (int n = wg / nsl; n < nroi && wg / nsl < nslots; n += nslots) {
+      const int flag = P.fbflag[n];
+      if (!flag) continue;
+      const float4 bx = *reinterpret_cast<const float4*>(a.rois + (long)n * 4);
+      const int lvl = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
+      for (int e = tid; e < csl * PPG; e += kBandThreads) {
+        const int c = slice * csl + e / PPG, g = e % PPG;
+        FwdOut o{0.f, -1.f, -1.f, 255};
+        if (lvl >= 0 && flag == 1) {
+          const int H = a.L.H[lvl], W = a.L.W[lvl];
+          o = roi_align_fwd_elem(a.L.data[lvl] + ((long)(n / a.R) * a.C + c) * H * W, H, W, bx.x, bx.y,
+                                 bx.z, bx.w, a.L.scale[lvl], g / POOL, g % POOL, POOL, POOL);
+        }
+        if (a.L.nlvl > 1) o.val = o.val + 0.0f;
+        a.out[((long)n * a.C + c) * PPG + g] = o.val;
+        if (PK) {
+          a.amax8[((long)n * a.C + c) * PPSG + g] = (unsigned char)o.code;
+        } else {
+          a.ax[((long)n * a.C + c) * PPG + g] = o.ax;
+          a.ay[((long)n * a.C + c) * PPG + g] = o.ay;
+        }
+      }
+    }
+    }
 #ifdef SD_PROFILING
   if (a.dbg && lane == 0) {
     long long* d = a.dbg + ((long)blockIdx.x * kBandWaves + wave) * 8;
@@ -2668,8 +2683,8 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     BandPlan& P = A.p;
     const int POOL = a.PH;
     bool ok = true;
-    int wg = 0, units = 0;
-    const int want_steps = tuning("roi_align_fwd_steps", 8), gmax = tuning("roi_align_fwd_g", 8);
+    int units = 0;
+    const int gmax = tuning("roi_align_fwd_g", 8);
     int nvalid_lv = 0;
     for (int l = 0; l < a.L.nlvl; ++l) nvalid_lv += a.L.stride[l] >= 0;
     for (int l = 0; l < a.L.nlvl; ++l) {
@@ -2677,52 +2692,44 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       const int H = a.L.H[l], W = a.L.W[l];
       const long HW = (long)H * W;
       if (W > 4095 || HW >= (1 << 20)) { ok = false; break; }
+      // halo: a bin row of a RoI that covers the whole map taps ceil(H / POOL) + 2 rows; small
+      // maps (P3..P5, the C4 map) get a halo that makes every RoI eligible, the finest level
+      // keeps 8 rows (its RoIs are small by the FPN assignment; the rest takes the exact path)
+      int halo = kBandHalo;
+      if (H <= 128) {
+        halo = (H + POOL - 1) / POOL + 2;
+        halo = halo < kBandHalo ? kBandHalo : (halo > 12 ? 12 : halo);
+      }
       // bands: as few as LDS allows, but enough that a unit's expected items (an even share of the
       // image's R * POOL bin rows per level) fit one round of the workgroup
       const int rb = (kBandBufFloats - 8) / W;   // rows one buffer holds
-      if (rb < kBandHalo + 4) { ok = false; break; }
-      int nbn = H <= rb ? 1 : (H + (rb - kBandHalo) - 1) / (rb - kBandHalo);
+      if (rb < halo + 4) { ok = false; break; }
+      int nbn = H <= rb ? 1 : (H + (rb - halo) - 1) / (rb - halo);
       const int cap = kBandNP * kBandWaves * (kWave / POOL);
       const long est = (long)a.R * POOL / (nvalid_lv > 0 ? nvalid_lv : 1);
       const int by_items = (int)((est * 5 + 4L * cap - 1) / (4L * cap));   // est / (0.8 cap)
       if (by_items > nbn && tuning("roi_align_fwd_split", 1)) nbn = by_items;
       if (nbn > H) nbn = H;
-      if (nbn > kBandMaxBands) { ok = false; break; }
+      if (nbn > kBandMaxBands) nbn = kBandMaxBands;   // (more items than that: rounds)
       int owned = (H + nbn - 1) / nbn;
       if (nbn > 1)
-        for (int o = owned; o < owned + 4 && o + kBandHalo <= rb; ++o)
+        for (int o = owned; o < owned + 4 && o + halo <= rb; ++o)
           if (((long)o * W) % 4 == 0) { owned = o; break; }  // 16-byte aligned band starts
+      if (owned + halo > rb) owned = rb - halo;
       nbn = (H + owned - 1) / owned;
+      if (nbn > kBandMaxBands) { ok = false; break; }
       P.nbands[l] = nbn;
+      P.halo[l] = halo;
       P.owned[l] = nbn == 1 ? H : owned;
-      P.rows[l] = nbn == 1 ? H : (owned + kBandHalo < H ? owned + kBandHalo : H);
+      P.rows[l] = nbn == 1 ? H : (owned + halo < H ? owned + halo : H);
       const long bstride = (((long)P.rows[l] * W + 4 + 3) & ~3L);
       int g = 1;
       for (int c = 2; c <= 8 && c <= gmax; c *= 2)
         if (a.C % c == 0 && c * bstride <= kBandBufFloats) g = c;
       if (bstride > kBandBufFloats) { ok = false; break; }
       P.g[l] = g;
-      const int nfill = a.C / g;
-      int st = 1;  // about want_steps channels per workgroup, whatever G is
-      for (int d = 1; d * g <= want_steps && d <= nfill; ++d)
-        if (nfill % d == 0) st = d;
-      P.steps[l] = st;
       P.unit_base[l] = units;
       units += a.B * P.nbands[l];
-      P.slot_lvl[P.nslot++] = l;
-    }
-    // launch order: the longest workgroups first (items per unit ~ 1 / bands, channels = G * steps)
-    for (int i = 0; ok && i < P.nslot; ++i)
-      for (int j = i + 1; j < P.nslot; ++j) {
-        const int li = P.slot_lvl[i], lj = P.slot_lvl[j];
-        const long wi = (long)P.g[li] * P.steps[li] * kBandMaxBands / P.nbands[li];
-        const long wj = (long)P.g[lj] * P.steps[lj] * kBandMaxBands / P.nbands[lj];
-        if (wj > wi) { P.slot_lvl[i] = lj; P.slot_lvl[j] = li; }
-      }
-    for (int i = 0; ok && i < P.nslot; ++i) {
-      const int l = P.slot_lvl[i];
-      wg += a.B * P.nbands[l] * (a.C / (P.g[l] * P.steps[l]));
-      P.wg_end[i] = wg;
     }
     // workspace carve-up
     auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -2732,6 +2739,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
                               POOL * sizeof(unsigned));
     const size_t segb = al16((size_t)units * kBandSub * sizeof(int2));
     const size_t need = 16 + 2 * ent + 2 * valb + itemb + segb + al16(nroi) + kBandMaxUnits * sizeof(int);
+    int wg = 0;
     P.nunits = units;
     P.grab = tuning("roi_align_fwd_grab", 4);
     if (P.grab < 1) P.grab = 1;
@@ -2755,11 +2763,12 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       A.f = a;
       const int nlist = a.B * a.L.nlvl * kBandSub, nent = cdiv((long)nroi * 2 * POOL, kBandThreads);
       const int ncoord = a.amax8 ? cdiv((long)nroi * 6 * POOL, kBandThreads) : 0;
+      P.nlist = nlist; P.nent = nent;
       const int smem = 2 * kBandBufFloats * (int)sizeof(float);
 #define SD_FWD_BAND(POOLV, PK)                                                                    \
   do {                                                                                            \
     hipLaunchKernelGGL((roi_fwd_prep_kernel<POOLV>), dim3(nlist + nent + ncoord), dim3(kBandThreads), 0, \
-                       st, A, nlist, nent);                                                       \
+                       st, A);                                                                    \
     auto k = roi_align_fwd_band<POOLV, PK>;                                                       \
     SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                      smem));                                                      \
@@ -2907,6 +2916,18 @@ extern "C" int sd_roi_align_v2_fwd(const float* data, const float* rois, float* 
                                    float* maxidx_x, float* maxidx_y, int B, int C, int H, int W,
                                    int R, int pooled_h, int pooled_w, float spatial_scale,
                                    void* stream) {
+  return sd_roi_align_v2_fwd_ws(data, rois, out, maxidx_x, maxidx_y, B, C, H, W, R, pooled_h, pooled_w,
+                                spatial_scale, nullptr, 0, stream);
+}
+
+extern "C" size_t sd_roi_align_v2_workspace_bytes(int B, int R) {
+  return sd_fpn_roi_align_workspace_bytes(B, R);
+}
+
+extern "C" int sd_roi_align_v2_fwd_ws(const float* data, const float* rois, float* out,
+                                      float* maxidx_x, float* maxidx_y, int B, int C, int H, int W,
+                                      int R, int pooled_h, int pooled_w, float spatial_scale,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
   SD_REQUIRE(H > 0 && W > 0 && (long)H * W < (1L << 30), "bad feature size %d x %d", H, W);
   SD_REQUIRE(spatial_scale >= 0.f && spatial_scale <= 1.f, "spatial_scale %g outside [0,1]",
@@ -2922,7 +2943,7 @@ extern "C" int sd_roi_align_v2_fwd(const float* data, const float* rois, float* 
   a.L.scale[0] = spatial_scale;
   a.rois = rois; a.out = out; a.ax = maxidx_x; a.ay = maxidx_y;
   a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
-  return launch_fwd(a, (hipStream_t)stream);
+  return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 extern "C" int sd_roi_align_v2_bwd(const float* out_grad, const float* rois, const float* maxidx_x,

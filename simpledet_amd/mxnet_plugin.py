@@ -120,9 +120,11 @@ def _build_ops(mx):
             _wait(data, rois)
             B, C, H, W = data.shape
             R = rois.shape[1]
-            lib().call("sd_roi_align_v2_fwd", _ptr(data), _ptr(rois), _ptr(out_data[0]),
+            wsb = lib().cdll.sd_roi_align_v2_workspace_bytes(B, R)
+            ws = _scratch(data, wsb)
+            lib().call("sd_roi_align_v2_fwd_ws", _ptr(data), _ptr(rois), _ptr(out_data[0]),
                        _ptr(out_data[1]), _ptr(out_data[2]), B, C, H, W, R, self.ph, self.pw,
-                       float(self.scale), None)
+                       float(self.scale), _ptr(ws), ctypes.c_size_t(wsb), None)
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):

@@ -75,8 +75,10 @@ def roi_align_v2_forward(data, rois, pooled_size, spatial_scale):
     out = torch.empty(shape, device=data.device, dtype=torch.float32)
     mx = torch.empty(shape, device=data.device, dtype=torch.float32)
     my = torch.empty(shape, device=data.device, dtype=torch.float32)
-    lib().call("sd_roi_align_v2_fwd", _p(data), _p(rois), _p(out), _p(mx), _p(my), B, C, H, W, R,
-               ph, pw, float(spatial_scale), _stream())
+    wsb = lib().cdll.sd_roi_align_v2_workspace_bytes(B, R)
+    ws = torch.empty(wsb, device=data.device, dtype=torch.uint8)
+    lib().call("sd_roi_align_v2_fwd_ws", _p(data), _p(rois), _p(out), _p(mx), _p(my), B, C, H, W, R,
+               ph, pw, float(spatial_scale), _p(ws), ctypes.c_size_t(wsb), _stream())
     return out, mx, my
 
 

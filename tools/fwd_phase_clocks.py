@@ -18,7 +18,7 @@ rois = torch.from_numpy(synth.random_rois(0, 2, 512)).cuda()
 strides = list(synth.FPN_STRIDES)
 for _ in range(3):
     ops.fpn_roi_align_forward_packed(feats, rois, strides, (7, 7))
-nblk = 512
+nblk = 256
 dbg = torch.zeros(nblk * 16 * 8 + nblk * 4 * 8, dtype=torch.int64, device="cuda")
 p = dbg.data_ptr()
 lo = p & 0xffffffff
@@ -36,6 +36,7 @@ print("workgroups that ran:", used.sum(), " span (ticks) %d" % ((d[used][:, :, 7
 b = d[used]
 print("per wave (ticks): setup %.0f  barrier wait %.0f  compute %.0f  total mean %.0f  min %d  max %d" % (
     b[:, :, 0].mean(), b[:, :, 1].mean(), b[:, :, 2].mean(), b[:, :, 4].mean(), b[:, :, 4].min(), b[:, :, 4].max()))
+
 print("units per workgroup: mean %.2f max %d; items visited per workgroup mean %.0f" % (b[:, 0, 6].mean(), b[:, 0, 6].max(), b[:, 0, 3].mean()))
 tot = b[:, :, 4].max(1)
 print("workgroup total ticks: p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(tot, [10, 50, 90, 100]).astype(int)))
