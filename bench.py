@@ -440,6 +440,33 @@ def main():
             }
         else:
             wd = orc.fpn_roi_align_bwd(dy_np, rois_np, o[1], o[2], fshapes, strides, nthreads=cores)
+        # the reference's OWN compiled CPU forward beside the port: operator_cxx/contrib/roi_align_v2.cc
+        # built where it lies into oracle/_ref/libref_roi_align_v2.so (oracle/build_ref_cxx.py), run as
+        # the graph the reference builds (assign -> 4 x ROIAlign_v2 -> add_n); serial, as the shim's
+        # Kernel::Launch is (MXNet's CPU Launch uses OpenMP: the multi-thread port above stands for that)
+        if cpu_baseline is not None:
+            try:
+                from oracle import refmx
+                if refmx.available("roi_align_v2"):
+                    per, _ = orc.fpn_roi_assign(rois_np, strides)
+                    t0 = time.perf_counter()
+                    ref_out = None
+                    for l, st_ in enumerate(strides):
+                        rop = refmx.RefOp("roi_align_v2", "_contrib_ROIAlign_v2", pooled_size=(7, 7),
+                                          spatial_scale=1.0 / st_)
+                        r_ = rop.forward([feats_np[l], per[l]], ctx="cpu")[0]
+                        ref_out = r_ if ref_out is None else ref_out + r_
+                    t_ref = time.perf_counter() - t0
+                    cpu_baseline["reference"] = {
+                        "value": args.images / t_ref, "unit": "images/s (forward only)", "cores": 1,
+                        "kind": "reference", "ms_forward": t_ref * 1e3,
+                        "sample": "1 pass of the forward graph (fpn_roi_assign -> 4 x ROIAlign_v2 -> add_n, "
+                                  "roi_align_v2-inl.h:157-195) through oracle/_ref/libref_roi_align_v2.so = "
+                                  "the reference's roi_align_v2.cc compiled against oracle/mxshim",
+                        "equals_gpu_forward_bit_for_bit": bool(np.array_equal(ref_out, state["out"].cpu().numpy())),
+                    }
+            except Exception as e:  # the reference library is optional on the GPU box
+                cpu_baseline["reference"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # the GPU results of the LAST TIMED step against the oracle (not timed): forward values bit
         # for bit, gradients elementwise within 1e-4
         fwd_ok = bool(np.array_equal(state["out"].cpu().numpy(), o[0]))
