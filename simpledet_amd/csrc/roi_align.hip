@@ -756,7 +756,7 @@ constexpr int kBandBufFloats = 16896;   // 66 KB per buffer, two buffers per wor
 constexpr int kBandHalo = 8;            // rows below a band that its items may still tap
 constexpr int kBandMaxBands = 16;
 constexpr int kBandNP = 4;              // passes a wave keeps in registers (one round)
-constexpr int kBandMaxVisits = 8;       // virtual units one workgroup works on, at most
+constexpr int kBandMaxVisits = 3;       // virtual units one workgroup works on, at most
 constexpr int kBandMaxUnits = 256;      // (level, image, band) units of one launch
 constexpr int kBandFillCost = 140, kBandPlaneCost = 60, kBandSetupCost = 1500;  // cost model, in item times
 constexpr int kBandSub = 4;             // list segments per unit (pre-pass workgroups per (level, image))
@@ -774,6 +774,7 @@ struct BandPlan {
   int nwg;                           // band workgroups (after the fallback workgroups)
   int nunits;
   int grab;                          // channels a workgroup reserves at a time
+  int gbias;                         // per cent added to the cost estimate of multi-plane units
   int pool;
   uint4* rowent;    // [B*R][pool]  {lo0 | step0 << 20 | empty << 31, lo1 | step1 << 20, a0, a1}
   uint4* colent;    // [B*R][pool]  {left0 | dup0 << 12 | left1 << 13 | dup1 << 25 | empty << 26, -, b0, b1}
@@ -1008,6 +1009,9 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
 
+#ifdef SD_PROFILING
+  const long long t_entry = __builtin_readcyclecounter();
+#endif
   // ---- persistent workgroups, one per CU.  Work = (virtual unit, channel): a virtual unit is a
   // unit's items cut into rounds of CAP (what one workgroup keeps in registers).  A workgroup
   // starts on the virtual unit its share of the estimated cost falls in, takes the unit's
@@ -1015,8 +1019,8 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
   // whatever the estimate was worth), and when the unit runs dry moves to the unit with the most
   // work left ----
   __shared__ int v_unit[kBandMaxUnits], v_first[kBandMaxUnits], v_items[kBandMaxUnits];
-  __shared__ int v_cost[kBandMaxUnits], v_start[kBandMaxUnits + 1], s_wsum[kBandWaves];
-  __shared__ int s_grab[2], s_pick, s_pickval;
+  __shared__ int v_cost[kBandMaxUnits], v_start[kBandMaxUnits + 1];
+  __shared__ int s_grab[2], s_pick;
   const int wg = (int)blockIdx.x - kBandFallbackWGs, nwg = (int)gridDim.x - kBandFallbackWGs;
   const int rsub = (a.R + kBandSub - 1) / kBandSub;
   auto level_of = [&](int u) {
@@ -1025,54 +1029,61 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
       if (a.L.stride[k] >= 0 && u >= P.unit_base[k]) l = k;
     return l;
   };
-  // exclusive block scan (16 waves): returns the prefix of v, the total through *tot
-  auto block_scan = [&](int v, int* tot) {
-    int incl = v;
+  // The table of virtual units and their cost prefix: one wave does it (lane = unit, 64 at a time,
+  // wave scans: no workgroup barriers on the start-up path), the others wait at one barrier.
+  __shared__ int s_nvu;
+  auto wave_incl_scan = [&](int v) {
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
+      const int t = __shfl_up(v, o);
+      if (lane >= o) v += t;
     }
-    __syncthreads();  // (s_wsum may still be read from the previous scan)
-    if (lane == kWave - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    int pre = 0, all = 0;
-    for (int w = 0; w < kBandWaves; ++w) {
-      const int c = s_wsum[w];
-      pre += w < wave ? c : 0;
-      all += c;
-    }
-    *tot = all;
-    return pre + incl - v;
+    return v;
   };
-  int nvu = 0;
-  {
-    int cnt = 0, rounds = 0, lv = 0;
-    if (tid < P.nunits) {
-      lv = level_of(tid);
+  if (wave == 0) {
+    int vbase = 0;
+    for (int u0 = 0; u0 < P.nunits; u0 += kWave) {
+      const int u = u0 + lane;
+      int cnt = 0, rounds = 0, lv = 0;
+      if (u < P.nunits) {
+        lv = level_of(u);
 #pragma unroll
-      for (int j = 0; j < kBandSub; ++j) cnt += P.seg[tid * kBandSub + j].y;
-      rounds = (cnt + CAP - 1) / CAP;
+        for (int j = 0; j < kBandSub; ++j) cnt += P.seg[u * kBandSub + j].y;
+        rounds = (cnt + CAP - 1) / CAP;
+      }
+      const int incl = wave_incl_scan(rounds);
+      const int vb = vbase + incl - rounds;
+      for (int r = 0; r < rounds && vb + r < kBandMaxUnits; ++r) {
+        const int it = cnt - r * CAP < CAP ? cnt - r * CAP : CAP;
+        v_unit[vb + r] = u;
+        v_first[vb + r] = r * CAP;
+        v_items[vb + r] = it;
+        // measured (profiles/r03_fwd_cost_model.txt): a fill takes ~ F0 + G * (F1 + k * items) ticks,
+        // linear in the items (the waves of a SIMD share the LDS and VALU rate); per channel, in units of k:
+        // (units whose fills hold several planes hand work out in coarser pieces: they get a larger
+        // share of the workgroups, finish early and their workgroups then join the fine-grained units)
+        const int cst = kBandFillCost / P.g[lv] + kBandPlaneCost + it;
+        v_cost[vb + r] = P.g[lv] > 1 ? cst + cst * P.gbias / 100 : cst;
+      }
+      vbase += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
-    const int vb = block_scan(rounds, &nvu);
-    if (nvu > kBandMaxUnits) nvu = kBandMaxUnits;  // (the launcher keeps the rounds of a level small)
-    for (int r = 0; r < rounds && vb + r < kBandMaxUnits; ++r) {
-      const int it = cnt - r * CAP < CAP ? cnt - r * CAP : CAP;
-      v_unit[vb + r] = tid;
-      v_first[vb + r] = r * CAP;
-      v_items[vb + r] = it;
-      // measured (profiles/r03_fwd_cost_model.txt): a fill takes ~ F0 + G * (F1 + k * items) ticks,
-      // linear in the items (the waves of a SIMD share the LDS and VALU rate); per channel, in units of k:
-      v_cost[vb + r] = kBandFillCost / P.g[lv] + kBandPlaneCost + it;
+    const int n = vbase < kBandMaxUnits ? vbase : kBandMaxUnits;  // (the launcher keeps a level's rounds few)
+    wave_lds_sync();
+    int run = 0;
+    for (int v0 = 0; v0 < n; v0 += kWave) {
+      const int v = v0 + lane;
+      const int mine = v < n ? kBandSetupCost + v_cost[v] * a.C : 0;
+      const int incl = wave_incl_scan(mine);
+      if (v < n) v_start[v] = run + incl - mine;
+      run += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
-    __syncthreads();
-    int tot = 0;
-    const int mine = tid < nvu ? kBandSetupCost + v_cost[tid] * a.C : 0;
-    const int pre = block_scan(mine, &tot);
-    if (tid < nvu) v_start[tid] = pre;
-    if (tid == 0) v_start[nvu] = tot;
-    __syncthreads();
+    if (lane == 0) {
+      v_start[n] = run;
+      s_nvu = n;
+    }
   }
+  __syncthreads();
+  const int nvu = s_nvu;
   int vu = 0;
   {
     const long pos = (long)v_start[nvu] * (2 * wg + 1) / (2 * nwg);
@@ -1095,18 +1106,31 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
 
   for (int visit = 0; visit < kBandMaxVisits && nvu > 0; ++visit) {
   if (visit) {
-    // the unit ran dry: move to the virtual unit with the most estimated work left (if any)
-    int left = 0;
-    if (tid < nvu) {
-      const int done = P.chan_ctr[tid];
-      // (joining costs a set-up: only worth it for a few fills)
-      left = a.C - done >= 3 * P.g[level_of(v_unit[tid])] ? (a.C - done) * v_cost[tid] : 0;
+    // the unit ran dry: move to the virtual unit with the most estimated work left (if any);
+    // one wave looks (fresh counter values), one barrier
+    if (wave == 0) {
+      int best = -1, bestval = 0;
+      for (int v0 = 0; v0 < nvu; v0 += kWave) {
+        const int v = v0 + lane;
+        int left = 0;
+        if (v < nvu) {
+          const int done = __hip_atomic_load(&P.chan_ctr[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (joining costs a set-up: only worth it for a few fills)
+          left = a.C - done >= 3 * P.g[level_of(v_unit[v])] ? (a.C - done) * v_cost[v] : 0;
+        }
+        int m = left;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          const int t = __shfl_xor(m, o);
+          m = t > m ? t : m;
+        }
+        if (m > bestval) {
+          bestval = m;
+          best = v0 + __builtin_ctzll(__ballot(left == m));
+        }
+      }
+      if (lane == 0) s_pick = best;
     }
-    if (tid == 0) { s_pick = -1; s_pickval = 0; }
-    __syncthreads();
-    if (left > 0) atomicMax(&s_pickval, left);
-    __syncthreads();
-    if (left > 0 && left == s_pickval) s_pick = tid;  // (any of the equals)
     __syncthreads();
     vu = s_pick;
     if (vu < 0) break;
@@ -1368,9 +1392,17 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     const int nroi = a.B * a.R;
     const int nsl = nwg >= a.nslice ? a.nslice : 1, csl = a.C / nsl, slice = wg % nsl;
     const int nslots = nwg / nsl;
-    for (int n = wg / nsl; n < nroi && wg / nsl < nslots; n += nslots) {
-      const int flag = P.fbflag[n];
-      if (!flag) continue;
+    // the flags of this workgroup's RoIs are fetched 64 at a time by every wave (one load each,
+    // not a chain of dependent loads), then only the flagged ones are visited
+    for (int n0 = wg / nsl; n0 < nroi && wg / nsl < nslots; n0 += nslots * kWave) {
+      const int nl = n0 + lane * nslots;
+      const int myflag = nl < nroi ? P.fbflag[nl] : 0;
+      unsigned long long todo = __ballot(myflag != 0);
+      while (todo) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int n = n0 + src * nslots;
+      const int flag = __builtin_amdgcn_readlane(myflag, src);
       const float4 bx = *reinterpret_cast<const float4*>(a.rois + (long)n * 4);
       const int lvl = a.L.nlvl > 1 ? fpn_level(bx.x, bx.y, bx.z, bx.w, a.L) : 0;
       for (int e = tid; e < csl * PPG; e += kBandThreads) {
@@ -1390,13 +1422,14 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
           a.ay[((long)n * a.C + c) * PPG + g] = o.ay;
         }
       }
+      }  // flagged RoIs
     }
     }
 #ifdef SD_PROFILING
   if (a.dbg && lane == 0) {
     long long* d = a.dbg + ((long)blockIdx.x * kBandWaves + wave) * 8;
     d[0] = t_setup; d[1] = t_wait; d[2] = t_comp; d[3] = dbg_count;
-    d[4] = __builtin_readcyclecounter() - t_begin; d[5] = 0; d[6] = dbg_units; d[7] = t_begin;
+    d[4] = __builtin_readcyclecounter() - t_begin; d[5] = t_begin - t_entry; d[6] = dbg_units; d[7] = t_begin;
   }
 #endif
 }
@@ -2742,6 +2775,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     int wg = 0;
     P.nunits = units;
     P.grab = tuning("roi_align_fwd_grab", 4);
+    P.gbias = tuning("roi_align_fwd_gbias", 0);
     if (P.grab < 1) P.grab = 1;
     if (units > kBandMaxUnits) ok = false;
     wg = tuning("roi_align_fwd_wgs", kNumCU);  // persistent workgroups, one per CU

@@ -37,6 +37,8 @@ b = d[used]
 print("per wave (ticks): setup %.0f  barrier wait %.0f  compute %.0f  total mean %.0f  min %d  max %d" % (
     b[:, :, 0].mean(), b[:, :, 1].mean(), b[:, :, 2].mean(), b[:, :, 4].mean(), b[:, :, 4].min(), b[:, :, 4].max()))
 
+print("partition before the first visit (ticks): mean %.0f max %d;  outside the visits: mean %.0f" % (
+    b[:, 0, 5].mean(), b[:, 0, 5].max(), (b[:, :, 4].max(1) - (b[:, 0, 0] + b[:, 0, 1] + b[:, 0, 2])).mean()))
 print("units per workgroup: mean %.2f max %d; items visited per workgroup mean %.0f" % (b[:, 0, 6].mean(), b[:, 0, 6].max(), b[:, 0, 3].mean()))
 tot = b[:, :, 4].max(1)
 print("workgroup total ticks: p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(tot, [10, 50, 90, 100]).astype(int)))
