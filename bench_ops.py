@@ -252,6 +252,25 @@ def run(seed=0, cpu=True, only=None):
                                   "fwd_frac": alg / ms_f / 1e6 / PEAK_HBM_GBS,
                                   "bwd_frac": alg / ms_b / 1e6 / PEAK_HBM_GBS,
                                   "config": "P2-P5 256ch 800x1333, N=2, 128 RoIs/img, 14x14, packed arg-max"}
+        # the same extractor with fp16 feature maps and fp16 output (BASELINE configs[4] "14x14 mask
+        # RoIAlign fp16"): its own algorithmic bytes = fp16 maps + rois + fp16 output + packed arg-max
+        # for the forward; the backward here = to_fp32, the fp32 kernel, to_fp16 (the casts counted)
+        feats16 = [f.half() for f in feats]
+        o16, am16 = ops.fpn_roi_align_forward_packed_f16(feats16, r14, strides4, (14, 14))
+        dy16 = dy14.half()
+        grads16 = [torch.empty_like(f) for f in feats16]
+        ms_f16 = _time_gpu(lambda: ops.fpn_roi_align_forward_packed_f16(feats16, r14, strides4, (14, 14)))
+        ms_b16 = _time_gpu(lambda: ops.fpn_roi_align_backward_packed_f16(dy16, r14, am16, shapes, strides4,
+                                                                        d_feats=grads16))
+        alg16 = sum(2 * f.numel() for f in feats) + 16 * r14.shape[0] * r14.shape[1] + 2 * o16.numel() + am16[0].numel()
+        res["roi_align_14x14_fp16"] = {"fwd_ms": ms_f16, "bwd_ms": ms_b16, "algorithmic_bytes_fwd": alg16,
+                                       "fwd_frac": alg16 / ms_f16 / 1e6 / PEAK_HBM_GBS,
+                                       "fwd_speedup_vs_fp32_io": ms_f / ms_f16,
+                                       "matches_fp32_path": bool(torch.equal(o16, ops.fpn_roi_align_forward_packed(
+                                           [f.float() for f in feats16], r14, strides4, (14, 14))[0].half())),
+                                       "config": "P2-P5 256ch fp16 maps, N=2, 128 RoIs/img, 14x14, fp16 output, "
+                                                 "packed arg-max; backward = casts around the fp32 kernel"}
+        del feats16, o16, am16, dy16, grads16
         if orc:
             w14 = orc.fpn_roi_align_fwd([N_(f) for f in feats], N_(r14), strides4, (14, 14), nthreads=16)
             res["roi_align_14x14"]["matches_oracle"] = same(o14, w14[0])

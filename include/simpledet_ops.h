@@ -68,6 +68,12 @@ int sd_stream_synchronize(void* stream);
  * the 8 TB/s spec peak and to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count */
 int sd_hbm_stream_copy(const void* src, void* dst, size_t bytes, int width_bytes, void* stream);
 
+/* fp16 <-> fp32 streaming casts (X.to_fp32 / X.to_fp16 of the reference's fp16 graphs, where an op
+ * boundary still needs them: the fp16 form of the RoIAlign backward).  n elements; dst of the
+ * second honours req (write / add, the sum formed in fp32).  16-byte aligned buffers for the first. */
+int sd_cast_f16_to_f32(const void* src, float* dst, size_t n, void* stream);
+int sd_cast_f32_to_f16(const float* src, void* dst, size_t n, int req, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ROIAlign_v2  (mx.sym.contrib.ROIAlign_v2, registered as _contrib_ROIAlign_v2)
  *   replaces ROIAlignForward_v2<gpu>  operator_cxx/contrib/roi_align_v2-inl.h:157-195
@@ -140,6 +146,18 @@ int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_ho
                                 int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
                                 float roi_canonical_level, void* workspace, size_t workspace_bytes,
                                 void* stream);
+/* fp16 I/O variant for fp16 graphs (the reference casts to fp32 around the op, models/FPN/builder.py:
+ * 581-586, 607-608): feats are fp16 (B,C,H,W), out is fp16 (B,R,C,ph,pw); the arithmetic is the fp32
+ * arithmetic of the op above (taps converted exactly, the maximum rounded to nearest even), i.e.
+ * bit-equal to to_fp32 -> sd_fpn_roi_align_fwd_packed -> to_fp16 without the two cast passes and with
+ * half the feature traffic.  argmax / coords / workspace as above; the workspace is REQUIRED (the fp16
+ * path exists on the band-resident kernel only), feats must be 16-byte aligned. */
+int sd_fpn_roi_align_fwd_packed_f16(const void* const* feats_host, const int* Hs_host,
+                                    const int* Ws_host, const int* strides_host, int nlvl,
+                                    const float* rois, void* out, uint8_t* argmax, float* coords, int B,
+                                    int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
+                                    float roi_canonical_level, void* workspace, size_t workspace_bytes,
+                                    void* stream);
 int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const uint8_t* argmax,
                                 const float* coords, float* const* d_feats_host, const int* Hs_host, const int* Ws_host,
                                 const int* strides_host, int nlvl, int req_data, int B, int C, int R,

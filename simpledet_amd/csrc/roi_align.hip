@@ -24,6 +24,7 @@
 #include <float.h>
 #include <math.h>
 #include <type_traits>
+#include <hip/hip_fp16.h>
 
 namespace sd {
 
@@ -58,7 +59,8 @@ struct FwdOut {
   int code;  // packed arg-max: row sample * 3 + column sample, 255 = none
 };
 
-__device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ plane, int height,
+template <typename TP = float>
+__device__ __forceinline__ FwdOut roi_align_fwd_elem(const TP* __restrict__ plane, int height,
                                                      int width, float x1, float y1, float x2,
                                                      float y2, float spatial_scale, int ph, int pw,
                                                      int pooled_height, int pooled_width) {
@@ -97,10 +99,10 @@ __device__ __forceinline__ FwdOut roi_align_fwd_elem(const float* __restrict__ p
         int wleft = iminr(imaxr((int)floorf(w), 0), width - 1);
         int wright = iminr(imaxr((int)ceilf(w), 0), width - 1);
         float beta = (wleft == wright) ? 0.5f : (w - (float)wleft) / (float)(wright - wleft);
-        float value = (1 - alpha) * (1 - beta) * plane[hlow * width + wleft] +
-                      alpha * (1 - beta) * plane[hhigh * width + wleft] +
-                      (1 - alpha) * beta * plane[hlow * width + wright] +
-                      alpha * beta * plane[hhigh * width + wright];
+        float value = (1 - alpha) * (1 - beta) * (float)plane[hlow * width + wleft] +
+                      alpha * (1 - beta) * (float)plane[hhigh * width + wleft] +
+                      (1 - alpha) * beta * (float)plane[hlow * width + wright] +
+                      alpha * beta * (float)plane[hhigh * width + wright];
         if (value > o.val) {
           o.val = value;
           o.ax = w;
@@ -140,6 +142,7 @@ struct FwdArgs {
   const int* order;  // optional locality order of the RoIs (a permutation of [0, B*R)), or null
   int ablate;  // profiling only: 1 stop after the tables
   long long* dbg;                     // profiling build only: per-wave phase clocks (or null)
+  int half_io;                        // 1: the feature maps and `out` are fp16 (band kernel only)
 };
 
 __global__ __launch_bounds__(256) void roi_align_fwd_naive(FwdArgs a) {
@@ -997,13 +1000,20 @@ __device__ __forceinline__ int band_fill(const float* gsrc, int len, float* buf,
   return shift;
 }
 
-template <int POOL, bool PK>
+// HALF: the feature maps and the output are fp16 (the arithmetic stays fp32: the taps are converted
+// on their way into LDS, the maximum is rounded to nearest even on the way out) -- what an fp16 graph
+// gets from X.to_fp32 -> ROIAlign -> X.to_fp16 (models/FPN/builder.py:581-586, 607-608) without the
+// two cast passes, and with half the feature traffic.
+template <int POOL, bool PK, bool HALF = false>
 __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
+  using TIn = typename std::conditional<HALF, __half, float>::type;
+  constexpr int AL = HALF ? 8 : 4;   // elements per 16 bytes of the input
   const FwdArgs& a = A.f;
   const BandPlan& P = A.p;
   constexpr int QL = POOL, IPP = kWave / QL;             // lanes per item, items per pass
-  // passes per wave and round (the float arg-max form carries four sample coordinates more per pass)
-  constexpr int NP = PK ? kBandNP : kBandNP - 1, CAP = NP * kBandWaves * IPP;
+  // passes per wave and round (the float arg-max form carries four sample coordinates more per
+  // pass, the fp16 form twelve staging registers)
+  constexpr int NP = (PK && !HALF) ? kBandNP : kBandNP - 1, CAP = NP * kBandWaves * IPP;
   constexpr int PPG = POOL * POOL, PPSG = amax_stride(PPG);
   extern __shared__ __attribute__((aligned(16))) float band_smem[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -1156,7 +1166,8 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
   const int r0 = band * P.owned[lvl];
   const int nrows = H - r0 < P.rows[lvl] ? H - r0 : P.rows[lvl];
   const int blen = nrows * W;                            // floats of one plane's band
-  const int bstride = (blen + 4 + 3) & ~3;               // LDS floats between the G planes of a fill
+  // LDS floats between the G planes of a fill (fp16: whole 8-element words, whatever the misalignment)
+  const int bstride = HALF ? ((blen + 14) >> 3) * 8 : (blen + 4 + 3) & ~3;
   // the unit's list = kBandSub segments, one per quarter of the image's RoIs
   const unsigned* items = P.items + ((long)img * SD_MAX_FPN_LEVELS + lvl) * kBandSub * rsub * POOL;
   int sgs[kBandSub], sgc[kBandSub], count = 0;
@@ -1178,16 +1189,62 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     d[0] = lvl; d[2] = nitems; d[3] = t_mark; d[4] = 1;
   }
 #endif
-  const float* gbase = a.L.data[lvl] + (long)img * a.C * HW + (long)r0 * W;  // channel 0 of the band
+  const TIn* gbase = reinterpret_cast<const TIn*>(a.L.data[lvl]) + (long)img * a.C * HW + (long)r0 * W;  // channel 0 of the band
   {
     // one fill = the band rows of G consecutive planes; plane g lands at g * bstride (+ its shift)
-    auto fill = [&](const float* src, float* dst, int gcount) {
-      int sh0 = 0;
-      for (int g = 0; g < gcount; ++g) {
-        const int sh = band_fill(src + (long)g * HW, blen, dst + g * bstride, wave, lane);
-        if (g == 0) sh0 = sh;
+    // fp32: straight into LDS (global_load_lds).  fp16: 16-byte words into registers when the fill
+    // is issued, converted and stored to LDS after the step's arithmetic (fill_commit).
+    constexpr int NST = HALF ? 3 : 1;   // staged 16-byte words per thread (<= kBandBufFloats / 8 / 1024 + 1)
+    uint4 st[NST];
+    const int n8u = (blen + 7 + 7) >> 3;  // words per plane at most (any misalignment)
+    auto fill = [&](const TIn* src, float* dst, int gcount) {
+      if constexpr (!HALF) {
+        int sh0 = 0;
+        for (int g = 0; g < gcount; ++g) {
+          const int sh = band_fill(src + (long)g * HW, blen, dst + g * bstride, wave, lane);
+          if (g == 0) sh0 = sh;
+        }
+        return sh0;
+      } else {
+        const int sh0 = (int)(((uintptr_t)src >> 1) & 7);
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+          const int f = tid + k * kBandThreads, g = f / n8u, i = f - g * n8u;
+          st[k] = make_uint4(0, 0, 0, 0);
+          if (g < gcount) {
+            const __half* sp = src + (long)g * HW;
+            const int sh = (int)(((uintptr_t)sp >> 1) & 7);
+            const int e0 = 8 * i - sh;                 // band element of the word's first half
+            if (e0 >= 0 && e0 + 8 <= blen) {
+              st[k] = *reinterpret_cast<const uint4*>(sp + e0);
+            } else if (e0 + 8 > 0 && e0 < blen) {      // a word that sticks out of the band: by halves
+              unsigned short h[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                h[j] = (e0 + j >= 0 && e0 + j < blen) ? reinterpret_cast<const unsigned short*>(sp)[e0 + j] : 0;
+              st[k] = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16,
+                                 h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
+            }
+          }
+        }
+        return sh0;
       }
-      return sh0;
+    };
+    auto fill_commit = [&](float* dst, int gcount) {
+      if constexpr (HALF) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+          const int f = tid + k * kBandThreads, g = f / n8u, i = f - g * n8u;
+          if (g < gcount) {
+            const __half2* hp = reinterpret_cast<const __half2*>(&st[k]);
+            const float2 p0 = __half22float2(hp[0]), p1 = __half22float2(hp[1]);
+            const float2 p2 = __half22float2(hp[2]), p3 = __half22float2(hp[3]);
+            float4* d = reinterpret_cast<float4*>(dst + g * bstride + 8 * i);
+            d[0] = make_float4(p0.x, p0.y, p1.x, p1.y);
+            d[1] = make_float4(p2.x, p2.y, p3.x, p3.y);
+          }
+        }
+      }
     };
     // ---- per-pass state, in registers across the channel loop.  The table loads go out before
     // the first fill (loads return in order: behind the fill they would wait for all of it), the
@@ -1226,6 +1283,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
       }
     }
     int shift_next = fill(gbase + (long)kcur * HW, buf0, a.C - kcur < G ? a.C - kcur : G);
+    fill_commit(buf0, a.C - kcur < G ? a.C - kcur : G);   // (fp16: the first fill is not hidden)
     if (tid == 0) s_grab[1] = grab(vu, GR);  // the reservation after this one (read past the next barrier)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -1321,7 +1379,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
         unsigned ao = aoff[i] + (unsigned)(kcur * PPSG);
         for (int g = 0; g < gcount; ++g) {
           // plane g of the fill; its 16-byte misalignment follows from plane 0's (HW floats apart)
-          const char* pl = base + ((long)g * bstride + ((shift + g * (HW & 3)) & 3)) * 4;
+          const char* pl = base + ((long)g * bstride + ((shift + g * (HW & (AL - 1))) & (AL - 1))) * 4;
           auto rd = [&](int off) {
             const F2u t = *reinterpret_cast<const F2u*>(pl + off);
             return v2f{t.x, t.y};
@@ -1350,7 +1408,8 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
           if (value > maxval) { maxval = value; bk = 4; if (!PK) { bx_ = cx1[i]; by_ = cy1[i]; } }
           if (a.L.nlvl > 1) maxval = maxval + 0.0f;
           if (flags[i] & 1) {
-            a.out[oo] = maxval;
+            if constexpr (HALF) reinterpret_cast<__half*>(a.out)[oo] = __float2half(maxval);
+            else a.out[oo] = maxval;
             if (PK) {
               a.amax8[ao] = (unsigned char)bk;
             } else {
@@ -1365,6 +1424,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
 #ifdef SD_PROFILING
       ++dbg_fills;
 #endif
+      if (knext < a.C) fill_commit((s & 1) ? buf0 : buf1, a.C - knext < G ? a.C - knext : G);
       if (tid == 0 && regrab) s_grab[slot] = grabbed;
       kcur = knext;
       if (kcur >= a.C) break;  // (uniform) the unit has no fill left for this workgroup
@@ -1410,11 +1470,12 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
         FwdOut o{0.f, -1.f, -1.f, 255};
         if (lvl >= 0 && flag == 1) {
           const int H = a.L.H[lvl], W = a.L.W[lvl];
-          o = roi_align_fwd_elem(a.L.data[lvl] + ((long)(n / a.R) * a.C + c) * H * W, H, W, bx.x, bx.y,
-                                 bx.z, bx.w, a.L.scale[lvl], g / POOL, g % POOL, POOL, POOL);
+          o = roi_align_fwd_elem(reinterpret_cast<const TIn*>(a.L.data[lvl]) + ((long)(n / a.R) * a.C + c) * H * W,
+                                 H, W, bx.x, bx.y, bx.z, bx.w, a.L.scale[lvl], g / POOL, g % POOL, POOL, POOL);
         }
         if (a.L.nlvl > 1) o.val = o.val + 0.0f;
-        a.out[((long)n * a.C + c) * PPG + g] = o.val;
+        if constexpr (HALF) reinterpret_cast<__half*>(a.out)[((long)n * a.C + c) * PPG + g] = __float2half(o.val);
+        else a.out[((long)n * a.C + c) * PPG + g] = o.val;
         if (PK) {
           a.amax8[((long)n * a.C + c) * PPSG + g] = (unsigned char)o.code;
         } else {
@@ -2735,7 +2796,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       }
       // bands: as few as LDS allows, but enough that a unit's expected items (an even share of the
       // image's R * POOL bin rows per level) fit one round of the workgroup
-      const int rb = (kBandBufFloats - 8) / W;   // rows one buffer holds
+      const int rb = (kBandBufFloats - 16) / W;  // rows one buffer holds
       if (rb < halo + 4) { ok = false; break; }
       int nbn = H <= rb ? 1 : (H + (rb - halo) - 1) / (rb - halo);
       const int cap = kBandNP * kBandWaves * (kWave / POOL);
@@ -2755,7 +2816,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       P.halo[l] = halo;
       P.owned[l] = nbn == 1 ? H : owned;
       P.rows[l] = nbn == 1 ? H : (owned + halo < H ? owned + halo : H);
-      const long bstride = (((long)P.rows[l] * W + 4 + 3) & ~3L);
+      const long bstride = a.half_io ? (((long)P.rows[l] * W + 14) >> 3) * 8 : (((long)P.rows[l] * W + 4 + 3) & ~3L);
       int g = 1;
       for (int c = 2; c <= 8 && c <= gmax; c *= 2)
         if (a.C % c == 0 && c * bstride <= kBandBufFloats) g = c;
@@ -2808,7 +2869,19 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
                                      smem));                                                      \
     hipLaunchKernelGGL(k, dim3(wg + kBandFallbackWGs), dim3(kBandThreads), smem, st, A);          \
   } while (0)
-      if (POOL == 7) {
+      if (a.half_io) {  // fp16 features and output, packed arg-max
+#define SD_FWD_BAND_H(POOLV)                                                                      \
+  do {                                                                                            \
+    hipLaunchKernelGGL((roi_fwd_prep_kernel<POOLV>), dim3(nlist + nent + ncoord), dim3(kBandThreads), 0, \
+                       st, A);                                                                    \
+    auto k = roi_align_fwd_band<POOLV, true, true>;                                               \
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                     smem));                                                      \
+    hipLaunchKernelGGL(k, dim3(wg + kBandFallbackWGs), dim3(kBandThreads), smem, st, A);          \
+  } while (0)
+        if (POOL == 7) SD_FWD_BAND_H(7); else SD_FWD_BAND_H(14);
+#undef SD_FWD_BAND_H
+      } else if (POOL == 7) {
         if (a.amax8) SD_FWD_BAND(7, true); else SD_FWD_BAND(7, false);
       } else {
         if (a.amax8) SD_FWD_BAND(14, true); else SD_FWD_BAND(14, false);
@@ -2818,6 +2891,9 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       return SD_OK;
     }
   }
+  if (a.half_io)
+    return fail(SD_ERR_UNSUPPORTED, "fp16 RoIAlign runs on the band-resident kernel only: it needs the workspace, "
+                "7x7 or 14x14 pooling, W in [2, 4095] and roi_align_fwd = 1, roi_align_fwd_band = 1");
   if (variant == 1 && a.amax8 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
     // packed arg-max (the fused op): the 64-VGPR build, four workgroups per CU
     hipLaunchKernelGGL((roi_align_fwd_tiled_lean<2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
@@ -3070,6 +3146,33 @@ extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const
   if (nlvl == 1) a.L.nlvl = 2, a.L.stride[1] = -1;
   a.rois = rois; a.out = out; a.amax8 = argmax; a.coords = coords;
   a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
+  return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+extern "C" int sd_fpn_roi_align_fwd_packed_f16(const void* const* feats_host, const int* Hs_host,
+                                               const int* Ws_host, const int* strides_host, int nlvl,
+                                               const float* rois, void* out, uint8_t* argmax,
+                                               float* coords, int B, int C, int R, int pooled_h,
+                                               int pooled_w, float roi_canonical_scale,
+                                               float roi_canonical_level, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
+  SD_REQUIRE(feats_host && Hs_host && Ws_host && strides_host, "null level description");
+  SD_REQUIRE((argmax && coords && out) || (long)B * R * C == 0, "out / argmax / coords is null");
+  SD_REQUIRE(((uintptr_t)argmax & 3) == 0 && ((uintptr_t)coords & 7) == 0 && ((uintptr_t)out & 1) == 0,
+             "argmax must be 4-byte, coords 8-byte and out 2-byte aligned");
+  FwdArgs a{};
+  if (int e = fill_levels(a.L, reinterpret_cast<const float* const*>(feats_host), Hs_host, Ws_host,
+                          strides_host, nlvl, roi_canonical_scale, roi_canonical_level))
+    return e;
+  for (int l = 0; l < nlvl; ++l) {
+    SD_REQUIRE(feats_host[l] || (long)B * C == 0, "feats[%d] null", l);
+    SD_REQUIRE(((uintptr_t)feats_host[l] & 15) == 0, "feats[%d] must be 16-byte aligned", l);
+  }
+  if (nlvl == 1) a.L.nlvl = 2, a.L.stride[1] = -1;
+  a.rois = rois; a.out = reinterpret_cast<float*>(out); a.amax8 = argmax; a.coords = coords;
+  a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
+  a.half_io = 1;
   return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 

@@ -3,6 +3,7 @@
 #include "../../include/simpledet_ops.h"
 #include <atomic>
 #include <string.h>
+#include <hip/hip_fp16.h>
 
 namespace sd {
 
@@ -104,6 +105,48 @@ extern "C" int sd_hbm_stream_copy(const void* src, void* dst, size_t bytes, int 
     sd::hbm_stream_copy<float2><<<grid, 256, 0, st>>>((const float2*)src, (float2*)dst, n);
   else
     sd::hbm_stream_copy<float><<<grid, 256, 0, st>>>((const float*)src, (float*)dst, n);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+namespace sd {
+// fp16 <-> fp32 streaming casts: the op-boundary casts of the fp16 RoIAlign backward (the backward
+// kernel accumulates and writes fp32; its fp16 form wraps it in these two passes)
+__global__ __launch_bounds__(256) void cast_h2f_kernel(const __half* __restrict__ src, float* __restrict__ dst, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+  for (; i + 8 <= n; i += stride) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+    const __half2* h = reinterpret_cast<const __half2*>(&v);
+    const float2 a = __half22float2(h[0]), b = __half22float2(h[1]), c = __half22float2(h[2]), d = __half22float2(h[3]);
+    reinterpret_cast<float4*>(dst + i)[0] = make_float4(a.x, a.y, b.x, b.y);
+    reinterpret_cast<float4*>(dst + i)[1] = make_float4(c.x, c.y, d.x, d.y);
+  }
+  if (i < n && i + 8 > n)
+    for (size_t j = i; j < n; ++j) dst[j] = __half2float(src[j]);
+}
+__global__ __launch_bounds__(256) void cast_f2h_kernel(const float* __restrict__ src, __half* __restrict__ dst, size_t n, int add) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride)
+    dst[i] = __float2half(add ? __half2float(dst[i]) + src[i] : src[i]);
+}
+}  // namespace sd
+
+extern "C" int sd_cast_f16_to_f32(const void* src, float* dst, size_t n, void* stream) {
+  if (n == 0) return SD_OK;
+  SD_REQUIRE(src && dst, "null buffer");
+  SD_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "buffers must be 16-byte aligned");
+  sd::cast_h2f_kernel<<<sd::kNumCU * 8, 256, 0, (hipStream_t)stream>>>((const __half*)src, dst, n);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+extern "C" int sd_cast_f32_to_f16(const float* src, void* dst, size_t n, int req, void* stream) {
+  if (n == 0 || req == SD_REQ_NULL) return SD_OK;
+  SD_REQUIRE(src && dst, "null buffer");
+  SD_REQUIRE(req == SD_REQ_WRITE || req == SD_REQ_ADD, "req must be write or add");
+  sd::cast_f2h_kernel<<<sd::kNumCU * 8, 256, 0, (hipStream_t)stream>>>(src, (__half*)dst, n, req == SD_REQ_ADD);
   SD_LAUNCH_CHECK();
   return SD_OK;
 }

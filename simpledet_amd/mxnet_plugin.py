@@ -674,10 +674,11 @@ def _build_ops(mx):
         one-byte arg-max + the per-RoI coordinate / tap table (sd_fpn_roi_align_fwd_packed);
         other sizes: the reference's two fp32 arg-max planes."""
 
-        def __init__(self, strides, pooled, scale0, lvl0):
+        def __init__(self, strides, pooled, scale0, lvl0, fp16=False):
             super().__init__()
             self.strides, self.pooled, self.scale0, self.lvl0 = strides, pooled, scale0, lvl0
             self.packed = _fpn_packed(pooled)
+            self.fp16 = fp16  # fp16 feature maps in, fp16 output out (packed pooling sizes only)
 
         def _levels(self, feats):
             ptrs = (ctypes.c_void_p * len(feats))(*[_ptr(f).value for f in feats])
@@ -691,7 +692,8 @@ def _build_ops(mx):
             ptrs, Hs, Ws = self._levels(feats)
             wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, rois.shape[1])
             ws = _scratch(rois, wsb)
-            lib().call("sd_fpn_roi_align_fwd_packed" if self.packed else "sd_fpn_roi_align_fwd", ptrs,
+            fn = "sd_fpn_roi_align_fwd_packed" if self.packed else "sd_fpn_roi_align_fwd"
+            lib().call(fn + "_f16" if self.fp16 else fn, ptrs,
                        Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois), _ptr(out_data[0]),
                        _ptr(out_data[1]), _ptr(out_data[2]), B, C, rois.shape[1], self.pooled[0],
                        self.pooled[1], float(self.scale0), float(self.lvl0), _ptr(ws),
@@ -705,7 +707,20 @@ def _build_ops(mx):
             if len(rq) != 1:
                 raise RuntimeError("fpn_roi_align: all feature gradients must share one req")
             B, C = feats[0].shape[:2]
+            req_data = rq.pop()
+            og, grads16 = out_grad[0], None
+            if self.fp16:
+                # the sums are formed by the fp32 kernel: the graph's to_fp32 / to_fp16 casts
+                # (models/FPN/builder.py:581-586, 607-608) happen here, at the op boundary
+                og = _scratch(rois, out_grad[0].size * 4).reshape(out_grad[0].shape)
+                lib().call("sd_cast_f16_to_f32", _ptr(out_grad[0]), _ptr(og), ctypes.c_size_t(out_grad[0].size), None)
+                grads16 = in_grad[:-1]
+                in_grad = [_scratch(rois, g.size * 4).reshape(g.shape) for g in grads16] + [in_grad[-1]]
+                rq = {REQ["write"]}
+            else:
+                rq = {req_data}
             ptrs, Hs, Ws = self._levels(in_grad[:-1])
+            out_grad = [og]
             if self.packed:  # with the workspace the per-band RoI lists are built once, not per channel
                 lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
                 wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(Hs, Ws, len(feats), B, rois.shape[1])
@@ -719,17 +734,23 @@ def _build_ops(mx):
                            _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B, C,
                            rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
                            float(self.lvl0), None)
+            if self.fp16:
+                for g32, g16 in zip(in_grad[:-1], grads16):
+                    lib().call("sd_cast_f32_to_f16", _ptr(g32), _ptr(g16), ctypes.c_size_t(g16.size), req_data, None)
             _sync()
             self.assign(in_grad[-1], req[-1], 0)
 
     class FPNRoIAlignProp(CustomOpProp):
         def __init__(self, rcnn_stride, pooled_size="(7, 7)", roi_canonical_scale="224",
-                     roi_canonical_level="4"):
+                     roi_canonical_level="4", fp16="False"):
             super().__init__(need_top_grad=True)
             self.rcnn_stride = _tuple(rcnn_stride, typ=int)
             self.pooled_size = _tuple(pooled_size, 2, int)
             self.scale0, self.lvl0 = float(roi_canonical_scale), float(roi_canonical_level)
             self.packed = _fpn_packed(self.pooled_size)
+            self.fp16 = _bool(fp16)
+            if self.fp16 and not self.packed:
+                raise ValueError("fpn_roi_align: fp16 I/O is provided for 7x7 and 14x14 pooling")
 
         def list_arguments(self):
             return ["data_s{}".format(s) for s in self.rcnn_stride] + ["rois"]
@@ -753,10 +774,12 @@ def _build_ops(mx):
         def infer_type(self, in_type):
             import numpy as np
             f32 = np.float32
+            if self.fp16:  # feature maps fp16, rois fp32 -> output fp16; the state keeps its types
+                return [np.float16] * (len(in_type) - 1) + [f32], [np.float16, np.uint8, f32], []
             return in_type, [f32, np.uint8 if self.packed else f32, f32], []
 
         def create_operator(self, ctx, shapes, dtypes):
-            return FPNRoIAlign(self.rcnn_stride, self.pooled_size, self.scale0, self.lvl0)
+            return FPNRoIAlign(self.rcnn_stride, self.pooled_size, self.scale0, self.lvl0, self.fp16)
 
         def declare_backward_dependency(self, out_grad, in_data, out_data):
             return [out_grad[0], in_data[-1], out_data[1], out_data[2]]
@@ -1003,19 +1026,23 @@ def patch_fpn_roi_align(builder_module=None, mx=None):
     def get_roi_feature(self, conv_fpn_feat, proposal):
         p = self.p
         strides = tuple(int(s) for s in p.stride)
+        out = int(p.out_size)
+        fp16 = bool(getattr(p, "fp16", False))
+        native16 = fp16 and out in (7, 14)   # the op reads / writes fp16 itself: no cast nodes
         feats = []
         for s_ in strides:
             f = conv_fpn_feat["stride%s" % s_]
-            if getattr(p, "fp16", False):
+            if fp16 and not native16:
                 f = mx.sym.Cast(data=f, dtype="float32", name="fpn_stride%s_to_fp32" % s_)
             feats.append(f)
-        out = int(p.out_size)
+        extra = {"fp16": "True"} if native16 else {}
         sym = mx.sym.Custom(*feats, proposal, op_type=_PREFIX + "fpn_roi_align",
                             rcnn_stride=_param_str(strides), pooled_size=_param_str((out, out)),
                             roi_canonical_scale=_param_str(p.roi_canonical_scale),
-                            roi_canonical_level=_param_str(p.roi_canonical_level), name="fpn_roi_align")
+                            roi_canonical_level=_param_str(p.roi_canonical_level), name="fpn_roi_align",
+                            **extra)
         roi_feat = mx.sym.reshape(data=sym[0], shape=(-3, -2), name="roi_feat_reshape")
-        if getattr(p, "fp16", False):
+        if fp16 and not native16:
             roi_feat = mx.sym.Cast(data=roi_feat, dtype="float16", name="roi_feat_to_fp16")
         return roi_feat
 

@@ -201,6 +201,35 @@ def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_cano
     return out, (amax, coords)
 
 
+def fpn_roi_align_forward_packed_f16(feats, rois, rcnn_stride, pooled_size, roi_canonical_scale=224,
+                                     roi_canonical_level=4):
+    """fp16 I/O variant of fpn_roi_align_forward_packed: feats fp16 (B,C,H_l,W_l), rois fp32 (B,R,4)
+    -> out fp16 (B,R,C,ph,pw), (argmax, coords).  Bit-equal to feats.float() -> the fp32 op ->
+    out.half() (models/FPN/builder.py:581-586, 607-608 wraps the op in exactly those casts)."""
+    _chk(rois, "rois", ndim=3)
+    if len(feats) != len(rcnn_stride):
+        raise ValueError("one feature map per stride expected")
+    B, C = feats[0].shape[:2]
+    for i, f in enumerate(feats):
+        _chk(f, "feats[%d]" % i, dtype=torch.float16, ndim=4)
+        if tuple(f.shape[:2]) != (B, C):
+            raise ValueError("all levels must share (B,C)")
+    if rois.shape[0] != B:
+        raise ValueError("rois batch mismatch")
+    ph, pw = _pair(pooled_size)
+    R = rois.shape[1]
+    out = torch.empty((B, R, C, ph, pw), device=rois.device, dtype=torch.float16)
+    amax = torch.empty((B, R, C, argmax_stride(ph, pw)), device=rois.device, dtype=torch.uint8)
+    coords = torch.empty((B, R, 9 * (ph + pw)), device=rois.device, dtype=torch.float32)
+    wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, R)
+    ws = torch.empty(wsb, device=rois.device, dtype=torch.uint8)
+    lib().call("sd_fpn_roi_align_fwd_packed_f16", _parr(feats), _iarr([f.shape[2] for f in feats]),
+               _iarr([f.shape[3] for f in feats]), _iarr(rcnn_stride), len(feats), _p(rois),
+               _p(out), _p(amax), _p(coords), B, C, R, ph, pw, float(roi_canonical_scale),
+               float(roi_canonical_level), _p(ws), ctypes.c_size_t(wsb), _stream())
+    return out, (amax, coords)
+
+
 def fpn_roi_align_backward_packed(out_grad, rois, argmax, feat_shapes, rcnn_stride,
                                   roi_canonical_scale=224, roi_canonical_level=4, req_data="write",
                                   d_feats=None):
@@ -228,6 +257,42 @@ def fpn_roi_align_backward_packed(out_grad, rois, argmax, feat_shapes, rcnn_stri
                _parr(d_feats), hs, ws_,
                _iarr(rcnn_stride), len(d_feats), rd, B, C, R, ph, pw, float(roi_canonical_scale),
                float(roi_canonical_level), _p(work), ctypes.c_size_t(work.numel() * 4), _stream())
+    return d_feats
+
+
+def cast_f16_to_f32(src, out=None):
+    _chk(src, "src", dtype=torch.float16)
+    out = torch.empty(src.shape, device=src.device, dtype=torch.float32) if out is None else out
+    lib().call("sd_cast_f16_to_f32", _p(src), _p(out), ctypes.c_size_t(src.numel()), _stream())
+    return out
+
+
+def cast_f32_to_f16(src, out=None, req="write"):
+    _chk(src, "src")
+    out = torch.empty(src.shape, device=src.device, dtype=torch.float16) if out is None else out
+    lib().call("sd_cast_f32_to_f16", _p(src), _p(out), ctypes.c_size_t(src.numel()),
+               REQ[req] if isinstance(req, str) else int(req), _stream())
+    return out
+
+
+def fpn_roi_align_backward_packed_f16(out_grad, rois, argmax, feat_shapes, rcnn_stride,
+                                      roi_canonical_scale=224, roi_canonical_level=4, req_data="write",
+                                      d_feats=None):
+    """Backward of fpn_roi_align_forward_packed_f16: out_grad fp16 -> gradients fp16.  The sums are
+    formed by the fp32 backward kernel; the fp16 interface is the two op-boundary casts of the
+    reference's fp16 graphs (to_fp32 on the way in, to_fp16 on the way out) around it -- a backward
+    kernel with fp16 I/O of its own is not built."""
+    _chk(out_grad, "out_grad", dtype=torch.float16, ndim=5)
+    rd = REQ[req_data] if isinstance(req_data, str) else int(req_data)
+    g32 = fpn_roi_align_backward_packed(cast_f16_to_f32(out_grad), rois, argmax, feat_shapes, rcnn_stride,
+                                        roi_canonical_scale, roi_canonical_level)
+    if d_feats is None:
+        if rd == REQ["add"]:
+            raise ValueError("req_data='add' needs d_feats")
+        d_feats = [torch.empty(tuple(s), device=out_grad.device, dtype=torch.float16) for s in feat_shapes]
+    for g, d in zip(g32, d_feats):
+        _chk(d, "d_feats", dtype=torch.float16, ndim=4)
+        cast_f32_to_f16(g, d, rd)
     return d_feats
 
 

@@ -123,6 +123,17 @@ def test_fused_fpn_roi_align_prop(plugin):
     assert q.infer_shape(shapes)[1] == [(2, 512, 256, 5, 5)] * 3
 
 
+def test_fused_fpn_roi_align_prop_fp16(plugin):
+    """fp16 = True: feature maps fp16, rois fp32 -> output fp16, the private state keeps its types"""
+    _, props, _ = plugin
+    p = props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)", pooled_size="(14, 14)", fp16="True")
+    tin, tout, _ = p.infer_type([np.float16] * 4 + [np.float32])
+    assert [np.dtype(t) for t in tin] == [np.dtype(np.float16)] * 4 + [np.dtype(np.float32)]
+    assert [np.dtype(t) for t in tout] == [np.dtype(np.float16), np.dtype(np.uint8), np.dtype(np.float32)]
+    with pytest.raises(ValueError):
+        props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)", pooled_size="(5, 5)", fp16="True")
+
+
 def test_symbol_alias_builds_custom_node_with_visible_outputs(plugin):
     mx, _, _ = plugin
     d, r = mx.sym.Variable("data"), mx.sym.Variable("rois")
@@ -187,11 +198,19 @@ def test_install_routes_fpn_extractor_to_the_fused_op_without_editing_the_refere
         assert custom.params == {"rcnn_stride": "(4, 8, 16, 32)", "pooled_size": "(7, 7)",
                                  "roi_canonical_scale": "224", "roi_canonical_level": "4"}
         assert FPNRoiAlign(p)._sd_reference_get_roi_feature(feats, rois) == "reference subgraph"
-        # fp16 graphs: fp32 around the op, as the reference does (builder.py:581-586, 607-608)
+        # fp16 graphs, 7x7 / 14x14: the op reads and writes fp16 itself (sd_fpn_roi_align_fwd_packed_f16),
+        # the cast nodes of builder.py:581-586, 607-608 are gone
         p.fp16 = True
+        node = FPNRoiAlign(p).get_roi_feature(feats, rois)
+        assert node[0] == "reshape"
+        custom = node[1][1]
+        assert custom.params["fp16"] == "True" and custom.inputs[0] is feats["stride4"]
+        # other pooling sizes keep the reference's casts around the fp32 op
+        p.out_size = 5
         node = FPNRoiAlign(p).get_roi_feature(feats, rois)
         assert node[0] == "cast" and node[2] == "float16" and node[1][0] == "reshape"
         assert node[1][1][1].inputs[0] == ("cast", feats["stride4"], "float32")
+        assert "fp16" not in node[1][1][1].params
     finally:
         for k, v in old.items():
             if v is None:

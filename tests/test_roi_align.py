@@ -499,19 +499,21 @@ def test_packed_backward_is_bit_reproducible_and_within_1e4_at_full_size(ops, or
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pooled,num", [((7, 7), 512), ((14, 14), 128)])
-def test_packed_backward_workspace_modes(ops, pooled, num):
+def test_packed_backward_workspace_modes(ops, oracle, pooled, num):
     """The packed backward with the workspace pre-pass (1: per-band RoI lists + tap tables, 27 KB
     bands; 2: lists only, 36 KB bands) and without (0: every workgroup builds its list).  Lists
     only == none bit for bit (same bands, same arithmetic); the tap-table mode cuts the planes into
-    different bands, hence other fixed-point scales: each is within ~3e-5 of the exact sum (the
-    oracle comparisons elsewhere), so the two agree within 1e-4; and each mode is bit-reproducible."""
+    different bands, hence other fixed-point scales: every mode is within 1e-4 of the exact sums (the
+    oracle), elementwise, and bit-reproducible."""
     import torch
     from simpledet_amd._lib import lib
     feats = [_t(f) for f in synth.feature_maps(8, batch=2, channels=64)]
     rois = _t(synth.random_rois(8, 2, num))
     out, am = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, pooled)
-    dy = torch.randn_like(out)
+    dy = _t(np.random.RandomState(81).standard_normal(tuple(out.shape)).astype(np.float32))
     shapes = [f.shape for f in feats]
+    fw = oracle.fpn_roi_align_fwd([f.cpu().numpy() for f in feats], rois.cpu().numpy(), STRIDES, pooled, nthreads=8)
+    want = oracle.fpn_roi_align_bwd(dy.cpu().numpy(), rois.cpu().numpy(), fw[1], fw[2], shapes, STRIDES, nthreads=8)
     res = {}
     for mode in (1, 2, 0):
         lib().set_tuning("roi_align_bwd_lists", mode)
@@ -524,8 +526,10 @@ def test_packed_backward_workspace_modes(ops, pooled, num):
             assert torch.equal(a, b), "mode %d is not bit-reproducible" % mode
     for a, b in zip(res[2], res[0]):
         assert torch.equal(a, b)
-    for a, b in zip(res[1], res[0]):
-        assert float((a - b).abs().max()) <= 1e-4
+    # every mode against the exact sums: the north_star bar, elementwise
+    for mode in (1, 0):
+        for a, w in zip(res[mode], want):
+            _assert_bwd_close(a.cpu().numpy(), w)
 
 
 @pytest.mark.gpu
@@ -574,3 +578,51 @@ def test_fused_fpn_roi_align_geometry_fuzz(ops, oracle):
                 err = float(np.abs(g.cpu().numpy() - w).max())
                 tol = 1e-4 * max(1.0, float(np.abs(w).max()) / 32.0)
                 assert err <= tol, msg + " %s backward max abs err %g (|dX| max %g)" % (which, err, np.abs(w).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pooled,num,channels", [((7, 7), 96, 16), ((14, 14), 40, 8), ((7, 7), 512, 64)])
+def test_fpn_packed_forward_fp16_io(ops, oracle, pooled, num, channels):
+    """fp16 feature maps in, fp16 output out, fp32 arithmetic: bit-equal to what an fp16 graph
+    computes with the reference's casts around the op (X.to_fp32 -> ROIAlign_v2 -> X.to_fp16,
+    models/FPN/builder.py:581-586, 607-608); the packed arg-max decodes to the oracle's floats."""
+    import torch
+    feats16 = [f.astype(np.float16) for f in synth.feature_maps(5, batch=2, channels=channels)]
+    rois = synth.random_rois(5, 2, num)
+    want = oracle.fpn_roi_align_fwd([f.astype(np.float32) for f in feats16], rois, STRIDES, pooled, nthreads=8)
+    out, (am, coords) = ops.fpn_roi_align_forward_packed_f16([_t(f) for f in feats16], _t(rois), STRIDES, pooled)
+    assert out.dtype == torch.float16
+    np.testing.assert_array_equal(out.cpu().numpy(), want[0].astype(np.float16))
+    # the same state as the fp32 op on the converted maps
+    o32, (am32, c32) = ops.fpn_roi_align_forward_packed([_t(f.astype(np.float32)) for f in feats16], _t(rois),
+                                                         STRIDES, pooled)
+    assert torch.equal(ops.argmax_codes(am, pooled), ops.argmax_codes(am32, pooled))
+    lvl = ops.fpn_roi_assign(_t(rois), STRIDES)[1].reshape(-1) >= 0
+    assert torch.equal(coords.reshape(lvl.numel(), -1)[lvl], c32.reshape(lvl.numel(), -1)[lvl])
+    assert torch.equal(out, o32.half())
+
+
+@pytest.mark.gpu
+def test_fpn_packed_backward_fp16_io(ops, oracle):
+    """fp16 gradient in, fp16 gradients out: the fp32 sums (within 1e-4 of the oracle's) rounded to
+    fp16 -- at most one fp16 step from the rounded exact sum wherever 1e-4 crosses a rounding boundary."""
+    import torch
+    feats16 = [f.astype(np.float16) for f in synth.feature_maps(6, batch=2, channels=16)]
+    rois = synth.random_rois(6, 2, 128)
+    out, am = ops.fpn_roi_align_forward_packed_f16([_t(f) for f in feats16], _t(rois), STRIDES, (7, 7))
+    dy16 = np.random.RandomState(7).standard_normal(tuple(out.shape)).astype(np.float16)
+    shapes = [f.shape for f in feats16]
+    g16 = ops.fpn_roi_align_backward_packed_f16(_t(dy16), _t(rois), am, shapes, STRIDES)
+    fw = oracle.fpn_roi_align_fwd([f.astype(np.float32) for f in feats16], rois, STRIDES, (7, 7), nthreads=8)
+    want = oracle.fpn_roi_align_bwd(dy16.astype(np.float32), rois, fw[1], fw[2], shapes, STRIDES, nthreads=8)
+    for g, w in zip(g16, want):
+        assert g.dtype == torch.float16
+        got = g.cpu().numpy().astype(np.float32)
+        step = np.maximum(np.abs(w) * 2.0 ** -10, 2.0 ** -24)   # one fp16 step at the value's magnitude
+        assert np.all(np.abs(got - w) <= 1e-4 + step)
+    # req = add accumulates into fp16 gradients
+    acc = [torch.ones(tuple(s), device="cuda", dtype=torch.float16) for s in shapes]
+    ops.fpn_roi_align_backward_packed_f16(_t(dy16), _t(rois), am, shapes, STRIDES, req_data="add", d_feats=acc)
+    for a_, w in zip(acc, want):
+        step = np.maximum(np.abs(w + 1) * 2.0 ** -10, 2.0 ** -24)
+        assert np.all(np.abs(a_.cpu().numpy().astype(np.float32) - (w + 1)) <= 1e-4 + 2 * step)
