@@ -778,6 +778,8 @@ struct BandPlan {
   int nunits;
   int grab;                          // channels a workgroup reserves at a time
   int gbias;                         // per cent added to the cost estimate of multi-plane units
+  int tail;                          // last per cent of a unit's channels handed out in small pieces
+  int tail_planes;                   // planes of such a piece (<= G)
   int pool;
   uint4* rowent;    // [B*R][pool]  {lo0 | step0 << 20 | empty << 31, lo1 | step1 << 20, a0, a1}
   uint4* colent;    // [B*R][pool]  {left0 | dup0 << 12 | left1 << 13 | dup1 << 25 | empty << 26, -, b0, b1}
@@ -1030,7 +1032,8 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
   // work left ----
   __shared__ int v_unit[kBandMaxUnits], v_first[kBandMaxUnits], v_items[kBandMaxUnits];
   __shared__ int v_cost[kBandMaxUnits], v_start[kBandMaxUnits + 1];
-  __shared__ int s_grab[2], s_pick;
+  __shared__ int2 s_grab[2];  // reservations {first channel, channels}
+  __shared__ int s_pick;
   const int wg = (int)blockIdx.x - kBandFallbackWGs, nwg = (int)gridDim.x - kBandFallbackWGs;
   const int rsub = (a.R + kBandSub - 1) / kBandSub;
   auto level_of = [&](int u) {
@@ -1150,15 +1153,21 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
   const int G = P.g[lvl], nb = P.nbands[lvl];
   // channels are reserved GR at a time (a run of consecutive channels: the (RoI, channel) rows of the
   // outputs are 196 bytes, neighbours share cache lines, and a run written by one CU merges in its L2)
+  // In the last P.tail per cent of a unit reservations shrink to single fills, so that what a
+  // workgroup still holds when the counter runs dry is small.
   const int GR = ((P.grab + G - 1) / G) * G;
+  int glast = 0;  // (thread 0) first channel of the last reservation it got
+  auto next_size = [&]() { return glast >= a.C - a.C * P.tail / 100 ? (P.tail_planes < G ? P.tail_planes : G) : GR; };
   {
     const int k = grab(vu, GR);
-    if (tid == 0) s_grab[0] = k;
+    if (tid == 0) s_grab[0] = make_int2(k, GR);
+    glast = k;
     __syncthreads();
   }
-  int kcur = s_grab[0];
+  int kcur = s_grab[0].x;
   if (kcur >= a.C) continue;  // (uniform) dry already
   int ck = kcur + G, cend = kcur + GR < a.C ? kcur + GR : a.C;   // rest of the current reservation
+  int gcur = cend - kcur < G ? cend - kcur : G, gnext = 0;       // planes of the current / next fill
   int slot = 1;                                                  // where the next reservation is parked
   const int ul = unit - P.unit_base[lvl];
   const int img = ul / nb, band = ul % nb;
@@ -1282,9 +1291,13 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
         ces[i] = P.colent[((long)img * a.R + n) * POOL + q];
       }
     }
-    int shift_next = fill(gbase + (long)kcur * HW, buf0, a.C - kcur < G ? a.C - kcur : G);
-    fill_commit(buf0, a.C - kcur < G ? a.C - kcur : G);   // (fp16: the first fill is not hidden)
-    if (tid == 0) s_grab[1] = grab(vu, GR);  // the reservation after this one (read past the next barrier)
+    int shift_next = fill(gbase + (long)kcur * HW, buf0, gcur);
+    fill_commit(buf0, gcur);   // (fp16: the first fill is not hidden)
+    if (tid == 0) {  // the reservation after this one (read past the next barrier)
+      const int sz = next_size();
+      glast = grab(vu, sz);
+      s_grab[1] = make_int2(glast, sz);
+    }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int it = (wave + kBandWaves * i) * IPP + lane / QL;
@@ -1338,7 +1351,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
       }
 #endif
       const int shift = shift_next;
-      const int gcount = a.C - kcur < G ? a.C - kcur : G;
+      const int gcount = gcur;
       // next fill: the rest of this reservation, else the parked one (and a new one is requested;
       // the counter's answer stays in a register while the step computes)
       int knext = a.C, grabbed = 0;
@@ -1347,18 +1360,24 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
         knext = ck;
         ck += G;
       } else {
-        const int b = s_grab[slot];
-        if (b < a.C) {
-          knext = b;
-          ck = b + G;
-          cend = b + GR < a.C ? b + GR : a.C;
+        const int2 b = s_grab[slot];
+        if (b.x < a.C) {
+          knext = b.x;
+          ck = b.x + G;
+          cend = b.x + b.y < a.C ? b.x + b.y : a.C;
           slot ^= 1;
           regrab = true;
         }
       }
-      if (knext < a.C)
-        shift_next = fill(gbase + (long)knext * HW, (s & 1) ? buf0 : buf1, a.C - knext < G ? a.C - knext : G);
-      if (regrab) grabbed = grab(vu, GR);
+      if (knext < a.C) {
+        gnext = cend - knext < G ? cend - knext : G;   // (cend: end of the reservation knext lies in)
+        shift_next = fill(gbase + (long)knext * HW, (s & 1) ? buf0 : buf1, gnext);
+      }
+      int gsz = 0;
+      if (regrab) {
+        gsz = next_size();
+        grabbed = grab(vu, gsz);
+      }
       const char* base = reinterpret_cast<const char*>((s & 1) ? buf1 : buf0);
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -1424,9 +1443,13 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
 #ifdef SD_PROFILING
       ++dbg_fills;
 #endif
-      if (knext < a.C) fill_commit((s & 1) ? buf0 : buf1, a.C - knext < G ? a.C - knext : G);
-      if (tid == 0 && regrab) s_grab[slot] = grabbed;
+      if (knext < a.C) fill_commit((s & 1) ? buf0 : buf1, gnext);
+      if (tid == 0 && regrab) {
+        s_grab[slot] = make_int2(grabbed, gsz);
+        glast = grabbed;
+      }
       kcur = knext;
+      gcur = gnext;
       if (kcur >= a.C) break;  // (uniform) the unit has no fill left for this workgroup
     }
 #ifdef SD_PROFILING
@@ -2837,6 +2860,9 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     P.nunits = units;
     P.grab = tuning("roi_align_fwd_grab", 4);
     P.gbias = tuning("roi_align_fwd_gbias", 0);
+    P.tail = tuning("roi_align_fwd_tail", 0);
+    P.tail_planes = tuning("roi_align_fwd_tail_planes", 8);
+    if (P.tail_planes < 1) P.tail_planes = 1;
     if (P.grab < 1) P.grab = 1;
     if (units > kBandMaxUnits) ok = false;
     wg = tuning("roi_align_fwd_wgs", kNumCU);  // persistent workgroups, one per CU

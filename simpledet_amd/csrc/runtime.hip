@@ -43,6 +43,8 @@ Knob g_knobs[] = {
     {"roi_align_fwd_band", 0, false},    // 1 band-resident forward: planes streamed through LDS, no gathers (default), 0 tiled kernels
     {"roi_align_fwd_steps", 0, false},   // channels per band workgroup (fills x planes per fill), default 8
     {"roi_align_fwd_gbias", 0, false},   // per cent added to the cost estimate of multi-plane units (default 0: 15 and 30 measured, no effect)
+    {"roi_align_fwd_tail_planes", 0, false},  // planes of a tail piece (default 8 = a whole fill)
+    {"roi_align_fwd_tail", 0, false},    // last per cent of a unit's channels reserved one fill at a time (default 0)
     {"roi_align_fwd_grab", 0, false},    // channels a band workgroup reserves at a time (default 4)
     {"roi_align_fwd_wgs", 0, false},     // persistent band workgroups (default 256 = one per CU)
     {"roi_align_fwd_split", 0, false},   // 1 more bands than LDS needs when a unit's expected items exceed a round (default)
