@@ -2825,7 +2825,10 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       const int cap = kBandNP * kBandWaves * (kWave / POOL);
       const long est = (long)a.R * POOL / (nvalid_lv > 0 ? nvalid_lv : 1);
       const int by_items = (int)((est * 5 + 4L * cap - 1) / (4L * cap));   // est / (0.8 cap)
-      if (by_items > nbn && tuning("roi_align_fwd_split", 1)) nbn = by_items;
+      // (packed arg-max only: with the three fp32 outputs of the drop-in op the stores dominate, and
+      // a RoI whose bin rows sit in one band is written as whole 196-byte rows -- C4: 254 vs 334 us;
+      // the extra rounds re-read planes that are still in L2)
+      if (by_items > nbn && a.amax8 && tuning("roi_align_fwd_split", 1)) nbn = by_items;
       if (nbn > H) nbn = H;
       if (nbn > kBandMaxBands) nbn = kBandMaxBands;   // (more items than that: rounds)
       int owned = (H + nbn - 1) / nbn;
