@@ -163,6 +163,21 @@ int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const 
                                 const int* strides_host, int nlvl, int req_data, int B, int C, int R,
                                 int pooled_h, int pooled_w, float roi_canonical_scale,
                                 float roi_canonical_level, void* stream);
+/* Numerics of the packed backward (and of the drop-in sd_roi_align_v2_bwd / sd_fpn_roi_align_bwd in
+ * their default form).  Every tap value is computed in fp32 exactly as the reference does; the SUM a
+ * pixel receives is accumulated in 32-bit fixed point whose unit is fixed per workgroup (one band of
+ * one channel) from max|dY| over that band and a bound on the weights a pixel can collect: ~2e-6 x
+ * max|dY| of the band per added value.  The result is independent of the order of the adds (the
+ * backward is bit-reproducible, the reference's float atomics are not), within 1e-4 of the exact sums
+ * for dY ~ N(0,1) (measured 2.5e-5), but the error is ABSOLUTE relative to the band's largest
+ * gradient: an element orders of magnitude smaller than max|dY| of its band keeps fewer significant
+ * digits than the reference's fp32 adds would give it.  Non-finite dY and extreme weight pile-ups
+ * switch a workgroup to fp32 compare-and-swap adds by themselves.  Callers that need fp32-relative
+ * sums everywhere select those adds for every workgroup with
+ *     sd_set_tuning("roi_align_bwd_packed", 0)   (packed arg-max)
+ *     sd_set_tuning("roi_align_bwd", 1) + sd_set_tuning("roi_align_bwd_accum", 0)   (float arg-max planes)
+ * at ~1.3-2.5 x the time; those paths sum in the order the hardware serves the adds, like the
+ * reference. */
 /* The same with a device workspace of sd_fpn_roi_align_bwd_workspace_bytes(): the per-band RoI
  * lists are then built by one small pre-pass instead of by every channel's workgroup (same
  * results bit for bit).  workspace may be NULL (= the call above). */
