@@ -10,6 +10,7 @@ import time
 import numpy as np
 
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
@@ -346,7 +347,10 @@ def run(seed=0, cpu=True, only=None):
             "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
             "col2im_ms": ms_c2i, "col2im_coord_ms": ms_crd,
             "fwd_ms": ms_f, "bwd_ms": ms_b, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
-            "gemm_frac_of_f32_mfma_peak": flops / gemm_ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
+            # fp32 products as three bf16 MFMA terms (hi/lo split): 3 x the flops on the bf16 pipe
+            "gemm_arith": "fp32 in/out, 3 bf16 MFMA terms per product (deform_gemm_split=1)",
+            "gemm_frac_of_bf16_mfma_peak": 3.0 * flops / gemm_ms / 1e9 / PEAK_BF16_MFMA_TFLOPS,
+            "gemm_vs_f32_mfma_peak": flops / gemm_ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
             "config": "x (16,256,50,84), 3x3 pad 1, 4 deformable groups, 256 filters, fp32"}
         if orc:
             wy = orc.deform_conv_fwd(N_(x[:1]), N_(off[:1]), N_(wt), 1, 1, 1, 4)

@@ -10,11 +10,13 @@
 //     the pixel axis (the col matrix is the HBM-bound stream: 4*9*C*Ho*Wo bytes per image).
 //   * col2im / col2im_coord: same ownership; the data gradient is scattered with hardware fp32
 //     atomics (as the reference does), the offset gradient is a per-lane reduction over channels.
-//   * GEMM: the only MFMA work on the hot path.  fp32 in / fp32 accumulate on
-//     v_mfma_f32_32x32x2_f32 (exact fp32 products, the reference computes this layer in fp32:
-//     models/tridentnet/resnet_v1.py:209), 128x128x16 tiles, 4 waves x (2x2) 32x32 accumulators,
-//     k-major LDS tiles so operand reads are conflict-free ds_read_b32, register-prefetched global
-//     loads, batch over images in grid.z; XCD-aware tile order keeps one image's col panel in one L2.
+//   * GEMM: the only MFMA work on the hot path, fp32 in / fp32 out (the reference computes this
+//     layer in fp32: models/tridentnet/resnet_v1.py:209).  Default: every fp32 product as three bf16
+//     MFMA terms of a hi/lo operand split (gemm_f32_split_bf16_kernel below: 4.5e-6 x max|C| on the
+//     DCN products, 2.5-2.9x the fp32 MFMA kernel); `deform_gemm_split = 0`: exact fp32 products on
+//     v_mfma_f32_32x32x2_f32 (gemm_f32_mfma_kernel: 128 x 64J x 16 tiles, k-major LDS tiles read
+//     as conflict-free ds_read_b32).  Both: 4 waves x (2x2) 32x32 accumulators, register-prefetched
+//     global loads, XCD-aware tile order that keeps one image's col panel in one L2.
 #include "common.h"
 #include "../../include/simpledet_ops.h"
 #include <math.h>
@@ -591,6 +593,11 @@ struct GemmArgs {
   long strideA, strideB, strideC;
   int mode;  // 0 store, 1 C += (read-modify-write), 2 atomic add
   int tiles_m, tiles_n;
+  int fast;  // split kernel: operands aligned for vector loads (launch_gemm)
+  long long* dbg;  // profiling build only: per-wave phase clocks
+  long dbg_cap;
+  int whole, whole_blocks, ksplit;  // split kernel: tiles run whole, their blocks (padded), k slices of the rest
+  int ablate;  // profiling build only: bit 0 skip the A prefetch, bit 1 skip the B prefetch
 };
 
 constexpr int BM = 128;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
@@ -738,6 +745,326 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix cores: every fp32 operand is split into two bf16 parts
+// (hi = RNE(x), lo = RNE(x - hi): 16 mantissa bits kept) while its tile is staged into LDS, and each
+// fp32 product becomes  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation (the dropped a_lo*b_lo term is <= 2^-18 of the product).  Three bf16 MFMAs replace
+// eight fp32 ones: 5.3x the fp32 MFMA peak.  Measured error of the DCN forward product (K = 2304):
+// 4.5e-6 x max|C| against an fp64 product (plain fp32 accumulation: 5e-7) -- a twentieth of the
+// 1e-4 parity bar.  Non-finite inputs give NaN (inf - inf in the split), as 0 x inf would.
+//   tile 128 x 128 x 64, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 accumulators of 32x32
+//   LDS: four planes (A hi, A lo, B hi, B lo) of 128 rows x 64 bf16 (128 B per row, k contiguous);
+//   the 16-byte granule gk (8 k values) of row r sits at position gk ^ ((r >> 1) & 7): fragment
+//   reads (32 consecutive rows, one granule each: ds_read_b128) and both kinds of staging writes
+//   (a row's 8 granules from 8 lanes; one granule of the even / odd rows from 64 lanes) touch all
+//   32 banks evenly.
+//   Tile order: the M tiles of one N panel run back to back on ONE XCD (block b -> XCD b % 8), so
+//   the B panel (the col matrix, the only large operand) leaves HBM once.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+constexpr int SBM = 128, SBN = 128, SBK = 64;
+constexpr int kSplitPlane = 128 * 128;  // bytes per LDS plane
+
+// hi / lo bf16 parts of two floats, packed (element 0 in the low half).  PK = false keeps the two
+// subtractions scalar: a packed v_pk_add_f32 wants its operands in adjacent registers, and for
+// values that come out of two different loads the compiler then shuffles registers right behind
+// the loads -- i.e. waits for the prefetch it was supposed to leave in flight.
+template <bool PK>
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const floatx2 v = {x0, x1};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float f0 = __builtin_bit_cast(float, hi << 16), f1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+  floatx2 r;
+  if (PK) {
+    r = floatx2{x0 - f0, x1 - f1};
+  } else {
+    float r0, r1;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(x0), "v"(f0));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(x1), "v"(f1));
+    r = floatx2{r0, r1};
+  }
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+// Operand tile of 128 rows x 64 k.  Global element (r, k) at base[r*sr + k*sk], one stride = 1.
+template <bool KCONTIG>
+struct SplitIO {
+  // KCONTIG: unit = (row, granule of 8 k): 1024 units, 4 trips of 8 values (two 16-byte loads)
+  // else   : unit = (4 consecutive rows, granule): 256 units, one trip of 32 values (eight 16-byte
+  //          loads, one per k; a wave = 32 row quads x 2 granules: 512 contiguous bytes per k row)
+  // Loads cost the wave ~100 cycles of issue each whatever their width, so all are 16 bytes wide.
+  static constexpr int TRIPS = KCONTIG ? 4 : 1;
+  static constexpr int NV = 32;
+
+  // FAST (decided on the host for the whole launch): 16-byte (KCONTIG) / 8-byte aligned vector
+  // loads of a full k step with no bounds tests -- rows past R are clamped (their products land in
+  // rows / columns of C that are never stored).  The general version tests every element and is
+  // used for the k tail and for unaligned operands.
+  template <bool FAST>
+  static __device__ __forceinline__ void load(const float* __restrict__ base, long sr, long sk,
+                                              int r0, int k0, int R, int K, int tid,
+                                              float (&v)[NV]) {
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int u = tid + t * 256;
+      if (KCONTIG) {
+        const int r = r0 + (u >> 3), ks = k0 + (u & 7) * 8;
+        if (FAST) {
+          const float* p = base + (long)min(r, R - 1) * sr + ks;
+          const float4 a = *reinterpret_cast<const float4*>(p);
+          const float4 b = *reinterpret_cast<const float4*>(p + 4);
+          v[t * 8 + 0] = a.x; v[t * 8 + 1] = a.y; v[t * 8 + 2] = a.z; v[t * 8 + 3] = a.w;
+          v[t * 8 + 4] = b.x; v[t * 8 + 5] = b.y; v[t * 8 + 6] = b.z; v[t * 8 + 7] = b.w;
+        } else {
+          const float* p = base + (long)r * sr + ks;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[t * 8 + e] = (r < R && ks + e < K) ? p[e] : 0.f;
+        }
+      } else {
+        const int rr = r0 + (u & 31) * 4, ks = k0 + (u >> 5) * 8;
+        if (FAST) {  // R is a multiple of 4 here
+          const float* p = base + (long)ks * sk + min(rr, R - 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            // kept as loaded (the registers of one load = rows rr .. rr + 3 of k = ks + e): a
+            // shuffle here would wait for the data before the MFMAs the load is meant to hide under
+            const float4 a = *reinterpret_cast<const float4*>(p + (long)e * sk);
+            v[4 * e] = a.x; v[4 * e + 1] = a.y; v[4 * e + 2] = a.z; v[4 * e + 3] = a.w;
+          }
+        } else {
+          const float* p = base + (long)ks * sk + rr;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * e + c] = (ks + e < K && rr + c < R) ? p[(long)e * sk + c] : 0.f;
+        }
+      }
+    }
+  }
+
+  // hi plane at T, lo plane at T + kSplitPlane (bytes)
+  static __device__ __forceinline__ void store(char* __restrict__ T, int tid, const float (&v)[NV]) {
+#pragma unroll
+    for (int t = 0; t < NV / 8; ++t) {
+      int r, gk;
+      uint4 h, l;
+      if (KCONTIG) {
+        const int u = tid + t * 256;
+        r = u >> 3;
+        gk = u & 7;
+        split2<true>(v[t * 8 + 0], v[t * 8 + 1], h.x, l.x);
+        split2<true>(v[t * 8 + 2], v[t * 8 + 3], h.y, l.y);
+        split2<true>(v[t * 8 + 4], v[t * 8 + 5], h.z, l.z);
+        split2<true>(v[t * 8 + 6], v[t * 8 + 7], h.w, l.w);
+      } else {  // row t of the quad: element k = e sits at v[4*e + t]
+        r = (tid & 31) * 4 + t;
+        gk = tid >> 5;
+        split2<false>(v[t + 0], v[t + 4], h.x, l.x);
+        split2<false>(v[t + 8], v[t + 12], h.y, l.y);
+        split2<false>(v[t + 16], v[t + 20], h.z, l.z);
+        split2<false>(v[t + 24], v[t + 28], h.w, l.w);
+      }
+      const int off = r * 128 + ((gk ^ ((r >> 1) & 7)) << 4);
+      *reinterpret_cast<uint4*>(T + off) = h;
+      *reinterpret_cast<uint4*>(T + kSplitPlane + off) = l;
+    }
+  }
+};
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmArgs a) {
+  using TA = SplitIO<AK>;
+  using TB = SplitIO<BKC>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                     // hi, lo
+  char* Bs = smem + 2 * kSplitPlane;   // hi, lo
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Tile sequence q = ((image * tiles_n + tn) * tiles_m + tm).  Block b runs on XCD b % 8: an XCD
+  // walks its N panels one after the other, all M tiles of each.  The first `whole` tiles of the
+  // sequence are one block each; the rest (the tiles of a mostly empty last round of the resident
+  // workgroups, launch_gemm) are cut into `ksplit` k slices that add into C atomically.
+  int q, ks0 = 0, ks1 = 0x7fffffff;  // k-step range of this block
+  bool piece = false;
+  if ((int)blockIdx.x < a.whole_blocks) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    q = ((slot / a.tiles_m) * 8 + xcd) * a.tiles_m + slot % a.tiles_m;
+    if (q >= a.whole) return;
+  } else {
+    const int pi = blockIdx.x - a.whole_blocks, sl = pi % a.ksplit;
+    q = a.whole + pi / a.ksplit;
+    const int nk = (a.K + SBK - 1) / SBK;
+    ks0 = (int)((long)nk * sl / a.ksplit);
+    ks1 = (int)((long)nk * (sl + 1) / a.ksplit);
+    piece = true;
+  }
+  const int tm = q % a.tiles_m, tn = (q / a.tiles_m) % a.tiles_n;
+  const int b = q / (a.tiles_m * a.tiles_n);
+  const float* A = a.A + (long)b * a.strideA;
+  const float* B = a.B + (long)b * a.strideB;
+  float* C = a.C + (long)b * a.strideC;
+  const int m0 = tm * SBM, n0 = tn * SBN;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses: row (lane & 31) of a 32-row block, granule 2*s + (lane >> 5)
+  const int frow = lane & 31, fg = lane >> 5, fsw = (frow >> 1) & 7;
+  const int a_off = (wm + frow) * 128, b_off = (wn + frow) * 128;
+
+  auto mfma_step = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int go = ((2 * s + fg) ^ fsw) << 4;
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(As + a_off + i * 32 * 128 + go);
+        al[i] = *reinterpret_cast<const bf16x8*>(As + kSplitPlane + a_off + i * 32 * 128 + go);
+        bh[i] = *reinterpret_cast<const bf16x8*>(Bs + b_off + i * 32 * 128 + go);
+        bl[i] = *reinterpret_cast<const bf16x8*>(Bs + kSplitPlane + b_off + i * 32 * 128 + go);
+      }
+      // small terms first, so that the large one meets the running sum last
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  const long sra = AK ? a.sam : 1, ska = AK ? 1 : a.sak, srb = BKC ? a.sbn : 1, skb = BKC ? 1 : a.sbk;
+  float ra[32], rb[32];
+#ifdef SD_PROFILING
+  long long p_vm = 0, p_cvt = 0, p_mfma = 0, p_ld = 0;
+  const long long p_begin = __builtin_readcyclecounter();
+#endif
+  // full k steps of aligned operands: register prefetch of the next tile under the MFMAs
+  const int nfull = min(a.fast ? a.K / SBK : 0, ks1);
+  if (nfull > ks0) {
+    TA::template load<true>(A, sra, ska, m0, ks0 * SBK, a.M, a.K, tid, ra);
+    TB::template load<true>(B, srb, skb, n0, ks0 * SBK, a.N, a.K, tid, rb);
+    for (int s = ks0; s < nfull; ++s) {
+#ifdef SD_PROFILING
+      const long long c0 = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long c1 = __builtin_readcyclecounter();
+#endif
+      __syncthreads();
+      TA::store(As, tid, ra);
+      TB::store(Bs, tid, rb);
+      __syncthreads();
+#ifdef SD_PROFILING
+      const long long c2 = __builtin_readcyclecounter();
+#endif
+      {
+        // the last step prefetches its own tile again (never used): no branch, so the loads and the
+        // MFMAs below are one scheduling region and can be interleaved
+        const int kn = min(s + 1, nfull - 1) * SBK;
+#ifdef SD_PROFILING
+        if (!(a.ablate & 1)) TA::template load<true>(A, sra, ska, m0, kn, a.M, a.K, tid, ra);
+        if (!(a.ablate & 2)) TB::template load<true>(B, srb, skb, n0, kn, a.N, a.K, tid, rb);
+#else
+        TA::template load<true>(A, sra, ska, m0, kn, a.M, a.K, tid, ra);
+        TB::template load<true>(B, srb, skb, n0, kn, a.N, a.K, tid, rb);
+#endif
+      }
+#ifdef SD_PROFILING
+      const long long c2a = c2;
+#endif
+      mfma_step();
+      // one prefetch load per three MFMAs: a load costs the wave ~100 cycles of issue, which the
+      // matrix pipe covers with the MFMAs already queued (issued as a block in front of the MFMAs,
+      // the 16 loads stall the wave for ~1.7 k cycles with the pipe idle)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
+#ifdef SD_PROFILING
+      __builtin_amdgcn_sched_barrier(0);
+      const long long c3 = __builtin_readcyclecounter();
+      p_vm += c1 - c0; p_cvt += c2 - c1; p_mfma += c3 - c2a; p_ld += c2a - c2;
+#endif
+    }
+  }
+#ifdef SD_PROFILING
+  if (a.dbg && lane == 0) {
+    const long id = (long)blockIdx.x * 4 + wave;
+    if (id < a.dbg_cap) {
+      long long* d = a.dbg + id * 8;
+      d[0] = p_vm; d[1] = p_cvt; d[2] = p_mfma; d[3] = p_begin; d[4] = __builtin_readcyclecounter();
+      d[5] = nfull - ks0; d[6] = p_ld;
+    }
+  }
+#endif
+  // the k tail, and everything when an operand is not aligned
+  for (int k0 = max(nfull, ks0) * SBK; k0 < a.K && k0 < (long)ks1 * SBK; k0 += SBK) {
+    TA::template load<false>(A, sra, ska, m0, k0, a.M, a.K, tid, ra);
+    TB::template load<false>(B, srb, skb, n0, k0, a.N, a.K, tid, rb);
+    __syncthreads();
+    TA::store(As, tid, ra);
+    TB::store(Bs, tid, rb);
+    __syncthreads();
+    mfma_step();
+  }
+  // D layout of the 32x32 tile: element e of lane l -> row (e/4)*8 + (l/32)*4 + e%4, col l%32
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm + i * 32 + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3);
+        if (row < a.M && col < a.N) {
+          float* c = C + (long)row * a.ldc + col;
+          const float v = acc[i][j][e];
+          if (piece || a.mode == 2) atomicAdd(c, v);
+          else if (a.mode == 0) *c = v;
+          else *c += v;
+        }
+      }
+    }
+}
+
+// zero the tiles that k slices add into (C = A.B with the last tiles cut along k)
+__global__ __launch_bounds__(256) void gemm_zero_tiles_kernel(GemmArgs a) {
+  const int q = a.whole + blockIdx.x;
+  const int tm = q % a.tiles_m, tn = (q / a.tiles_m) % a.tiles_n, b = q / (a.tiles_m * a.tiles_n);
+  float* C = a.C + (long)b * a.strideC;
+  const int col = tn * SBN + (threadIdx.x & 127);
+  if (col >= a.N) return;
+  for (int r = threadIdx.x >> 7; r < SBM; r += 2) {
+    const int row = tm * SBM + r;
+    if (row < a.M) C[(long)row * a.ldc + col] = 0.f;
+  }
+}
+
+template <bool AK, bool BKC>
+static int launch_gemm_split(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f32_split_bf16_kernel<AK, BKC>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSplitPlane));
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC>), grid, dim3(256), 4 * kSplitPlane, st, g);
+  return SD_OK;
+}
+
 // Tile width by wave quantisation: the grid is only a few tiles per CU (4.1 for the DCN forward
 // product with 128-wide tiles), so the last partial round costs up to a full tile time.  Pick the
 // J in {1, 2, 3} that maximises  (tiles / CU) / ceil(tiles / CU)  x  (N / padded N)  x  the measured
@@ -755,6 +1082,55 @@ static void launch_gemm_j(const GemmArgs& g, int J, dim3 grid, hipStream_t st) {
 
 static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return SD_OK;
+  if (tuning("deform_gemm_split", 1) == 1) {
+    const bool ak = g.sak == 1, bk = g.sbk == 1;
+    SD_REQUIRE(ak || g.sam == 1, "GEMM: A needs a unit stride");
+    SD_REQUIRE(bk || g.sbn == 1, "GEMM: B needs a unit stride");
+    g.tiles_m = cdiv(g.M, SBM);
+    g.tiles_n = cdiv(g.N, SBN);
+    SD_REQUIRE((long)g.tiles_m * g.tiles_n * batch < (1L << 27), "GEMM: too many tiles");
+    const int tiles = g.tiles_m * g.tiles_n * batch, nk = cdiv(g.K, SBK);
+    // Two workgroups are resident per CU.  When the last round of them would be less than half
+    // full, its tiles are cut into k slices (atomic adds into zeroed / existing C) so that the
+    // round takes a slice's time instead of a tile's.  Sums of slices are order dependent in the
+    // last bits; `deform_gemm_ksplit = 0` keeps every tile in one block.
+    const int slots = 2 * kNumCU, rem = tiles % slots;
+    g.whole = tiles;
+    g.ksplit = 1;
+    if (tuning("deform_gemm_ksplit", 1) == 1 && tiles > slots && rem > 0 && rem <= slots / 2 && nk >= 4) {
+      int ks = slots / rem;
+      if (ks > nk / 2) ks = nk / 2;
+      if (ks >= 2) {
+        g.whole = tiles - rem;
+        g.ksplit = ks;
+      }
+    }
+    const int groups = cdiv(g.whole, g.tiles_m);  // (image, N panel) groups of the whole tiles
+    g.whole_blocks = cdiv(groups, 8) * 8 * g.tiles_m;
+    const dim3 grid(g.whole_blocks + (tiles - g.whole) * g.ksplit, 1, 1);
+    if (g.whole < tiles && g.mode == 0)
+      hipLaunchKernelGGL(gemm_zero_tiles_kernel, dim3(tiles - g.whole), dim3(256), 0, st, g);
+    auto aligned = [](const float* p, bool kc, long srow, long sk, long sbatch, int rows) {
+      return kc ? (((uintptr_t)p & 15) == 0 && srow % 4 == 0 && sbatch % 4 == 0)
+                : (((uintptr_t)p & 15) == 0 && sk % 4 == 0 && sbatch % 4 == 0 && rows % 4 == 0);
+    };
+#ifdef SD_PROFILING
+    g.dbg = reinterpret_cast<long long*>(((uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_hi", 0) << 32) |
+                                         (uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_lo", 0));
+    g.dbg_cap = SD_PROF_TUNING("gemm_dbg_cap", 0);
+    g.ablate = SD_PROF_TUNING("gemm_ablate", 0);
+#endif
+    g.fast = aligned(g.A, ak, g.sam, g.sak, g.strideA, g.M) &&
+             aligned(g.B, bk, g.sbn, g.sbk, g.strideB, g.N);
+    int e;
+    if (ak && bk) e = launch_gemm_split<true, true>(g, grid, st);
+    else if (ak) e = launch_gemm_split<true, false>(g, grid, st);
+    else if (bk) e = launch_gemm_split<false, true>(g, grid, st);
+    else e = launch_gemm_split<false, false>(g, grid, st);
+    if (e) return e;
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+  }
   g.tiles_m = cdiv(g.M, BM);
   int J = tuning("deform_gemm_j", 0);
   if (J < 1 || J > 3) {

@@ -36,6 +36,8 @@ Knob g_knobs[] = {
     {"roi_align_fwd_padlds", 0, false},  // profiling build only: extra dynamic LDS bytes (occupancy sweep)
     {"roi_align_dbg_lo", 0, false},      // profiling build only: device buffer for per-wave phase clocks
     {"roi_align_dbg_hi", 0, false},
+    {"gemm_ablate", 0, false},           // profiling build only: skip the A (1) / B (2) prefetch of the split GEMM
+    {"gemm_dbg_cap", 0, false},          // profiling build only: waves the buffer above has room for (split GEMM)
 #endif
     {"roi_align_fwd_order", 0, false},   // 1: locality order of the RoIs (-25% L2-miss reads, same time; default 0)
     {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)
@@ -62,6 +64,8 @@ Knob g_knobs[] = {
     {"proposal_topk", 0, false},         // 0 by level size (default), 1 single workgroup, 2 multi-workgroup
     {"top_proposal_select", 0, false},   // 1 radix select before the sort when top_n < N (default)
     {"soft_nms_threads", 0, false},      // threads per problem: 64, 128 or 256 (default)
+    {"deform_gemm_split", 0, false}, // 1 (default): fp32 products as three bf16 MFMA terms (hi/lo split); 0: fp32 MFMA
+    {"deform_gemm_ksplit", 0, false},// 1 (default): tiles of a mostly empty last round are cut into k slices (atomic adds)
     {"deform_gemm_bk", 0, false},    // K extent of a GEMM tile: 16 (default) or 32
     {"deform_gemm_j", 0, false},     // GEMM tile width 64*J (1..3), 0 = by wave quantisation (default)
     {"dcn_im2col", 0, false},        // 1 LDS-plane im2col (default), 0 per-lane global gathers

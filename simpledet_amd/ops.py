@@ -714,7 +714,9 @@ def deform_col2im_coord(col, x, offset, kernel=(3, 3), pad=1, stride=1, dilate=1
 
 
 def gemm_f32(a, b, trans_a=False, trans_b=False, out=None, accumulate=0):
-    """Batched fp32 MFMA GEMM: a (Bt,M,K) or its transpose, b (Bt,K,N) or its transpose."""
+    """Batched fp32-in / fp32-out matrix-core GEMM: a (Bt,M,K) or its transpose, b (Bt,K,N) or its
+    transpose.  Products are three bf16 MFMA terms of a hi/lo split (4.5e-6 x max|C|) unless the
+    tuning key `deform_gemm_split` is 0 (fp32 MFMA); see include/simpledet_ops.h."""
     _chk(a, "a", ndim=3)
     _chk(b, "b", ndim=3)
     Bt = a.shape[0]

@@ -157,26 +157,69 @@ def test_lds_plane_kernels_equal_per_lane_kernels(ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", [1, 0])
 @pytest.mark.parametrize("shape", [(1, 128, 128, 16), (2, 256, 300, 72), (3, 70, 4200, 33),
-                                   (1, 1, 1, 1), (2, 129, 257, 17)])
-def test_mfma_gemm_all_layouts(ops, shape):
-    import torch
+                                   (1, 1, 1, 1), (2, 129, 257, 17), (2, 130, 258, 200), (1, 64, 132, 67)])
+def test_mfma_gemm_all_layouts(ops, shape, split):
+    """sd_gemm_f32 in its four operand layouts and three accumulate modes, on both matrix-core
+    paths: `deform_gemm_split` = 1 (default: fp32 products as three bf16 MFMA terms of a hi/lo
+    split, error bound 2^-16 per product) and 0 (fp32 MFMA).  Tolerances relative to max|C|:
+    2e-5 and 2e-6 (measured 6e-6 / 3e-7); shapes cover aligned and unaligned leading dimensions
+    (the vector-load path and the per-element path) and a k tail."""
+    from simpledet_amd._lib import lib
     Bt, M, N, K = shape
     rs = np.random.RandomState(0)
     A = rs.standard_normal((Bt, M, K)).astype(np.float32)
     B = rs.standard_normal((Bt, K, N)).astype(np.float32)
     want = np.einsum("bmk,bkn->bmn", A.astype(np.float64), B.astype(np.float64))
-    tol = 1e-4 * np.sqrt(K) * 4
-    for ta in (False, True):
-        for tb in (False, True):
-            a = _t(A.transpose(0, 2, 1).copy() if ta else A)
-            b = _t(B.transpose(0, 2, 1).copy() if tb else B)
-            got = ops.gemm_f32(a, b, ta, tb).cpu().numpy()
-            assert np.abs(got - want).max() <= tol, (ta, tb, np.abs(got - want).max())
-    # accumulate modes
-    c0 = rs.standard_normal((Bt, M, N)).astype(np.float32)
-    got = ops.gemm_f32(_t(A), _t(B), out=_t(c0), accumulate=1).cpu().numpy()
-    assert np.abs(got - (want + c0)).max() <= tol
+    tol = (2e-5 if split else 2e-6) * max(1.0, float(np.abs(want).max()))
+    lib().set_tuning("deform_gemm_split", split)
+    try:
+        for ta in (False, True):
+            for tb in (False, True):
+                a = _t(A.transpose(0, 2, 1).copy() if ta else A)
+                b = _t(B.transpose(0, 2, 1).copy() if tb else B)
+                got = ops.gemm_f32(a, b, ta, tb).cpu().numpy()
+                assert np.abs(got - want).max() <= tol, (ta, tb, np.abs(got - want).max())
+        # accumulate modes
+        c0 = rs.standard_normal((Bt, M, N)).astype(np.float32)
+        for mode in (1, 2):
+            got = ops.gemm_f32(_t(A), _t(B), out=_t(c0), accumulate=mode).cpu().numpy()
+            assert np.abs(got - (want + c0)).max() <= tol, mode
+    finally:
+        lib().set_tuning("deform_gemm_split", 1)
+
+
+@pytest.mark.gpu
+def test_gemm_k_slices_of_the_last_round(ops):
+    """528 tiles on 512 resident workgroups: the 16 tiles of the last round are cut into k slices
+    that add into zeroed C (store mode) or into C (accumulate modes); `deform_gemm_ksplit = 0`
+    keeps whole tiles.  Both agree with the fp64 product; garbage in C does not leak into the
+    store-mode result."""
+    import torch
+    from simpledet_amd._lib import lib
+    torch.manual_seed(3)
+    Bt, M, N, K = 33, 512, 512, 520  # 4 x 4 tiles per image; k tail of 8
+    A = torch.randn(Bt, M, K, device="cuda")
+    B = torch.randn(Bt, K, N, device="cuda")
+    want = torch.bmm(A.double(), B.double())
+    tol = 2e-5 * float(want.abs().max())
+    outs = []
+    for ks in (1, 0):
+        lib().set_tuning("deform_gemm_ksplit", ks)
+        try:
+            c = torch.full((Bt, M, N), float("nan"), device="cuda")
+            got = ops.gemm_f32(A, B, out=c)
+            assert float((got.double() - want).abs().max()) <= tol, ks
+            outs.append(got)
+            c0 = torch.randn(Bt, M, N, device="cuda")
+            for mode in (1, 2):
+                got = ops.gemm_f32(A, B, out=c0.clone(), accumulate=mode)
+                assert float((got.double() - want - c0.double()).abs().max()) <= tol, (ks, mode)
+        finally:
+            lib().set_tuning("deform_gemm_ksplit", 1)
+    # whole tiles are the same blocks in both modes
+    assert torch.equal(outs[0][:32], outs[1][:32])
 
 
 @pytest.mark.gpu
