@@ -216,6 +216,104 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
   for (int i = tid; i < band_elems; i += 256) d[i] = req_add ? d[i] + plane[i] : plane[i];
 }
 
+// The same gradient for CC channels of one deformable group at a time.  Where a col element lands
+// and with which four weights depends on (tap, pixel, group) only, and working that out (the
+// clamping chain of get_gradient_weight(), ~100 mostly divergent instructions) was the bulk of the
+// kernel above, which repeats it for every channel.  Here a workgroup keeps the row band of CC
+// channel planes in LDS, works the four (LDS index, weight) pairs out once per (tap, pixel) and
+// applies them to the CC col values -- read as 16-byte loads, four pixels per lane.
+//   grid: x = channel chunk, y = band, z = image; LDS = CC * band floats
+template <int CC, int T>
+__global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __restrict__ col,
+                                                                const float* __restrict__ offset,
+                                                                float* __restrict__ dx, DcnGeom g,
+                                                                int band_rows, int req_add) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];
+  const int P = g.Ho * g.Wo, K2 = g.kh * g.kw;
+  const int c0 = blockIdx.x * CC, n = blockIdx.z;
+  const int row0 = blockIdx.y * band_rows, row1 = iminr(row0 + band_rows, g.H);
+  const int band_elems = (row1 - row0) * g.W;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < CC * band_elems; i += T) plane[i] = 0.f;
+  __syncthreads();
+  const int cpg = g.C / g.dgroup, grp = c0 / cpg;
+  const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P;
+  const float* cp = col + ((long)n * g.C + c0) * K2 * P;
+  const long cstride = (long)K2 * P;  // col elements per channel
+  for (int tap = 0; tap < K2; ++tap) {
+    const int i = tap / g.kw, j = tap % g.kw;
+    const float* oh = off + (long)(2 * tap) * P;
+    const float* ow = oh + P;
+    const float* ct = cp + (long)tap * P;
+    for (int p4 = tid * 4; p4 < P; p4 += T * 4) {  // P % 4 == 0 (host)
+      const float4 ofh = *reinterpret_cast<const float4*>(oh + p4);
+      const float4 ofw = *reinterpret_cast<const float4*>(ow + p4);
+      float4 cv[CC];
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) cv[cc] = *reinterpret_cast<const float4*>(ct + cc * cstride + p4);
+      int h_out = p4 / g.Wo, w_out = p4 - h_out * g.Wo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float offset_h = e == 0 ? ofh.x : e == 1 ? ofh.y : e == 2 ? ofh.z : ofh.w;
+        const float offset_w = e == 0 ? ofw.x : e == 1 ? ofw.y : e == 2 ? ofw.z : ofw.w;
+        const int h_in = h_out * g.stride_h - g.pad_h, w_in = w_out * g.stride_w - g.pad_w;
+        if (++w_out == g.Wo) {
+          w_out = 0;
+          ++h_out;
+        }
+        const float inv_h = h_in + i * g.dil_h + offset_h;
+        const float inv_w = w_in + j * g.dil_w + offset_w;
+        // same arithmetic as deform_col2im_kernel above, as (index, weight) pairs
+        float ah = inv_h, aw = inv_w;
+        const bool inside = !(ah < 0 || ah > g.H || aw < 0 || aw > g.W);
+        int hl = (int)ah, wl = (int)aw, hh_, wh_;
+        if (hl >= g.H - 1) {
+          hh_ = hl = g.H - 1;
+          ah = (float)hl;
+        } else {
+          hh_ = hl + 1;
+        }
+        if (wl >= g.W - 1) {
+          wh_ = wl = g.W - 1;
+          aw = (float)wl;
+        } else {
+          wh_ = wl + 1;
+        }
+        const int fh = (int)floorf(inv_h), fw = (int)floorf(inv_w);
+        float fhv[2], fwv[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int hh = fh + d;
+          const bool ok = inside && hh >= 0 && hh < g.H && fabsf(inv_h - hh) < 1 && hh >= row0 && hh < row1;
+          fhv[d] = !ok ? 0.f : hh == hl ? (hh + 1 - ah) : hh == hh_ ? (ah + 1 - hh) : 0.f;
+          const int ww = fw + d;
+          const bool okw = ww >= 0 && ww < g.W && fabsf(inv_w - ww) < 1;
+          fwv[d] = !okw ? 0.f : ww == wl ? (ww + 1 - aw) : ww == wh_ ? (aw + 1 - ww) : 0.f;
+        }
+        const int base = (fh - row0) * g.W + fw;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float w = fhv[d >> 1] * fwv[d & 1];
+          if (w != 0.f) {
+            float* q = plane + base + (d >> 1) * g.W + (d & 1);
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+              const float gv = e == 0 ? cv[cc].x : e == 1 ? cv[cc].y : e == 2 ? cv[cc].z : cv[cc].w;
+              lds_add_cas(q + cc * band_elems, w * gv);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int cc = 0; cc < CC; ++cc) {
+    float* d = dx + (((long)n * g.C + c0 + cc) * g.H + row0) * g.W;
+    const float* pl = plane + cc * band_elems;
+    for (int i = tid; i < band_elems; i += T) d[i] = req_add ? d[i] + pl[i] : pl[i];
+  }
+}
+
 // grid: x = pixel tiles, y = offset channel (group, tap, dir), z = image
 __global__ __launch_bounds__(256) void deform_col2im_coord_kernel(const float* __restrict__ col,
                                                                   const float* __restrict__ x,
@@ -1226,6 +1324,28 @@ extern "C" int sd_deform_col2im(const float* col, const float* offset, float* dx
   if (N == 0 || req == SD_REQ_NULL) return SD_OK;
   SD_REQUIRE(col && offset && dx, "null tensor pointer");
   hipStream_t st = (hipStream_t)stream;
+  {
+    // four channels of a group per workgroup (the sample geometry is worked out once for them):
+    // bands of at most 72 KB for the four planes, two workgroups of 512 lanes per CU
+    constexpr int CC = 4, T = 512;
+    const int P = g.Ho * g.Wo;
+    const long budget4 = 72 * 1024;
+    int nb4 = (int)(((long)CC * H * W * 4 + budget4 - 1) / budget4);
+    const int rows4 = (H + nb4 - 1) / nb4;
+    nb4 = (H + rows4 - 1) / rows4;
+    if (tuning("dcn_col2im", 1) == 1 && (C / dgroup) % CC == 0 && P % 4 == 0 &&
+        (((uintptr_t)col | (uintptr_t)offset) & 15) == 0 && (long)CC * rows4 * W * 4 <= 150 * 1024 &&
+        nb4 <= 65535) {
+      const size_t lds4 = (size_t)CC * rows4 * W * sizeof(float);
+      if (lds4 > 64 * 1024)
+        SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+      hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
+                         col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0);
+      SD_LAUNCH_CHECK();
+      return SD_OK;
+    }
+  }
   // row bands of at most 36 KB so that four workgroups share a CU
   const long budget = 36 * 1024;
   int nb = (int)(((long)H * W * 4 + budget - 1) / budget);

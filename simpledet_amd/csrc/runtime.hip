@@ -72,6 +72,7 @@ Knob g_knobs[] = {
     {"dcn_im2col_split", 0, false},  // channel splits per (image, group, pixel tile), default 1
     {"dcn_im2col_nt", 0, false},     // bit 0: non-temporal col stores (default 1); bits 1-2 exist in the profiling build only
     {"dcn_window", 0, false},        // 1 stage only the touched range of each plane (default)
+    {"dcn_col2im", 0, false},        // 1 four channels per workgroup, shared sample geometry (default), 0 one channel
     {"dcn_coord", 0, false},         // 1 LDS-plane offset gradient (default), 0 per-lane gathers
 };
 }  // namespace
