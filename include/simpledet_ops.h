@@ -49,8 +49,10 @@ const char* sd_last_error(void);
  * size).  History: 1 round 1; 2 packed arg-max rows padded to whole dwords (7x7: 49 -> 52 bytes)
  * and 4-byte aligned; 3 sd_fpn_roi_align_workspace_bytes grew (the forward's band lists / tap
  * entries live in the workspace; with a smaller or NULL workspace the forward still runs, on the
- * slower tiled kernels).  sd_abi_version() returns the library's value; compare with this macro. */
-#define SD_ABI_VERSION 3
+ * slower tiled kernels); 4 sd_gemm_f32 computes products as three bf16 MFMA terms by default
+ * (same signature, documented error model), sd_proposal_mask_target_ratio / sd_cast_* / *_f16 added.
+ * sd_abi_version() returns the library's value; compare with this macro. */
+#define SD_ABI_VERSION 4
 int sd_abi_version(void);
 /* kernel-variant knobs for A/B measurements (bench.py, tests); every variant computes the same
  * result.  Unknown keys are an error.  Knobs that disable parts of a kernel for profiling exist
@@ -267,7 +269,7 @@ int sd_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
  *   gt_polys (B,M,L) DEVICE, per gt box [category, n_seg, len_1..len_n, x,y,x,y,...] padded with -1
  *   mask_target (B, FG, mask_size, mask_size), FG = (int)(image_rois * fg_fraction): rows of the
  *   sampled foreground RoIs hold the 0/1 mask of their gt polygon in the RoI's frame, the rest -1.
- *   output_ratio (mask-scoring R-CNN only) is not provided. */
+ *   output_ratio = false; the _ratio entry below is output_ratio = true. */
 int sd_proposal_mask_target(const float* rois, const float* gt_boxes, const float* gt_polys,
                             const float* valid_ranges, int filter_scales, int N, int M, int L,
                             int mask_size, const sd_proposal_target_param* param_host,
@@ -275,6 +277,28 @@ int sd_proposal_mask_target(const float* rois, const float* gt_boxes, const floa
                             float* bbox_weight, float* match_gt_iou, float* mask_target,
                             int32_t* kept_index, void* workspace, size_t workspace_bytes,
                             void* stream);
+/* ProposalMaskTarget with output_ratio = true (mask scoring R-CNN, models/msrcnn/builder.py:219-237)
+ *   replaces convertPoly2MaskWithRatio  operator_cxx/proposal_mask_target.cc:20-152 (called :368-372)
+ *   and the seventh output of ProposalMaskTargetOp  proposal_mask_target-inl.h:244,333-336,453-456
+ *   mask_ratio (B, FG): for the sampled foreground rows, the pixels of the gt polygon inside the RoI
+ *   (rasterised at image resolution, RoI corners truncated to int) over its pixels inside the
+ *   bounding box of RoI and polygon, max(crop / (full + 1e-4), 1e-10); 0 for the other rows.  The
+ *   mask itself is computed with the double coordinates of that function (:53-63) -- it can differ
+ *   from output_ratio = false in a rounding case, as in the reference.
+ *   max_raster_pixels bounds crop_h * crop_w and full_h * full_w (the image area suffices when RoIs
+ *   and polygons lie inside the image); a row whose raster is larger gets NaN.
+ *   workspace: sd_proposal_mask_target_ratio_workspace_bytes(B, N, M, image_rois, fg_fraction,
+ *   max_raster_pixels) bytes (two bitmaps of max_raster_pixels bits per foreground row). */
+size_t sd_proposal_mask_target_ratio_workspace_bytes(int B, int N, int M, int image_rois,
+                                                     float fg_fraction, int max_raster_pixels);
+int sd_proposal_mask_target_ratio(const float* rois, const float* gt_boxes, const float* gt_polys,
+                                  const float* valid_ranges, int filter_scales, int N, int M, int L,
+                                  int mask_size, const sd_proposal_target_param* param_host,
+                                  int32_t* rng_state, float* roi_output, float* label,
+                                  float* bbox_target, float* bbox_weight, float* match_gt_iou,
+                                  float* mask_target, float* mask_ratio, int max_raster_pixels,
+                                  int32_t* kept_index, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 int sd_proposal_target_v2(const float* rois, const float* gt_boxes, const float* valid_ranges,
                           int filter_scales, int N, int M,
                           const sd_proposal_target_param* param_host, int32_t* rng_state,
@@ -291,6 +315,9 @@ int sd_proposal_target_v2(const float* rois, const float* gt_boxes, const float*
  *   zero padded.  keep_index (B,post) int32 optional: original row of every kept box, -1 pad.
  *   threshold_ge = 0: suppress IoU > threshold (nms.cu:140); 1: IoU >= threshold
  *   (proposal_v3.cu:319).  The sort is stable (ties keep the lower input row first).
+ *   Sizes: pre <= 16384 (one LDS sort; the bit matrix is pre^2 / 8 bytes).  N itself is free
+ *   (< 2^24): with more than 16384 unsorted rows the pre best are picked by a radix select and
+ *   only they are sorted -- the rows nms.cu:311-313 keeps of its full sort (:303).
  *   workspace: DEVICE scratch of sd_nms_workspace_bytes(B, N, pre_nms_top_n) bytes.
  * ---------------------------------------------------------------------------------------------- */
 size_t sd_nms_workspace_bytes(int B, int N, int pre_nms_top_n);

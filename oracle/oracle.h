@@ -87,13 +87,21 @@ int orc_proposal_target_v2(const float* rois, const float* gt_boxes, const float
                            int filter_scales, int N, int M, const orc_proposal_target_param* p,
                            orc_glibc_rand* rng, float* roi_out, float* label, float* bbox_target,
                            float* bbox_weight, float* match_gt_iou, int* kept_index);
-/* ProposalMaskTarget (proposal_mask_target-inl.h / .cc), output_ratio = false */
+/* ProposalMaskTarget (proposal_mask_target-inl.h / .cc), output_ratio = false (the _ratio variant below: true) */
 int orc_proposal_mask_target(const float* rois, const float* gt_boxes, const float* gt_polys,
                              const float* valid_ranges, int filter_scales, int N, int M, int L,
                              int mask_size, const orc_proposal_target_param* p, orc_glibc_rand* rng,
                              float* roi_out, float* label, float* bbox_target, float* bbox_weight,
                              float* match_gt_iou, int* kept_index, float* mask_target);
 int orc_poly2mask(const float* roi, const float* poly, int mask_size, float* mask);
+/* output_ratio = true (proposal_mask_target.cc:20-152, 368-372): + mask_ratio (B, FG) */
+int orc_proposal_mask_target_ratio(const float* rois, const float* gt_boxes, const float* gt_polys,
+                                   const float* valid_ranges, int filter_scales, int N, int M, int L,
+                                   int mask_size, const orc_proposal_target_param* p,
+                                   orc_glibc_rand* rng, float* roi_out, float* label,
+                                   float* bbox_target, float* bbox_weight, float* match_gt_iou,
+                                   int* kept_index, float* mask_target, float* mask_ratio);
+int orc_poly2mask_ratio(const float* roi, const float* poly, int mask_size, float* mask, double* ratio);
 int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, int M,
                              const orc_proposal_target_param* p, float* roi_out, float* label,
                              float* bbox_target, float* bbox_weight, float* match_gt_iou,

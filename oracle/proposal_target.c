@@ -235,6 +235,97 @@ static void convert_poly2mask(const float* roi, const float* poly, int mask_size
   free(bm);
 }
 
+/* convertPoly2MaskWithRatio, operator_cxx/proposal_mask_target.cc:20-152 (output_ratio = true, the
+ * mask-scoring R-CNN heads: models/msrcnn/builder.py:219-237).  Besides the mask it rasterises the
+ * polygon twice at image resolution -- inside the RoI (crop_h x crop_w, RoI corners truncated to
+ * int) and inside the bounding box of RoI and polygon (full_h x full_w) -- and returns
+ * max(crop_pixels / (full_pixels + 1e-4), 1e-10).  NOTE the mask itself is computed here with
+ * DOUBLE coordinates (`double poly_index`, :53-63) where convertPoly2Mask uses DType. */
+static double convert_poly2mask_with_ratio(const float* roi, const float* poly, int mask_size,
+                                           float* mask) {
+  float w = roi[2] - roi[0], h = roi[3] - roi[1];
+  w = fmax2(1.f, w);
+  h = fmax2(1.f, h);
+  int n_seg = (int)poly[1];
+  if (n_seg < 0) n_seg = 0;
+  RLE *rles, *rles_origin, *rles_crop;
+  rlesInit(&rles, (siz)n_seg);
+  rlesInit(&rles_origin, (siz)n_seg);
+  rlesInit(&rles_crop, (siz)n_seg);
+  const int roi_x_1 = (int)roi[0], roi_x_2 = (int)roi[2], roi_y_1 = (int)roi[1], roi_y_2 = (int)roi[3];
+  const int crop_w = roi_x_2 - roi_x_1 + 1, crop_h = roi_y_2 - roi_y_1 + 1;
+  int offset = 2 + n_seg;
+  double origin_x_1 = roi[0], origin_x_2 = roi[2], origin_y_1 = roi[1], origin_y_2 = roi[3];
+  for (int i = 0; i < n_seg; i++) {
+    int cur_len = (int)poly[i + 2];
+    double* xys = (double*)malloc(sizeof(double) * (cur_len > 0 ? cur_len : 1));
+    double* xys_crop = (double*)malloc(sizeof(double) * (cur_len > 0 ? cur_len + 1 : 2));
+    for (int j = 0; j < cur_len; j++) { /* (an odd cur_len writes one past the reference's buffer) */
+      if (j % 2 == 0) {
+        double poly_index = poly[offset + j + 1];
+        origin_y_1 = origin_y_1 < poly_index ? origin_y_1 : poly_index;
+        origin_y_2 = origin_y_2 > poly_index ? origin_y_2 : poly_index;
+        xys[j] = (poly_index - roi[1]) * mask_size / h;
+        xys_crop[j + 1] = poly_index - roi[1];
+      } else {
+        double poly_index = poly[offset + j - 1];
+        origin_x_1 = origin_x_1 < poly_index ? origin_x_1 : poly_index;
+        origin_x_2 = origin_x_2 > poly_index ? origin_x_2 : poly_index;
+        xys[j] = (poly_index - roi[0]) * mask_size / w;
+        xys_crop[j - 1] = poly_index - roi[0];
+      }
+    }
+    rleFrPoly(rles + i, xys, (siz)(cur_len / 2), (siz)mask_size, (siz)mask_size);
+    rleFrPoly(rles_crop + i, xys_crop, (siz)(cur_len / 2), (siz)crop_h, (siz)crop_w);
+    free(xys);
+    free(xys_crop);
+    offset += cur_len;
+  }
+  const int int_x_1 = (int)origin_x_1, int_x_2 = (int)origin_x_2, int_y_1 = (int)origin_y_1,
+            int_y_2 = (int)origin_y_2;
+  const int full_w = int_x_2 - int_x_1 + 1, full_h = int_y_2 - int_y_1 + 1;
+  offset = 2 + n_seg;
+  for (int i = 0; i < n_seg; i++) {
+    int cur_len = (int)poly[i + 2];
+    double* xys_origin = (double*)malloc(sizeof(double) * (cur_len > 0 ? cur_len + 1 : 2));
+    for (int j = 0; j < cur_len; j++) {
+      if (j % 2 == 0) xys_origin[j + 1] = (double)poly[offset + j + 1] - origin_y_1;
+      else xys_origin[j - 1] = (double)poly[offset + j - 1] - origin_x_1;
+    }
+    rleFrPoly(rles_origin + i, xys_origin, (siz)(cur_len / 2), (siz)full_h, (siz)full_w);
+    free(xys_origin);
+    offset += cur_len;
+  }
+  const int area = mask_size * mask_size;
+  const size_t nfull = (size_t)full_w * full_h, ncrop = (size_t)crop_w * crop_h;
+  byte* bm = (byte*)malloc((size_t)area * (n_seg > 0 ? n_seg : 1));
+  byte* bo = (byte*)calloc(nfull * (n_seg > 0 ? n_seg : 1) + 1, 1);
+  byte* bc = (byte*)calloc(ncrop * (n_seg > 0 ? n_seg : 1) + 1, 1);
+  rleDecode(rles, bm, (siz)n_seg);
+  rleDecode(rles_origin, bo, (siz)n_seg);
+  rleDecode(rles_crop, bc, (siz)n_seg);
+  for (int j = 0; j < area; j++) {
+    float cur = 0;
+    for (int i = 0; i < n_seg; i++)
+      if (bm[(size_t)i * area + j] == 1) { cur = 1; break; }
+    mask[j] = cur;
+  }
+  double origin_mask_sum = 0, crop_mask_sum = 0;
+  for (size_t i = 0; i < nfull; i++)
+    for (int sgi = 0; sgi < n_seg; sgi++)
+      if (bo[(size_t)sgi * nfull + i] == 1) { origin_mask_sum += 1; break; }
+  for (size_t i = 0; i < ncrop; i++)
+    for (int sgi = 0; sgi < n_seg; sgi++)
+      if (bc[(size_t)sgi * ncrop + i] == 1) { crop_mask_sum += 1; break; }
+  double mask_ratio = crop_mask_sum / (origin_mask_sum + 0.0001);
+  mask_ratio = mask_ratio > 1e-10 ? mask_ratio : 1e-10;
+  rlesFree(&rles, (siz)n_seg);
+  rlesFree(&rles_origin, (siz)n_seg);
+  rlesFree(&rles_crop, (siz)n_seg);
+  free(bm); free(bo); free(bc);
+  return mask_ratio;
+}
+
 /* valid_ranges selects the v2 / mask-target front end; gt_polys != NULL adds ProposalMaskTarget's
  * mask output (proposal_mask_target-inl.h:141-330, proposal_mask_target.cc:218-378):
  * mask_target (B, FG, ms, ms) with FG = (index_t)(image_rois * fg_fraction), -1 filled, rows
@@ -244,7 +335,8 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
                                 const orc_proposal_target_param* p, rand_fn rf, void* rs,
                                 float* roi_out, float* label, float* bbox_target,
                                 float* bbox_weight, float* match_gt_iou, int* kept_index,
-                                const float* gt_polys, int L, int mask_size, float* mask_target) {
+                                const float* gt_polys, int L, int mask_size, float* mask_target,
+                                float* mask_ratio /* non-NULL: output_ratio = true */) {
   const int B = p->batch_images, S = p->image_rois, K4 = 4 * p->num_classes;
   int rc = 0;
   /* outputs are zero-initialised containers (proposal_target-inl.h:189-193) */
@@ -304,15 +396,25 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
     if (mask_target && !no_gt) /* an image without gt has one all -1 polygon row: nothing to draw
                                   (and no roi reaches fg_thresh against the 1-pixel zero box ... if one
                                   does, n_seg = -1 draws an all-zero mask; restated in the else branch) */
-      for (unsigned r = 0; r < fg_this && r < (unsigned)FG; ++r)
-        convert_poly2mask(roi_out + ((size_t)i * S + r) * 4,
-                          gt_polys + ((size_t)i * M + gt_src[gt_of_row[r]]) * L, mask_size,
-                          mask_target + ((size_t)i * FG + r) * mask_size * mask_size);
+      for (unsigned r = 0; r < fg_this && r < (unsigned)FG; ++r) {
+        const float* roi = roi_out + ((size_t)i * S + r) * 4;
+        const float* poly = gt_polys + ((size_t)i * M + gt_src[gt_of_row[r]]) * L;
+        float* m = mask_target + ((size_t)i * FG + r) * mask_size * mask_size;
+        if (mask_ratio) /* proposal_mask_target.cc:368-372 */
+          mask_ratio[(size_t)i * FG + r] = (float)convert_poly2mask_with_ratio(roi, poly, mask_size, m);
+        else
+          convert_poly2mask(roi, poly, mask_size, m);
+      }
     else if (mask_target) {
       float neg1[4] = {-1.f, -1.f, -1.f, -1.f};
-      for (unsigned r = 0; r < fg_this && r < (unsigned)FG; ++r)
-        convert_poly2mask(roi_out + ((size_t)i * S + r) * 4, neg1, mask_size,
-                          mask_target + ((size_t)i * FG + r) * mask_size * mask_size);
+      for (unsigned r = 0; r < fg_this && r < (unsigned)FG; ++r) {
+        const float* roi = roi_out + ((size_t)i * S + r) * 4;
+        float* m = mask_target + ((size_t)i * FG + r) * mask_size * mask_size;
+        if (mask_ratio)
+          mask_ratio[(size_t)i * FG + r] = (float)convert_poly2mask_with_ratio(roi, neg1, mask_size, m);
+        else
+          convert_poly2mask(roi, neg1, mask_size, m);
+      }
     }
   }
   free(kept_rois); free(kept_gt); free(gt_src); free(gt_of_row);
@@ -324,7 +426,7 @@ int orc_proposal_target(const float* rois, const float* gt_boxes, int N, int M,
                         float* label, float* bbox_target, float* bbox_weight, float* match_gt_iou,
                         int* kept_index) {
   return proposal_target_impl(rois, gt_boxes, NULL, 0, N, M, p, rand_state, rng, roi_out, label,
-                              bbox_target, bbox_weight, match_gt_iou, kept_index, NULL, 0, 0, NULL);
+                              bbox_target, bbox_weight, match_gt_iou, kept_index, NULL, 0, 0, NULL, NULL);
 }
 
 /* ProposalMaskTarget without output_ratio.  valid_ranges may be NULL (num_args = 3). */
@@ -336,7 +438,29 @@ int orc_proposal_mask_target(const float* rois, const float* gt_boxes, const flo
   if (p->image_rois < 0 || !gt_polys || !mask_target) return -2;
   return proposal_target_impl(rois, gt_boxes, valid_ranges, valid_ranges ? filter_scales : 0, N, M, p,
                               rand_state, rng, roi_out, label, bbox_target, bbox_weight,
-                              match_gt_iou, kept_index, gt_polys, L, mask_size, mask_target);
+                              match_gt_iou, kept_index, gt_polys, L, mask_size, mask_target, NULL);
+}
+
+/* ProposalMaskTarget with output_ratio = true: the seventh output mask_ratio (B, FG), zero filled
+ * (proposal_mask_target-inl.h:244), rows [0, fg_rois_this_image) computed. */
+int orc_proposal_mask_target_ratio(const float* rois, const float* gt_boxes, const float* gt_polys,
+                                   const float* valid_ranges, int filter_scales, int N, int M, int L,
+                                   int mask_size, const orc_proposal_target_param* p,
+                                   orc_glibc_rand* rng, float* roi_out, float* label,
+                                   float* bbox_target, float* bbox_weight, float* match_gt_iou,
+                                   int* kept_index, float* mask_target, float* mask_ratio) {
+  if (p->image_rois < 0 || !gt_polys || !mask_target || !mask_ratio) return -2;
+  const int FG = (int)(p->image_rois * p->fg_fraction);
+  memset(mask_ratio, 0, sizeof(float) * (size_t)p->batch_images * (FG > 0 ? FG : 0));
+  return proposal_target_impl(rois, gt_boxes, valid_ranges, valid_ranges ? filter_scales : 0, N, M, p,
+                              rand_state, rng, roi_out, label, bbox_target, bbox_weight,
+                              match_gt_iou, kept_index, gt_polys, L, mask_size, mask_target,
+                              mask_ratio);
+}
+
+int orc_poly2mask_ratio(const float* roi, const float* poly, int mask_size, float* mask, double* ratio) {
+  *ratio = convert_poly2mask_with_ratio(roi, poly, mask_size, mask);
+  return 0;
 }
 
 int orc_poly2mask(const float* roi, const float* poly, int mask_size, float* mask) {
@@ -351,7 +475,7 @@ int orc_proposal_target_v2(const float* rois, const float* gt_boxes, const float
   if (p->image_rois < 0 || !valid_ranges) return -2;
   return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, N, M, p, rand_state, rng,
                               roi_out, label, bbox_target, bbox_weight, match_gt_iou, kept_index,
-                              NULL, 0, 0, NULL);
+                              NULL, 0, 0, NULL, NULL);
 }
 
 int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, int M,
@@ -359,5 +483,5 @@ int orc_proposal_target_libc(const float* rois, const float* gt_boxes, int N, in
                              float* bbox_target, float* bbox_weight, float* match_gt_iou,
                              int* kept_index) {
   return proposal_target_impl(rois, gt_boxes, NULL, 0, N, M, p, rand_libc, NULL, roi_out, label,
-                              bbox_target, bbox_weight, match_gt_iou, kept_index, NULL, 0, 0, NULL);
+                              bbox_target, bbox_weight, match_gt_iou, kept_index, NULL, 0, 0, NULL, NULL);
 }

@@ -254,8 +254,9 @@ def proposal_target(rois, gt_boxes, param, rng=None, use_libc=False, valid_range
 
 
 def proposal_mask_target(rois, gt_boxes, gt_polys, param, mask_size=28, rng=None, valid_ranges=None,
-                         filter_scales=False):
-    """ProposalMaskTarget (output_ratio=False): the six outputs + kept_index."""
+                         filter_scales=False, output_ratio=False):
+    """ProposalMaskTarget: the six outputs + kept_index; with output_ratio=True the mask ratio
+    (B, FG) of proposal_mask_target.cc:20-152 is appended after kept_index."""
     rois, pr = _f(rois)
     gt, pg = _f(gt_boxes)
     polys, pp = _f(gt_polys)
@@ -275,6 +276,13 @@ def proposal_mask_target(rois, gt_boxes, gt_polys, param, mask_size=28, rng=None
         vr, pv = _f(valid_ranges)
     if rng is None:
         rng = GlibcRand(1)
+    if output_ratio:
+        ratio = np.empty((B, FG), np.float32)
+        cdll().orc_proposal_mask_target_ratio(pr, pg, pp, pv, int(filter_scales), N, M, L, int(mask_size),
+                                              ctypes.byref(param), ctypes.byref(rng), ro.ctypes, lb.ctypes,
+                                              bt.ctypes, bw.ctypes, iou.ctypes, kept.ctypes, mask.ctypes,
+                                              ratio.ctypes)
+        return ro, lb, bt, bw, iou, mask, kept, ratio
     cdll().orc_proposal_mask_target(pr, pg, pp, pv, int(filter_scales), N, M, L, int(mask_size),
                                     ctypes.byref(param), ctypes.byref(rng), ro.ctypes, lb.ctypes,
                                     bt.ctypes, bw.ctypes, iou.ctypes, kept.ctypes, mask.ctypes)
@@ -287,6 +295,15 @@ def poly2mask(roi, poly, mask_size=28):
     m = np.empty((mask_size, mask_size), np.float32)
     cdll().orc_poly2mask(pr, pp, int(mask_size), m.ctypes)
     return m
+
+
+def poly2mask_ratio(roi, poly, mask_size=28):
+    roi, pr = _f(roi)
+    poly, pp = _f(poly)
+    m = np.empty((mask_size, mask_size), np.float32)
+    r = ctypes.c_double(0)
+    cdll().orc_poly2mask_ratio(pr, pp, int(mask_size), m.ctypes, ctypes.byref(r))
+    return m, r.value
 
 
 def std_random_shuffle(a):

@@ -519,11 +519,12 @@ __device__ __forceinline__ void proposal_gather_filter(const PropArgs& a, int im
 // key, a second select on the row index when the ties at that key are only partly taken, unordered
 // compaction of the selected rows into composite (key, row) words and an LDS sort of the P2 >= pre
 // words.  keys[0 .. pre) end up in the order of a stable descending sort.
+template <int STRIDE = 1>  // score of row i at sc[i * STRIDE]
 __device__ __forceinline__ void select_sort_topk(const float* __restrict__ sc, int count, int pre,
                                                  int P2, unsigned long long* keys, int* hist,
                                                  int* ncand) {
   const int tid = threadIdx.x, T = blockDim.x;
-  auto skey = [&](int i) { return ordered_desc_bits(sc[i]); };  // ascending key = best score first
+  auto skey = [&](int i) { return ordered_desc_bits(sc[(long)i * STRIDE]); };  // ascending key = best score first
   // ---- the pre-th smallest score key ----
   unsigned prefix = 0, mask = 0;
   int want = pre, last_bucket = 0;
@@ -585,6 +586,27 @@ __global__ __launch_bounds__(1024) void proposal_topk_kernel(PropArgs a) {
   const int img = blockIdx.x;
   select_sort_topk(a.score_all + (long)img * a.count, a.count, a.pre, a.P2, keys, hist, &ncand);
   proposal_gather_filter(a, img, keys, threadIdx.x, blockDim.x);
+}
+
+// _contrib_NMS with more rows than the LDS sort holds (nms.cu:303 sorts any N): only the first
+// pre_nms_top_n rows of the sorted order are ever used (nms.cu:311-313), so they are selected by
+// the radix select above (scores at stride 5 inside the (N, 5) rows) and only they are sorted.
+__global__ __launch_bounds__(1024) void nms_select_sort_kernel(SortArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // P2 >= pre words
+  __shared__ int hist[260];
+  __shared__ int ncand;
+  const int img = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const float* d = a.dets + (long)img * a.N * 5;
+  select_sort_topk<5>(d + 4, a.N, a.pre, a.P2, keys, hist, &ncand);
+  __syncthreads();
+  for (int i = tid; i < a.pre; i += T) {
+    const int src = (int)(unsigned)(keys[i] & 0xffffffffu);
+    const float* p = d + (long)src * 5;
+    const long o = (long)img * a.pre + i;
+    a.ws.order[o] = src;
+    a.ws.boxes[o] = make_float4(p[0], p[1], p[2], p[3]);
+    a.ws.score[o] = p[4];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -819,10 +841,17 @@ extern "C" int sd_nms(const float* dets, int B, int N, int pre_nms_top_n, int po
   SD_REQUIRE(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
   int P2 = 1;
   while (P2 < N) P2 <<= 1;
-  if (!already_sorted && P2 > kMaxSortKeys)
-    return fail(SD_ERR_UNSUPPORTED, "NMS: N=%d exceeds the in-LDS sort capacity (%d); pass "
-                "already_sorted=1 with pre-sorted input", N, kMaxSortKeys);
+  // more rows than one LDS sort holds: select the pre_nms_top_n best first (pre < N), sort those
+  const bool select = !already_sorted && P2 > kMaxSortKeys;
+  if (select && pre > kMaxSortKeys)
+    return fail(SD_ERR_UNSUPPORTED, "NMS: N=%d unsorted rows need pre_nms_top_n <= %d (the in-LDS "
+                "sort capacity; got %d), or already_sorted=1 with pre-sorted input", N, kMaxSortKeys, pre);
   SD_REQUIRE(pre <= kMaxSortKeys, "NMS: pre_nms_top_n=%d exceeds %d", pre, kMaxSortKeys);
+  SD_REQUIRE(N < (1 << 24), "NMS: N=%d rows per image exceed 2^24", N);
+  if (select) {
+    P2 = 1;
+    while (P2 < pre) P2 <<= 1;
+  }
   NmsWs ws;
   char* base = reinterpret_cast<char*>(align_up((size_t)(uintptr_t)workspace, 256));
   const size_t need = nms_layout(B, pre, nb, &ws, base) + (size_t)(base - (char*)workspace);
@@ -836,7 +865,14 @@ extern "C" int sd_nms(const float* dets, int B, int N, int pre_nms_top_n, int po
     SD_HIP_CHECK(hipFuncSetAttribute((const void*)nms_sort_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int sort_threads = P2 / 2 >= 1024 ? 1024 : (P2 / 2 >= 64 ? P2 / 2 : 64);
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(sort_threads), lds, st, sa);
+  if (select) {
+    if (lds > 64 * 1024)
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)nms_select_sort_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(nms_select_sort_kernel, dim3(B), dim3(1024), lds, st, sa);
+  } else {
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(sort_threads), lds, st, sa);
+  }
   SD_LAUNCH_CHECK();
 
   MaskArgs ma{ws, pre, nb, nb * (nb + 1) / 2, threshold, threshold_ge};

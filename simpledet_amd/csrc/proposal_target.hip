@@ -47,6 +47,9 @@ struct PtArgs {
   int v2;                     // v2 / MaskTarget: an empty roi / gt list is replaced by one zero row
   const float* polys;         // ProposalMaskTarget: (B, M, L) gt polygons, or null
   float* mask_out;            // (B, FG, ms, ms)
+  float* ratio_out;           // output_ratio: (B, FG) mask ratio, or null
+  unsigned long long* bits;   // output_ratio: per fg row 2 x bit_words words (toggle / union bitmaps)
+  int bit_words;              // words per bitmap = ceil(max_raster_pixels / 64)
   int L, mask_size, FG;
   PtWs ws;
   sd_proposal_target_param p;
@@ -557,10 +560,17 @@ __global__ __launch_bounds__(kMaskThreads) void pt_mask_kernel(PtArgs a) {
     // vertices in the RoI's mask frame, x5, rounded: "x" of the mask API = row coordinate
     for (int t = tid; t < k; t += kMaskThreads) {
       const float px = poly[offset + 2 * t], py = poly[offset + 2 * t + 1];
-      const float fy = (py - roi.y) * (float)ms / h;  // xys[2t]
-      const float fx = (px - roi.x) * (float)ms / w;  // xys[2t+1]
-      vx[t] = (int)(5.0 * (double)fy + .5);
-      vy[t] = (int)(5.0 * (double)fx + .5);
+      if (a.ratio_out) {  // convertPoly2MaskWithRatio: `double poly_index` (:53-63)
+        const double fy = ((double)py - (double)roi.y) * (double)ms / (double)h;
+        const double fx = ((double)px - (double)roi.x) * (double)ms / (double)w;
+        vx[t] = (int)(5.0 * fy + .5);
+        vy[t] = (int)(5.0 * fx + .5);
+      } else {
+        const float fy = (py - roi.y) * (float)ms / h;  // xys[2t]
+        const float fx = (px - roi.x) * (float)ms / w;  // xys[2t+1]
+        vx[t] = (int)(5.0 * (double)fy + .5);
+        vy[t] = (int)(5.0 * (double)fx + .5);
+      }
     }
     __syncthreads();
     if (tid == 0 && k > 0) { vx[k] = vx[0]; vy[k] = vy[0]; }
@@ -637,6 +647,206 @@ __global__ __launch_bounds__(kMaskThreads) void pt_mask_kernel(PtArgs a) {
     offset += cur_len;
   }
   for (int j = tid; j < area; j += kMaskThreads) out[j] = acc[j] ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// output_ratio (mask scoring R-CNN, models/msrcnn/builder.py:219-237): convertPoly2MaskWithRatio,
+// proposal_mask_target.cc:20-152.  Besides the mask, the polygon is rasterised at image resolution
+// inside the RoI (crop_h x crop_w, corners truncated to int) and inside the bounding box of RoI and
+// polygon (full_h x full_w); the ratio is crop pixels / (full pixels + 1e-4), at least 1e-10.
+// Those rasters are up to the image size, so the crossing bitmap of pt_mask_kernel moves to global
+// memory, one bit per pixel: toggles by 64-bit atomic xor, and every lane owns a contiguous run of
+// words for zeroing, the prefix parity (word parities scanned across the workgroup, a shift-xor
+// ladder inside the word), the OR over the segments and the final popcount.  A raster larger than
+// the caller's bound (max_raster_pixels) yields NaN for that row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kMaskThreads) void pt_mask_ratio_kernel(PtArgs a) {
+  __shared__ int vx[kMaskMaxVerts + 1], vy[kMaskMaxVerts + 1], start[kMaskMaxVerts + 1];
+  __shared__ int wave_sums[kMaskThreads / kWave];
+  __shared__ int s_total;
+  __shared__ double s_red[4][kMaskThreads / kWave];
+  __shared__ int s_par[kMaskThreads];
+  const int row = blockIdx.x, img = row / a.FG, slot = row % a.FG, tid = threadIdx.x;
+  const int* c = a.ws.counts + img * 8;
+  const int fg_this = c[5];
+  if (slot >= fg_this) {  // -inl.h:244: zero filled
+    if (tid == 0) a.ratio_out[row] = 0.f;
+    return;
+  }
+  const int kidx = a.ws.kept[(long)img * a.S + slot];
+  const int g = a.ws.gta[(long)img * a.Ncand + kidx];
+  const int src = a.ws.gtsrc[(long)img * a.Mws + g];
+  const float4 roi = reinterpret_cast<const float4*>(a.roi_out)[(long)img * a.S + slot];
+  const float* poly = src >= 0 ? a.polys + ((long)img * a.M + src) * a.L : nullptr;
+  int n_seg = poly ? (int)poly[1] : 0;
+  if (n_seg < 0) n_seg = 0;
+  // :46-66 bounding box of RoI and polygon, in double
+  double bx1 = (double)roi.x, bx2 = (double)roi.z, by1 = (double)roi.y, by2 = (double)roi.w;
+  {
+    int offset = 2 + n_seg;
+    for (int sgi = 0; sgi < n_seg; ++sgi) {
+      const int cur_len = (int)poly[sgi + 2];
+      for (int t = tid; t < cur_len / 2; t += kMaskThreads) {
+        const double px = (double)poly[offset + 2 * t], py = (double)poly[offset + 2 * t + 1];
+        bx1 = px < bx1 ? px : bx1; bx2 = px > bx2 ? px : bx2;
+        by1 = py < by1 ? py : by1; by2 = py > by2 ? py : by2;
+      }
+      offset += cur_len;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      const double t1 = __shfl_xor(bx1, o), t2 = __shfl_xor(bx2, o), t3 = __shfl_xor(by1, o), t4 = __shfl_xor(by2, o);
+      bx1 = t1 < bx1 ? t1 : bx1; bx2 = t2 > bx2 ? t2 : bx2;
+      by1 = t3 < by1 ? t3 : by1; by2 = t4 > by2 ? t4 : by2;
+    }
+    if ((tid & (kWave - 1)) == 0) {
+      s_red[0][tid / kWave] = bx1; s_red[1][tid / kWave] = bx2;
+      s_red[2][tid / kWave] = by1; s_red[3][tid / kWave] = by2;
+    }
+    __syncthreads();
+    for (int wv = 0; wv < kMaskThreads / kWave; ++wv) {
+      bx1 = s_red[0][wv] < bx1 ? s_red[0][wv] : bx1; bx2 = s_red[1][wv] > bx2 ? s_red[1][wv] : bx2;
+      by1 = s_red[2][wv] < by1 ? s_red[2][wv] : by1; by2 = s_red[3][wv] > by2 ? s_red[3][wv] : by2;
+    }
+  }
+  unsigned long long* tog = a.bits + (long)row * 2 * a.bit_words;
+  unsigned long long* acc = tog + a.bit_words;
+  double sums[2] = {0.0, 0.0};  // crop, full
+  bool too_large = false;
+  for (int pass = 0; pass < 2; ++pass) {
+    int H, W;
+    double ox, oy;  // subtracted from the polygon coordinates
+    if (pass == 0) {  // :40-43, :57,:64
+      W = (int)roi.z - (int)roi.x + 1;
+      H = (int)roi.w - (int)roi.y + 1;
+      ox = (double)roi.x;
+      oy = (double)roi.y;
+    } else {  // :74-96
+      W = (int)bx2 - (int)bx1 + 1;
+      H = (int)by2 - (int)by1 + 1;
+      ox = bx1;
+      oy = by1;
+    }
+    const long area = (long)H * W;
+    if (H <= 0 || W <= 0) continue;  // an empty raster has no pixels
+    if (area > (long)a.bit_words * 64) {
+      too_large = true;
+      continue;
+    }
+    const int nw = (int)((area + 63) >> 6);
+    const int chunk = (nw + kMaskThreads - 1) / kMaskThreads;
+    const int w0 = iminr(tid * chunk, nw), w1 = iminr(w0 + chunk, nw);
+    for (int wd = w0; wd < w1; ++wd) { tog[wd] = 0ull; acc[wd] = 0ull; }
+    int offset = 2 + n_seg;
+    for (int sgi = 0; sgi < n_seg; ++sgi) {
+      const int cur_len = (int)poly[sgi + 2];
+      int k = cur_len / 2;
+      if (k > kMaskMaxVerts) k = kMaskMaxVerts;
+      __syncthreads();  // vx / vy / start of the previous segment are no longer read
+      for (int t = tid; t < k; t += kMaskThreads) {
+        const double px = (double)poly[offset + 2 * t], py = (double)poly[offset + 2 * t + 1];
+        vx[t] = (int)(5.0 * (px - ox) + .5);  // the mask API's x = image x here (no swap, :57,:64)
+        vy[t] = (int)(5.0 * (py - oy) + .5);
+      }
+      __syncthreads();
+      if (tid == 0 && k > 0) { vx[k] = vx[0]; vy[k] = vy[0]; }
+      __syncthreads();
+      int run = 0;
+      for (int base = 0; base < k; base += kMaskThreads) {
+        const int e = base + tid;
+        int cnt = 0;
+        if (e < k) {
+          const int dx = abs(vx[e] - vx[e + 1]), dy = abs(vy[e] - vy[e + 1]);
+          cnt = (dx > dy ? dx : dy) + 1;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const int t = __shfl_up(incl, o);
+          if ((tid & (kWave - 1)) >= o) incl += t;
+        }
+        __syncthreads();
+        if ((tid & (kWave - 1)) == kWave - 1) wave_sums[tid / kWave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int wv = 0; wv < kMaskThreads / kWave; ++wv) {
+          if (wv < tid / kWave) woff += wave_sums[wv];
+          tot += wave_sums[wv];
+        }
+        if (e < k) start[e] = run + woff + incl - cnt;
+        run += tot;
+      }
+      if (tid == 0) { start[k] = run; s_total = run; }
+      // the zeroed words must be in L2 before another lane's atomic lands on them
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      const int m = s_total;
+      for (int gidx = 1 + tid; gidx < m; gidx += kMaskThreads) {
+        int lo = 0, hi = k - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (start[mid] <= gidx) lo = mid; else hi = mid - 1;
+        }
+        int u1, v1, u0, v0;
+        poly_point(vx, vy, lo, gidx - start[lo], &u1, &v1);
+        if (gidx - 1 >= start[lo]) poly_point(vx, vy, lo, gidx - 1 - start[lo], &u0, &v0);
+        else poly_point(vx, vy, lo - 1, gidx - 1 - start[lo - 1], &u0, &v0);
+        if (u1 != u0) {
+          double xd = (double)(u1 < u0 ? u1 : u1 - 1);
+          xd = (xd + .5) / 5.0 - .5;
+          if (floor(xd) != xd || xd < 0 || xd > (double)(W - 1)) continue;
+          double yd = (double)(v1 < v0 ? v1 : v0);
+          yd = (yd + .5) / 5.0 - .5;
+          if (yd < 0) yd = 0; else if (yd > (double)H) yd = (double)H;
+          yd = ceil(yd);
+          const long pos = (long)xd * H + (long)yd;
+          if (pos < area) atomicXor(&tog[pos >> 6], 1ull << (pos & 63));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      // prefix parity: parity of this lane's words, exclusive xor-scan over the lanes
+      int par = 0;
+      for (int wd = w0; wd < w1; ++wd)
+        par ^= __popcll(__hip_atomic_load(&tog[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1;
+      s_par[tid] = par;
+      __syncthreads();
+      int carry = 0;
+      for (int t = 0; t < tid; ++t) carry ^= s_par[t];
+      for (int wd = w0; wd < w1; ++wd) {
+        const unsigned long long bitsw = __hip_atomic_load(&tog[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long pp = bitsw;
+        pp ^= pp << 1; pp ^= pp << 2; pp ^= pp << 4; pp ^= pp << 8; pp ^= pp << 16; pp ^= pp << 32;
+        if (carry) pp = ~pp;
+        carry ^= __popcll(bitsw) & 1;
+        acc[wd] |= pp;
+        tog[wd] = 0ull;
+      }
+      offset += cur_len;
+    }
+    // pixels of the union; the bits of the last word past the raster are not pixels
+    long cnt = 0;
+    for (int wd = w0; wd < w1; ++wd) {
+      unsigned long long v = acc[wd];
+      if (wd == nw - 1 && (area & 63)) v &= (1ull << (area & 63)) - 1ull;
+      cnt += __popcll(v);
+    }
+    double dc = (double)cnt;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) dc += __shfl_xor(dc, o);
+    __syncthreads();
+    if ((tid & (kWave - 1)) == 0) s_red[0][tid / kWave] = dc;
+    __syncthreads();
+    double tot = 0;
+    for (int wv = 0; wv < kMaskThreads / kWave; ++wv) tot += s_red[0][wv];
+    sums[pass] = tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double ratio = sums[0] / (sums[1] + 0.0001);
+    ratio = ratio > 1e-10 ? ratio : 1e-10;
+    a.ratio_out[row] = too_large ? __int_as_float(0x7fc00000) : (float)ratio;
+  }
 }
 
 static inline size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
@@ -716,7 +926,8 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
                                 float* bbox_weight, float* match_gt_iou, int32_t* kept_index,
                                 void* workspace, size_t workspace_bytes, void* stream,
                                 const float* gt_polys = nullptr, int L = 0, int mask_size = 0,
-                                float* mask_target = nullptr) {
+                                float* mask_target = nullptr, float* mask_ratio = nullptr,
+                                int max_raster_pixels = 0) {
   SD_REQUIRE(param_host, "param is null");
   const sd_proposal_target_param& p = *param_host;
   const int B = p.batch_images, S = p.image_rois;
@@ -733,7 +944,14 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
   SD_REQUIRE((((uintptr_t)rois | (uintptr_t)roi_output) & 15) == 0, "rois must be 16-byte aligned");
   PtArgs a{};
   char* base = reinterpret_cast<char*>(align_up((size_t)(uintptr_t)workspace, 256));
-  const size_t need = pt_layout(B, N, M, S, &a.ws, base) + (size_t)(base - (char*)workspace);
+  size_t need = pt_layout(B, N, M, S, &a.ws, base) + (size_t)(base - (char*)workspace);
+  if (mask_ratio) {  // two bitmaps of max_raster_pixels bits per foreground row behind the rest
+    const int FG = (int)((float)S * p.fg_fraction);
+    a.bit_words = (max_raster_pixels + 63) / 64;
+    a.bits = reinterpret_cast<unsigned long long*>((char*)workspace + align_up(need, 256));
+    need = align_up(need, 256) + (size_t)B * FG * 2 * a.bit_words * sizeof(unsigned long long);
+    a.ratio_out = mask_ratio;
+  }
   if (!workspace || workspace_bytes < need)
     return fail(SD_ERR_WORKSPACE, "ProposalTarget workspace too small: %zu < %zu bytes",
                 workspace_bytes, need);
@@ -766,6 +984,10 @@ static int proposal_target_impl(const float* rois, const float* gt_boxes, const 
     SD_REQUIRE(lds3 <= 64 * 1024, "mask_size=%d too large", mask_size);
     hipLaunchKernelGGL(pt_mask_kernel, dim3(B * a.FG), dim3(kMaskThreads), lds3, st, a);
     SD_LAUNCH_CHECK();
+    if (mask_ratio) {
+      hipLaunchKernelGGL(pt_mask_ratio_kernel, dim3(B * a.FG), dim3(kMaskThreads), 0, st, a);
+      SD_LAUNCH_CHECK();
+    }
   }
   return SD_OK;
 }
@@ -778,6 +1000,40 @@ extern "C" int sd_proposal_target(const float* rois, const float* gt_boxes, int 
   return proposal_target_impl(rois, gt_boxes, nullptr, 0, 0, N, M, param_host, rng_state, roi_output,
                               label, bbox_target, bbox_weight, match_gt_iou, kept_index, workspace,
                               workspace_bytes, stream);
+}
+
+extern "C" size_t sd_proposal_mask_target_ratio_workspace_bytes(int B, int N, int M, int image_rois,
+                                                                float fg_fraction,
+                                                                int max_raster_pixels) {
+  if (B <= 0 || N < 0 || M < 0 || image_rois < 0 || max_raster_pixels <= 0) return 256;
+  const int FG = (int)((float)image_rois * fg_fraction);
+  const size_t words = ((size_t)max_raster_pixels + 63) / 64;
+  return align_up(pt_layout(B, N, M, kPtMaxRois, nullptr, nullptr) + 256, 256) + 256 +
+         (size_t)B * (FG > 0 ? FG : 0) * 2 * words * sizeof(unsigned long long);
+}
+
+extern "C" int sd_proposal_mask_target_ratio(const float* rois, const float* gt_boxes,
+                                             const float* gt_polys, const float* valid_ranges,
+                                             int filter_scales, int N, int M, int L, int mask_size,
+                                             const sd_proposal_target_param* param_host,
+                                             int32_t* rng_state, float* roi_output, float* label,
+                                             float* bbox_target, float* bbox_weight,
+                                             float* match_gt_iou, float* mask_target,
+                                             float* mask_ratio, int max_raster_pixels,
+                                             int32_t* kept_index, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  SD_REQUIRE(param_host, "param is null");
+  SD_REQUIRE(param_host->image_rois >= 0,
+             "ProposalMaskTarget: image_rois=-1 is undefined in the reference (negative tensor shape)");
+  SD_REQUIRE(mask_size > 0 && L >= 2, "bad mask_size / polygon length");
+  SD_REQUIRE((gt_polys && mask_target && mask_ratio) || param_host->batch_images == 0,
+             "gt_polys / mask_target / mask_ratio is null");
+  SD_REQUIRE(max_raster_pixels > 0, "max_raster_pixels must be positive");
+  SD_REQUIRE(!filter_scales || valid_ranges, "filter_scales needs valid_ranges (num_args = 4)");
+  return proposal_target_impl(rois, gt_boxes, valid_ranges, filter_scales, 1, N, M, param_host,
+                              rng_state, roi_output, label, bbox_target, bbox_weight, match_gt_iou,
+                              kept_index, workspace, workspace_bytes, stream, gt_polys, L, mask_size,
+                              mask_target, mask_ratio, max_raster_pixels);
 }
 
 extern "C" int sd_proposal_target_v2(const float* rois, const float* gt_boxes,

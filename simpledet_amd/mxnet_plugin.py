@@ -343,7 +343,7 @@ def _build_ops(mx):
     ops["ProposalTarget_v2"] = (ProposalTargetV2Prop, (None, "ProposalTarget_v2"))
 
     # ---- ProposalMaskTarget (proposal_mask_target-inl.h): rois, gt_boxes, gt_polys [, valid_ranges]
-    #      -> the five ProposalTarget outputs + mask_target (6 visible; mask_ratio not provided) ----
+    #      -> the five ProposalTarget outputs + mask_target (+ mask_ratio with output_ratio) ----
     class ProposalMaskTarget(CustomOp):
         def __init__(self, p):
             super().__init__()
@@ -376,6 +376,19 @@ def _build_ops(mx):
                 lib().call("sd_glibc_srand_host", ctypes.c_uint32(1), host)
                 _state["rng"][key] = _state["mx"].nd.array(list(host), ctx=rois.context, dtype="int32")
             rng = _state["rng"][key]
+            if p["output_ratio"]:  # proposal_mask_target-inl.h:159-161: the seventh output, kWriteTo
+                _require_write(req[6:7], ["mask_ratio"])
+                mp = p["max_raster_pixels"]
+                wsb = lib().cdll.sd_proposal_mask_target_ratio_workspace_bytes(
+                    B, N, M, p["image_rois"], ctypes.c_float(p["fg_fraction"]), mp)
+                ws = _scratch(rois, wsb)
+                lib().call("sd_proposal_mask_target_ratio", _ptr(rois), _ptr(gt), _ptr(polys), _ptr(vr),
+                           int(p["filter_scales"]), N, M, L, p["mask_size"], ctypes.byref(cp), _ptr(rng),
+                           _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
+                           _ptr(out_data[4]), _ptr(out_data[5]), _ptr(out_data[6]), mp, None, _ptr(ws),
+                           ctypes.c_size_t(wsb), None)
+                _sync()
+                return
             wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
             ws = _scratch(rois, wsb)
             lib().call("sd_proposal_mask_target", _ptr(rois), _ptr(gt), _ptr(polys), _ptr(vr),
@@ -393,7 +406,7 @@ def _build_ops(mx):
                      bg_thresh_hi, bg_thresh_lo, proposal_without_gt, fg_fraction="0.25",
                      class_agnostic="False", ohem="False", output_ratio="False", output_iou="False",
                      filter_scales="False", bbox_mean="(0,0,0,0)", bbox_std="(0.1,0.1,0.2,0.2)",
-                     bbox_weight="(1,1,1,1)", num_args=None):
+                     bbox_weight="(1,1,1,1)", num_args=None, max_raster_pixels="1982464"):
             # num_args is the reference op's key_var_num_args (proposal_mask_target.cc:485): MXNet's
             # front end fills it in from the number of symbol inputs and no call site passes it
             # (models/maskrcnn/builder.py:115,184), so it defaults to what filter_scales implies
@@ -402,8 +415,11 @@ def _build_ops(mx):
                              output_iou, bbox_mean, bbox_std, bbox_weight)
             if _bool(ohem):
                 raise ValueError("ProposalMaskTarget: OHEM not Implemented.")
-            if _bool(output_ratio):
-                raise ValueError("ProposalMaskTarget: output_ratio (mask scoring) is not provided")
+            # output_ratio (mask scoring R-CNN, models/msrcnn/builder.py:219-237): the seventh output.
+            # max_raster_pixels is this adapter's own attribute (not the reference's): the bound on
+            # the image-resolution rasters the ratio counts, default 1408 x 1408
+            self.p["output_ratio"] = _bool(output_ratio)
+            self.p["max_raster_pixels"] = int(max_raster_pixels)
             if self.p["image_rois"] < 0:
                 raise ValueError("ProposalMaskTarget: image_rois=-1 is undefined in the reference")
             self.p["filter_scales"] = _bool(filter_scales)
@@ -413,22 +429,28 @@ def _build_ops(mx):
             if self.num_args != want:
                 raise ValueError("num_args=%d but filter_scales=%s takes %d inputs"
                                  % (self.num_args, self.p["filter_scales"], want))
-            self.num_visible_outputs = 6  # proposal_mask_target-inl.h:387-395 without output_ratio
+            # proposal_mask_target-inl.h:387-409 (the graph unpacks match_gt_iou either way:
+            # models/maskrcnn/builder.py:115, models/msrcnn/builder.py:219)
+            self.num_visible_outputs = 7 if self.p["output_ratio"] else 6
 
         def list_arguments(self):
             base = ["rois", "gt_boxes", "gt_polys"]
             return base + ["valid_ranges"] if self.p["filter_scales"] else base
 
         def list_outputs(self):
-            return ["roi_output", "label", "bbox_target", "bbox_weight", "match_gt_iou", "mask_target"]
+            base = ["roi_output", "label", "bbox_target", "bbox_weight", "match_gt_iou", "mask_target"]
+            return base + ["mask_ratio"] if self.p["output_ratio"] else base
 
         def infer_shape(self, in_shape):
             p = self.p
             B, S, K = p["batch_images"], p["image_rois"], p["num_classes"]
             import numpy as np
             FG = int(np.float32(S) * np.float32(p["fg_fraction"]))
-            return in_shape, [(B, S, 4), (B, S), (B, S, K * 4), (B, S, K * 4), (B, S),
-                              (B, FG, p["mask_size"], p["mask_size"])]
+            out = [(B, S, 4), (B, S), (B, S, K * 4), (B, S, K * 4), (B, S),
+                   (B, FG, p["mask_size"], p["mask_size"])]
+            if p["output_ratio"]:
+                out.append((B, FG))  # -inl.h:453-456
+            return in_shape, out
 
         def create_operator(self, ctx, shapes, dtypes):
             return ProposalMaskTarget(self.p)

@@ -479,11 +479,15 @@ def proposal_mask_target(rois, gt_boxes, gt_polys, num_classes, batch_images, im
                          fg_fraction=0.25, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0,
                          proposal_without_gt=False, class_agnostic=False, bbox_mean=(0., 0., 0., 0.),
                          bbox_std=(.1, .1, .2, .2), bbox_weight=(1., 1., 1., 1.), rng_state=None,
-                         valid_ranges=None, filter_scales=False, return_index=False):
+                         valid_ranges=None, filter_scales=False, return_index=False, output_ratio=False,
+                         max_raster_pixels=1408 * 1408):
     """ProposalMaskTarget (proposal_mask_target-inl.h): ProposalTarget_v2's five outputs plus
     mask_target (B, int(image_rois*fg_fraction), mask_size, mask_size): the 0/1 mask of each sampled
     foreground RoI's gt polygon in the RoI's frame, -1 rows past the sampled foreground.
-    gt_polys (B,M,L): [category, n_seg, len_1..len_n, x,y,...] padded with -1."""
+    gt_polys (B,M,L): [category, n_seg, len_1..len_n, x,y,...] padded with -1.
+    output_ratio=True (mask scoring R-CNN, proposal_mask_target.cc:20-152) appends mask_ratio (B, FG)
+    after mask_target; max_raster_pixels bounds the image-resolution rasters it counts (a row whose
+    RoI or RoI-and-polygon bounding box has more pixels gets NaN)."""
     _chk(rois, "rois", ndim=3)
     _chk(gt_boxes, "gt_boxes", ndim=3)
     _chk(gt_polys, "gt_polys", ndim=3)
@@ -515,6 +519,17 @@ def proposal_mask_target(rois, gt_boxes, gt_polys, num_classes, batch_images, im
     iou = torch.empty((B, S), device=dev, dtype=torch.float32)
     mask = torch.empty((B, FG, int(mask_size), int(mask_size)), device=dev, dtype=torch.float32)
     kept = torch.empty((B, S), device=dev, dtype=torch.int32) if return_index else None
+    if output_ratio:
+        ratio = torch.empty((B, FG), device=dev, dtype=torch.float32)
+        wsb = lib().cdll.sd_proposal_mask_target_ratio_workspace_bytes(
+            B, N, M, S, ctypes.c_float(float(fg_fraction)), int(max_raster_pixels))
+        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        lib().call("sd_proposal_mask_target_ratio", _p(rois), _p(gt_boxes), _p(gt_polys), _p(valid_ranges),
+                   int(bool(filter_scales)), N, M, L, int(mask_size), ctypes.byref(p), _p(rng_state), _p(ro),
+                   _p(lb), _p(bt), _p(bw), _p(iou), _p(mask), _p(ratio), int(max_raster_pixels), _p(kept),
+                   _p(ws), ctypes.c_size_t(wsb), _stream())
+        res = (ro, lb, bt, bw, iou, mask, ratio)
+        return res + (kept,) if return_index else res
     wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     lib().call("sd_proposal_mask_target", _p(rois), _p(gt_boxes), _p(gt_polys), _p(valid_ranges),

@@ -264,7 +264,10 @@ def case_proposal_target_v2(i):
 
 
 PMT_CFGS = [dict(seed=8, B=2, N=1000, M=40, S=128), dict(seed=9, B=2, N=600, M=20, S=64, fg_fraction=0.5),
-            dict(seed=10, B=2, N=500, M=30, S=128, ranges=[[0, 120], [80, 500]])]
+            dict(seed=10, B=2, N=500, M=30, S=128, ranges=[[0, 120], [80, 500]]),
+            # output_ratio = true: the mask scoring R-CNN heads (models/msrcnn/builder.py:219-237)
+            dict(seed=11, B=2, N=800, M=30, S=128, ratio=True),
+            dict(seed=12, B=2, N=400, M=12, S=64, fg_fraction=0.5, ratio=True)]
 PMT_NAMES = PT_NAMES + ("mask_target",)
 
 
@@ -273,6 +276,7 @@ def case_proposal_mask_target(i):
     "ref" runner is the reference's proposal_mask_target.cc compiled against the RESTATED COCO mask
     API (oracle/mask_api.c; the real one is not vendored): op logic pinned, rasterisation not."""
     c = PMT_CFGS[i]
+    ratio = bool(c.get("ratio"))
 
     def run(runner):
         kw = dict(num_classes=81, batch_images=c["B"], image_rois=c["S"], fg_fraction=c.get("fg_fraction", 0.25),
@@ -283,20 +287,22 @@ def case_proposal_mask_target(i):
         if runner == "ref":
             from oracle import refmx
             op = _ref("proposal_mask_target", "ProposalMaskTarget", num_args=4 if vr is not None else 3,
-                      mask_size=28, output_iou=True, filter_scales=vr is not None, **kw)
+                      mask_size=28, output_iou=True, filter_scales=vr is not None, output_ratio=ratio, **kw)
             refmx.srand(1)
             res = op.forward([rois, gt, polys] + ([vr] if vr is not None else []))
         elif runner == "oracle":
             orc = _orc()
             p = orc.make_pt_param(81, c["B"], c["S"], kw["fg_fraction"], 0.5, 0.5, 0.0, False)
             res = orc.proposal_mask_target(rois, gt, polys, p, 28, rng=orc.GlibcRand(1), valid_ranges=vr,
-                                           filter_scales=vr is not None)[:6]
+                                           filter_scales=vr is not None, output_ratio=ratio)
+            res = list(res[:6]) + ([res[7]] if ratio else [])
         else:
             ops = _ops()
             res = [_n(t) for t in ops.proposal_mask_target(
                 _t(rois), _t(gt), _t(polys), mask_size=28, rng_state=ops.glibc_rand_state(1),
-                valid_ranges=None if vr is None else _t(vr), filter_scales=vr is not None, **kw)]
-        return dict(zip(PMT_NAMES, res))
+                valid_ranges=None if vr is None else _t(vr), filter_scales=vr is not None,
+                output_ratio=ratio, **kw)]
+        return dict(zip(PMT_NAMES + (("mask_ratio",) if ratio else ()), res))
     return run
 
 

@@ -109,7 +109,11 @@ def _t(a):
                                  dict(H=20, W=24, off_scale=40.0),     # wild offsets: whole-plane window, many outside
                                  dict(H=20, W=24, off_scale=0.0),      # zero offsets: minimal window
                                  dict(k=1, pad=0, H=12, W=16),         # run-time tap count
-                                 dict(k=5, pad=2, H=12, W=16, dg=2)])  # 25 taps: per-lane fallback kernels
+                                 dict(k=5, pad=2, H=12, W=16, dg=2),   # 25 taps: per-lane fallback kernels
+                                 # groups of 4n channels with Ho*Wo % 4 == 0: the four-channel col2im
+                                 dict(H=12, W=16, C=16), dict(H=20, W=24, C=16, off_scale=40.0),
+                                 dict(H=16, W=20, C=32, dg=2, stride=2), dict(H=12, W=16, C=16, pad=2, dil=2),
+                                 dict(N=1, C=16, H=100, W=168, F=4, off_scale=3.0)])  # ... in 4 row bands
 def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
     x, off, w, kw = _case(7, **cfg)
     a = dict(kernel=kw["kernel"], pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"],

@@ -110,6 +110,31 @@ def test_nms_and_soft_nms_at_capacity(ops, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,pre,post", [(20000, 6000, 1000), (70000, 12000, 2000), (16385, 16384, 300)])
+def test_nms_more_rows_than_the_lds_sort_holds(ops, oracle, N, pre, post):
+    """_contrib_NMS sorts any N (nms.cu:303) and keeps the first pre_nms_top_n rows of that order
+    (:311-313).  Above 16384 unsorted rows the pre best are picked by a radix select and only they
+    are sorted: same boxes, scores and keep indices as the oracle's full sort, ties included (a
+    quarter of the scores are duplicated so that the selection threshold falls inside a tie run)."""
+    d = synth.nms_dets(21, N)
+    rs = np.random.RandomState(N)
+    dup = rs.choice(N, N // 4, replace=False)
+    d[dup, 4] = d[rs.choice(N, N // 4), 4]
+    d = d[None]
+    want = oracle.nms(d, pre, post, 0.7)
+    got = ops.nms(_t(d), pre, post, 0.7, return_index=True)
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+    np.testing.assert_array_equal(got[1].cpu().numpy(), want[1])
+    # the kept rows are rows of the input: original indices agree with a stable descending sort
+    order = np.argsort(-d[0, :, 4], kind="stable")[:pre]
+    idx = got[2].cpu().numpy()[0]
+    assert set(idx[idx >= 0].tolist()) <= set(order.tolist())
+    # every row unsorted and pre_nms_top_n beyond the sort capacity: a clear error, not a wrong answer
+    with pytest.raises(RuntimeError, match="pre_nms_top_n <= 16384"):
+        ops.nms(_t(d), 16385, post, 0.7)
+
+
+@pytest.mark.gpu
 def test_fused_fpn_roi_align_14x14_mask_head(ops, oracle):
     """The mask-head extractor (14x14, packed arg-max, strided bin order in the backward)."""
     feats = synth.feature_maps(12, batch=2, channels=6)

@@ -110,6 +110,65 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def test_oracle_mask_ratio_properties(oracle):
+    """convertPoly2MaskWithRatio (proposal_mask_target.cc:20-152): a polygon inside the RoI has all
+    its pixels in the crop (ratio 1 up to the 1e-4 in the denominator), a RoI covering the left half
+    of a rectangle about half, a RoI away from the polygon the 1e-10 floor; no segments -> the floor."""
+    rect = lambda x1, y1, x2, y2: [x1, y1, x2, y1, x2, y2, x1, y2]
+    poly = np.array([1.0, 1.0, 8.0] + rect(100, 50, 300, 150) + [-1.0] * 20, np.float32)
+    m, r = oracle.poly2mask_ratio(np.array([90, 40, 310, 160], np.float32), poly, 28)
+    assert abs(r - 1.0) < 1e-6 and m.sum() > 0
+    m, r = oracle.poly2mask_ratio(np.array([100, 50, 200, 150], np.float32), poly, 28)
+    assert 0.49 < r < 0.52
+    m, r = oracle.poly2mask_ratio(np.array([400, 300, 500, 400], np.float32), poly, 28)
+    assert r == 1e-10 and m.sum() == 0
+    empty = np.array([1.0, 0.0] + [-1.0] * 20, np.float32)
+    m, r = oracle.poly2mask_ratio(np.array([10, 10, 50, 50], np.float32), empty, 28)
+    assert r == 1e-10 and m.sum() == 0
+
+
+@pytest.mark.gpu
+def test_hip_mask_ratio_equals_oracle(ops, oracle):
+    """output_ratio = true: masks (double coordinates, :53-63) and ratios bit for bit, on RoIs that
+    cut their polygon (jittered and shifted gt boxes), polygons of 1-3 possibly overlapping
+    segments, and image-sized rasters; a raster above max_raster_pixels gives NaN for that row only."""
+    B, M = 2, 40
+    gt = synth.gt_boxes(31, B, M, min_n=M, max_n=M)
+    polys = synth.gt_polys(31, gt, max_len=400)
+    # overlapping segments: the second segment of every third polygon is a copy of the first, shifted
+    for b in range(B):
+        for j in range(0, M, 3):
+            row = polys[b, j]
+            if row[1] >= 2 and row[2] == row[3]:
+                k = int(row[2])
+                o = 2 + int(row[1])
+                row[o + k:o + 2 * k] = row[o:o + k] + 2.5
+    rs = np.random.RandomState(5)
+    rois = gt[:, :, :4] + rs.uniform(-6, 6, (B, M, 4)).astype(np.float32)
+    w = gt[:, :, 2] - gt[:, :, 0]
+    rois[:, ::4, 0] += 0.3 * w[:, ::4]   # a quarter of the RoIs lose the left part of their object
+    rois[:, ::4, 2] += 0.3 * w[:, ::4]
+    rois = np.maximum(rois, 0).astype(np.float32)
+    got = ops.proposal_mask_target(_t(rois), _t(gt), _t(polys), 81, B, 64, mask_size=28, fg_fraction=1.0,
+                                   fg_thresh=0.3, proposal_without_gt=True, rng_state=ops.glibc_rand_state(1),
+                                   return_index=True, output_ratio=True)
+    p = oracle.make_pt_param(81, B, 64, fg_fraction=1.0, fg_thresh=0.3, proposal_without_gt=True)
+    want = oracle.proposal_mask_target(rois, gt, polys, p, 28, rng=oracle.GlibcRand(1), output_ratio=True)
+    np.testing.assert_array_equal(got[7].cpu().numpy(), want[6])      # kept index
+    np.testing.assert_array_equal(got[5].cpu().numpy(), want[5])      # masks
+    ratio = got[6].cpu().numpy()
+    np.testing.assert_array_equal(ratio, want[7])
+    live = want[7][want[7] != 0]
+    assert len(live) > 40 and live.min() < 0.9 and live.max() > 0.99
+    # the bound: rows whose crop or full raster has more pixels become NaN, the others stay
+    small = ops.proposal_mask_target(_t(rois), _t(gt), _t(polys), 81, B, 64, mask_size=28, fg_fraction=1.0,
+                                     fg_thresh=0.3, proposal_without_gt=True, rng_state=ops.glibc_rand_state(1),
+                                     output_ratio=True, max_raster_pixels=20000)[6].cpu().numpy()
+    nan = np.isnan(small)
+    assert nan.any() and not nan.all()
+    np.testing.assert_array_equal(small[~nan], want[7][~nan])
+
+
 @pytest.mark.gpu
 def test_proposal_target_v2_and_mask_target_fuzz(ops, oracle):
     """50 random problems each: ProposalTarget_v2 (valid_ranges, filter_scales on / off) and

@@ -164,6 +164,23 @@ def test_proposal_mask_target_alias_as_the_reference_graph_calls_it(plugin):
         props["ProposalMaskTarget"](num_args="4", **node.params)
 
 
+def test_proposal_mask_target_output_ratio_as_msrcnn_calls_it(plugin):
+    """models/msrcnn/builder.py:219-237 unpacks seven outputs (output_iou=True, output_ratio=True):
+    the seventh is mask_ratio (B, FG), proposal_mask_target-inl.h:453-456."""
+    mx, props, _ = plugin
+    proposal, gt_bbox, gt_poly = (mx.sym.Variable(n) for n in ("proposal", "gt_bbox", "gt_poly"))
+    outs = mx.sym.ProposalMaskTarget(
+        proposal, gt_bbox, gt_poly, mask_size=28, num_classes=81, class_agnostic=False, batch_images=2,
+        proposal_without_gt=False, image_rois=512, fg_fraction=0.25, fg_thresh=0.5, bg_thresh_hi=0.5,
+        bg_thresh_lo=0.0, bbox_weight=(1.0, 1.0, 1.0, 1.0), bbox_mean=(0.0, 0.0, 0.0, 0.0),
+        bbox_std=(0.1, 0.1, 0.2, 0.2), output_iou=True, output_ratio=True, name="subsample_proposal")
+    node = outs if not isinstance(outs, list) else outs[0][1]
+    p = props["ProposalMaskTarget"](**node.params)
+    assert p.list_outputs()[-1] == "mask_ratio" and len(p.list_outputs()) == 7 and p.num_visible_outputs == 7
+    _, shapes = p.infer_shape([(2, 2000, 4), (2, 100, 5), (2, 100, 500)])
+    assert shapes[5] == (2, 128, 28, 28) and shapes[6] == (2, 128)
+
+
 def test_install_routes_fpn_extractor_to_the_fused_op_without_editing_the_reference(plugin):
     """models/FPN/builder.py:567-610 builds assign + 4 x roi_align + add_n; install() rebinds
     FPNRoiAlign.get_roi_feature so the same call emits one sd_fpn_roi_align node."""
