@@ -432,7 +432,9 @@ int sd_deform_conv_bwd(const float* out_grad, const float* x, const float* offse
  *   cls_prob (B,2A,H,W) (foreground = second half)  bbox_pred (B,4A,H,W)  im_info (B,3) DEVICE
  *   out (B,post,4)  score (B,post): post = is_train ? min(post_nms_top_n, pre) : post_nms_top_n;
  *   padding past the kept boxes: zeros (test) or the kept boxes repeated cyclically (is_train).
- *   iou_loss=true is not supported (no reference config uses it).
+ *   sd_proposal_v3_iou is the op with iou_loss = true: IoUPredKernel (proposal_v3.cu:163-205, the
+ *   four deltas are added to the anchor's corners) in place of BBoxPredKernel; no reference config
+ *   enables it.
  * ---------------------------------------------------------------------------------------------- */
 size_t sd_proposal_v3_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n);
 int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info, float* out,
@@ -441,6 +443,12 @@ int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* i
                    const float* scales_host, int n_scales, const float* ratios_host, int n_ratios,
                    int feature_stride, int is_train, void* workspace, size_t workspace_bytes,
                    void* stream);
+int sd_proposal_v3_iou(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                       float* out, float* score, int B, int A, int H, int W, int rpn_pre_nms_top_n,
+                       int rpn_post_nms_top_n, float threshold, int rpn_min_size,
+                       const float* scales_host, int n_scales, const float* ratios_host,
+                       int n_ratios, int feature_stride, int is_train, void* workspace,
+                       size_t workspace_bytes, void* stream);
 /* get_top_proposal CustomOp (models/FPN/get_top_proposal.py:15-39): the top_n rows of bbox (B,N,4)
  * by score (B,N) descending (ties: lower row first), zero padded when N < top_n */
 int sd_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,

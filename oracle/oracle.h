@@ -120,6 +120,11 @@ void orc_proposal_v3(const float* cls_prob, const float* bbox_pred, const float*
                      int A, int H, int W, int pre_nms_top_n, int post_nms_top_n, float threshold,
                      int min_size, const float* scales, int ns, const float* ratios, int nr,
                      int feature_stride, int is_train, float* out, float* score_out);
+/* iou_loss = true: IoUPredKernel (proposal_v3.cu:163-205) instead of BBoxPredKernel */
+void orc_proposal_v3_iou(const float* cls_prob, const float* bbox_pred, const float* im_info, int B,
+                         int A, int H, int W, int pre_nms_top_n, int post_nms_top_n, float threshold,
+                         int min_size, const float* scales, int ns, const float* ratios, int nr,
+                         int feature_stride, int is_train, float* out, float* score_out);
 /* models/FPN/get_top_proposal.py:15-39 */
 void orc_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,
                           float* out_bbox, float* out_score);

@@ -18,7 +18,8 @@
  * One deliberate deviation: the reference evaluates exp(dw) with CUDA's expf, whose last-bit
  * behaviour no other libm reproduces; both this oracle and the HIP kernel use
  * (float)exp((double)dw), which is the correctly rounded value in all but ~1e-8 of cases.
- * iou_loss = true (IoUPredKernel) is not restated: no config of the reference enables it.
+ * iou_loss = true (IoUPredKernel :163-205: corners = anchor corners + deltas, clipped) is
+ * orc_proposal_v3_iou; no config of the reference enables it.
  */
 #include "oracle.h"
 #include <math.h>
@@ -88,10 +89,11 @@ int orc_proposal_v3_post(int count, int pre_nms_top_n, int post_nms_top_n, int i
   return post;
 }
 
-void orc_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info, int B,
-                     int A, int H, int W, int pre_nms_top_n, int post_nms_top_n, float threshold,
-                     int min_size, const float* scales, int ns, const float* ratios, int nr,
-                     int feature_stride, int is_train, float* out, float* score_out) {
+static void proposal_v3_impl(const float* cls_prob, const float* bbox_pred, const float* im_info, int B,
+                             int A, int H, int W, int pre_nms_top_n, int post_nms_top_n, float threshold,
+                             int min_size, const float* scales, int ns, const float* ratios, int nr,
+                             int feature_stride, int is_train, int iou_loss, float* out,
+                             float* score_out) {
   const int count = A * H * W;
   int pre = pre_nms_top_n > 0 ? pre_nms_top_n : count;
   if (pre > count) pre = count;
@@ -135,11 +137,21 @@ void orc_proposal_v3(const float* cls_prob, const float* bbox_pred, const float*
       float py1 = pred_ctr_y - 0.5f * pred_h;
       float px2 = pred_ctr_x + 0.5f * pred_w - 1.0f;
       float py2 = pred_ctr_y + 0.5f * pred_h - 1.0f;
+      if (iou_loss) { /* IoUPredKernel, proposal_v3.cu:181-194: the four deltas move the corners */
+        px1 = x1 + deltas[((long)(a * 4) * H + h) * W + w];
+        py1 = y1 + deltas[((long)(a * 4 + 1) * H + h) * W + w];
+        px2 = x2 + deltas[((long)(a * 4 + 2) * H + h) * W + w];
+        py2 = y2 + deltas[((long)(a * 4 + 3) * H + h) * W + w];
+      }
       prop[index * 5 + 0] = fmaxc(fminc(px1, im_width - 1.0f), 0.0f);
       prop[index * 5 + 1] = fmaxc(fminc(py1, im_height - 1.0f), 0.0f);
       prop[index * 5 + 2] = fmaxc(fminc(px2, im_width - 1.0f), 0.0f);
       prop[index * 5 + 3] = fmaxc(fminc(py2, im_height - 1.0f), 0.0f);
       prop[index * 5 + 4] = fg[((long)a * H + h) * W + w];
+      /* IoUPredKernel only (:201-203; commented out in BBoxPredKernel :151-153): anchors past the
+       * unpadded image, real_height = (int)(im_height / feature_stride) (:510-511) */
+      if (iou_loss && (h >= (int)(im_height / feature_stride) || w >= (int)(im_width / feature_stride)))
+        prop[index * 5 + 4] = -1.0f;
       sc[index] = prop[index * 5 + 4];
       order[index] = index;
     }
@@ -191,6 +203,22 @@ void orc_proposal_v3(const float* cls_prob, const float* bbox_pred, const float*
     }
   }
   free(prop); free(sc); free(order); free(top); free(removed); free(keep);
+}
+
+void orc_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info, int B,
+                     int A, int H, int W, int pre_nms_top_n, int post_nms_top_n, float threshold,
+                     int min_size, const float* scales, int ns, const float* ratios, int nr,
+                     int feature_stride, int is_train, float* out, float* score_out) {
+  proposal_v3_impl(cls_prob, bbox_pred, im_info, B, A, H, W, pre_nms_top_n, post_nms_top_n, threshold,
+                   min_size, scales, ns, ratios, nr, feature_stride, is_train, 0, out, score_out);
+}
+
+void orc_proposal_v3_iou(const float* cls_prob, const float* bbox_pred, const float* im_info, int B,
+                         int A, int H, int W, int pre_nms_top_n, int post_nms_top_n, float threshold,
+                         int min_size, const float* scales, int ns, const float* ratios, int nr,
+                         int feature_stride, int is_train, float* out, float* score_out) {
+  proposal_v3_impl(cls_prob, bbox_pred, im_info, B, A, H, W, pre_nms_top_n, post_nms_top_n, threshold,
+                   min_size, scales, ns, ratios, nr, feature_stride, is_train, 1, out, score_out);
 }
 
 /* models/FPN/get_top_proposal.py:15-39; ties keep the lower row first (stable) */

@@ -437,7 +437,7 @@ def proposal_v3_anchors(stride, scales, ratios):
 
 
 def proposal_v3(cls_prob, bbox_pred, im_info, pre, post, threshold, min_size, scales, ratios,
-                stride, is_train=False):
+                stride, is_train=False, iou_loss=False):
     cls_prob, pc = _f(cls_prob)
     bbox_pred, pb = _f(bbox_pred)
     im_info, pi = _f(im_info)
@@ -447,9 +447,10 @@ def proposal_v3(cls_prob, bbox_pred, im_info, pre, post, threshold, min_size, sc
     peff = cdll().orc_proposal_v3_post(A * H * W, int(pre), int(post), int(is_train))
     out = np.empty((B, peff, 4), np.float32)
     score = np.empty((B, peff, 1), np.float32)
-    cdll().orc_proposal_v3(pc, pb, pi, B, A, H, W, int(pre), int(post), ctypes.c_float(threshold),
-                           int(min_size), _fa(scales), len(scales), _fa(ratios), len(ratios),
-                           int(stride), int(is_train), out.ctypes, score.ctypes)
+    fn = cdll().orc_proposal_v3_iou if iou_loss else cdll().orc_proposal_v3
+    fn(pc, pb, pi, B, A, H, W, int(pre), int(post), ctypes.c_float(threshold),
+       int(min_size), _fa(scales), len(scales), _fa(ratios), len(ratios),
+       int(stride), int(is_train), out.ctypes, score.ctypes)
     return out, score
 
 

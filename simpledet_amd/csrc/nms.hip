@@ -369,6 +369,7 @@ struct PropArgs {
   NmsWs ws;
   float anchors[kMaxAnchors * 4];
   int A, H, W, stride, count, pre, P2;
+  int iou_loss;  // IoUPredKernel instead of BBoxPredKernel
   float min_size;
   // multi-workgroup top-k (large levels): per image 4 x 256 digit counters, a candidate counter and
   // P2 candidate keys in global memory; G workgroups per image
@@ -404,13 +405,25 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(PropArgs a) {
   dh = (float)((double)dh < 4.135166556742356 ? (double)dh : 4.135166556742356);
   const float pred_ctr_x = dx * width + ctr_x, pred_ctr_y = dy * height + ctr_y;
   const float pred_w = (float)exp((double)dw) * width, pred_h = (float)exp((double)dh) * height;
+  float px1 = pred_ctr_x - 0.5f * pred_w, py1 = pred_ctr_y - 0.5f * pred_h;
+  float px2 = pred_ctr_x + 0.5f * pred_w - 1.0f, py2 = pred_ctr_y + 0.5f * pred_h - 1.0f;
+  if (a.iou_loss) {  // IoUPredKernel (:163-205): the four deltas move the anchor's corners
+    px1 = x1 + dx;
+    py1 = y1 + dy;
+    px2 = x2 + deltas[(long)(an * 4 + 2) * plane + hw];
+    py2 = y2 + deltas[(long)(an * 4 + 3) * plane + hw];
+  }
   float4 o;
-  o.x = fmaxr(fminr(pred_ctr_x - 0.5f * pred_w, im_width - 1.0f), 0.0f);
-  o.y = fmaxr(fminr(pred_ctr_y - 0.5f * pred_h, im_height - 1.0f), 0.0f);
-  o.z = fmaxr(fminr(pred_ctr_x + 0.5f * pred_w - 1.0f, im_width - 1.0f), 0.0f);
-  o.w = fmaxr(fminr(pred_ctr_y + 0.5f * pred_h - 1.0f, im_height - 1.0f), 0.0f);
+  o.x = fmaxr(fminr(px1, im_width - 1.0f), 0.0f);
+  o.y = fmaxr(fminr(py1, im_height - 1.0f), 0.0f);
+  o.z = fmaxr(fminr(px2, im_width - 1.0f), 0.0f);
+  o.w = fmaxr(fminr(py2, im_height - 1.0f), 0.0f);
   a.boxes_all[(long)img * a.count + index] = o;
-  a.score_all[(long)img * a.count + index] = fg[(long)an * plane + hw];
+  float sc = fg[(long)an * plane + hw];
+  // IoUPredKernel only (:201-203; commented out in BBoxPredKernel): anchors past the unpadded image
+  if (a.iou_loss && (h >= (int)(im_height / (float)a.stride) || w >= (int)(im_width / (float)a.stride)))
+    sc = -1.0f;
+  a.score_all[(long)img * a.count + index] = sc;
 }
 
 // one 8-bit digit of a radix select among the elements whose key matches `prefix` under `mask`:
@@ -928,12 +941,13 @@ extern "C" size_t sd_proposal_v3_workspace_bytes(int B, int A, int H, int W, int
          align_up((size_t)B * P2 * 8, 256) + 512;
 }
 
-extern "C" int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info,
-                              float* out, float* score, int B, int A, int H, int W,
-                              int rpn_pre_nms_top_n, int rpn_post_nms_top_n, float threshold,
-                              int rpn_min_size, const float* scales_host, int n_scales,
-                              const float* ratios_host, int n_ratios, int feature_stride,
-                              int is_train, void* workspace, size_t workspace_bytes, void* stream) {
+static int proposal_v3_impl(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                            float* out, float* score, int B, int A, int H, int W,
+                            int rpn_pre_nms_top_n, int rpn_post_nms_top_n, float threshold,
+                            int rpn_min_size, const float* scales_host, int n_scales,
+                            const float* ratios_host, int n_ratios, int feature_stride,
+                            int is_train, int iou_loss, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   SD_REQUIRE(B >= 0 && A > 0 && H > 0 && W > 0, "bad dimensions");
   SD_REQUIRE(scales_host && ratios_host && n_scales * n_ratios == A,
              "num_anchors (%d) != ratios (%d) x scales (%d)", A, n_ratios, n_scales);
@@ -972,6 +986,7 @@ extern "C" int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, con
   a.cls_prob = cls_prob; a.bbox_pred = bbox_pred; a.im_info = im_info;
   a.A = A; a.H = H; a.W = W; a.stride = feature_stride; a.count = count; a.pre = pre;
   a.min_size = (float)rpn_min_size;
+  a.iou_loss = iou_loss ? 1 : 0;
   a.P2 = P2;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(proposal_decode_kernel, dim3((count + 255) / 256, B), dim3(256), 0, st, a);
@@ -1044,6 +1059,31 @@ __global__ __launch_bounds__(1024) void top_proposal_kernel(TopArgs a) {
     a.out_bbox[(long)img * a.top_n + i] = b;
     a.out_score[(long)img * a.top_n + i] = s;
   }
+}
+
+extern "C" int sd_proposal_v3(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                              float* out, float* score, int B, int A, int H, int W,
+                              int rpn_pre_nms_top_n, int rpn_post_nms_top_n, float threshold,
+                              int rpn_min_size, const float* scales_host, int n_scales,
+                              const float* ratios_host, int n_ratios, int feature_stride,
+                              int is_train, void* workspace, size_t workspace_bytes, void* stream) {
+  return proposal_v3_impl(cls_prob, bbox_pred, im_info, out, score, B, A, H, W, rpn_pre_nms_top_n,
+                          rpn_post_nms_top_n, threshold, rpn_min_size, scales_host, n_scales,
+                          ratios_host, n_ratios, feature_stride, is_train, 0, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int sd_proposal_v3_iou(const float* cls_prob, const float* bbox_pred,
+                                  const float* im_info, float* out, float* score, int B, int A,
+                                  int H, int W, int rpn_pre_nms_top_n, int rpn_post_nms_top_n,
+                                  float threshold, int rpn_min_size, const float* scales_host,
+                                  int n_scales, const float* ratios_host, int n_ratios,
+                                  int feature_stride, int is_train, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  return proposal_v3_impl(cls_prob, bbox_pred, im_info, out, score, B, A, H, W, rpn_pre_nms_top_n,
+                          rpn_post_nms_top_n, threshold, rpn_min_size, scales_host, n_scales,
+                          ratios_host, n_ratios, feature_stride, is_train, 1, workspace,
+                          workspace_bytes, stream);
 }
 
 extern "C" int sd_get_top_proposal(const float* bbox, const float* score, int B, int N, int top_n,

@@ -831,7 +831,8 @@ def _build_ops(mx):
                 self.assign(out_data[0], "write", 0)
                 self.assign(out_data[1], "write", 0)
             fa = lambda v: (ctypes.c_float * len(v))(*v)
-            lib().call("sd_proposal_v3", _ptr(cls_prob), _ptr(bbox_pred), _ptr(im_info),
+            lib().call("sd_proposal_v3_iou" if g["iou_loss"] else "sd_proposal_v3",
+                       _ptr(cls_prob), _ptr(bbox_pred), _ptr(im_info),
                        _ptr(out_data[0]), _ptr(out_data[1]), B, A, H, W, g["pre"], g["post"],
                        float(g["thr"]), g["min_size"], fa(g["scales"]), len(g["scales"]),
                        fa(g["ratios"]), len(g["ratios"]), g["stride"], int(g["is_train"]), _ptr(ws),
@@ -848,12 +849,10 @@ def _build_ops(mx):
                      feature_stride="16", output_score="False", iou_loss="False", is_train="False",
                      workspace="256"):
             super().__init__(need_top_grad=False)
-            if _bool(iou_loss):
-                raise ValueError("Proposal_v3: iou_loss=True is not supported")
             self.g = dict(pre=int(rpn_pre_nms_top_n), post=int(rpn_post_nms_top_n),
                           thr=float(threshold), min_size=int(rpn_min_size), scales=_tuple(scales),
                           ratios=_tuple(ratios), stride=int(feature_stride),
-                          is_train=_bool(is_train))
+                          is_train=_bool(is_train), iou_loss=_bool(iou_loss))  # proposal_v3.cu:536
             self.num_visible_outputs = 2 if _bool(output_score) else 1
 
         def list_arguments(self):

@@ -799,7 +799,7 @@ def _farr(vals):
 
 def proposal_v3(cls_prob, bbox_pred, im_info, rpn_pre_nms_top_n=6000, rpn_post_nms_top_n=300,
                 threshold=0.7, rpn_min_size=16, scales=(4., 8., 16., 32.), ratios=(0.5, 1., 2.),
-                feature_stride=16, is_train=False):
+                feature_stride=16, is_train=False, iou_loss=False):
     """Proposal_v3: cls_prob (B,2A,H,W), bbox_pred (B,4A,H,W), im_info (B,3) ->
     output (B,post,4), score (B,post,1)   (shapes proposal_v3-inl.h:196-214)."""
     _chk(cls_prob, "cls_prob", ndim=4)
@@ -818,7 +818,8 @@ def proposal_v3(cls_prob, bbox_pred, im_info, rpn_pre_nms_top_n=6000, rpn_post_n
     score = torch.empty((B, post, 1), device=cls_prob.device, dtype=torch.float32)
     wsb = lib().cdll.sd_proposal_v3_workspace_bytes(B, A, H, W, int(rpn_pre_nms_top_n))
     ws = torch.empty(wsb, device=cls_prob.device, dtype=torch.uint8)
-    lib().call("sd_proposal_v3", _p(cls_prob), _p(bbox_pred), _p(im_info), _p(out), _p(score), B, A,
+    lib().call("sd_proposal_v3_iou" if iou_loss else "sd_proposal_v3",
+               _p(cls_prob), _p(bbox_pred), _p(im_info), _p(out), _p(score), B, A,
                H, W, int(rpn_pre_nms_top_n), int(rpn_post_nms_top_n), float(threshold),
                int(rpn_min_size), _farr(scales), len(scales), _farr(ratios), len(ratios),
                int(feature_stride), int(bool(is_train)), _p(ws), ctypes.c_size_t(wsb), _stream())

@@ -332,7 +332,10 @@ PV3_CFGS = [dict(stride=16, H=50, W=84, pre=2000, post=1000, ms=0, train=False),
             dict(stride=32, H=25, W=42, pre=2000, post=1000, ms=16, train=True),
             dict(stride=8, H=100, W=167, pre=2000, post=2000, ms=0, train=False),
             dict(stride=64, H=13, W=21, pre=2000, post=2000, ms=0, train=False),
-            dict(stride=4, H=200, W=334, pre=2000, post=2000, ms=8, train=False)]
+            dict(stride=4, H=200, W=334, pre=2000, post=2000, ms=8, train=False),
+            # iou_loss = true (IoUPredKernel, proposal_v3.cu:163-205; deltas are corner offsets in pixels)
+            dict(stride=16, H=50, W=84, pre=2000, post=1000, ms=0, train=False, iou=True),
+            dict(stride=32, H=25, W=42, pre=1000, post=300, ms=16, train=True, iou=True)]
 
 
 def case_proposal_v3(i):
@@ -340,17 +343,21 @@ def case_proposal_v3(i):
 
     def run(runner):
         cls, bb, info = synth.rpn_outputs(i, 2, 3, c["H"], c["W"], c["stride"])
+        iou = bool(c.get("iou"))
+        if iou:
+            bb = (bb * 24).astype(np.float32)
         if runner == "ref":
             out, score = _ref("proposal_v3", "_contrib_Proposal_v3", rpn_pre_nms_top_n=c["pre"],
                               rpn_post_nms_top_n=c["post"], threshold=0.7, rpn_min_size=c["ms"], scales=(8,),
                               ratios=(0.5, 1, 2), feature_stride=c["stride"], output_score=True,
-                              is_train=c["train"]).forward([cls, bb, info], ctx="gpu")
+                              is_train=c["train"], iou_loss=iou).forward([cls, bb, info], ctx="gpu")
         elif runner == "oracle":
             out, score = _orc().proposal_v3(cls, bb, info, c["pre"], c["post"], 0.7, c["ms"], (8,),
-                                            (0.5, 1, 2), c["stride"], c["train"])
+                                            (0.5, 1, 2), c["stride"], c["train"], iou_loss=iou)
         else:
             out, score = [_n(t) for t in _ops().proposal_v3(_t(cls), _t(bb), _t(info), c["pre"], c["post"], 0.7,
-                                                             c["ms"], (8,), (0.5, 1, 2), c["stride"], c["train"])]
+                                                             c["ms"], (8,), (0.5, 1, 2), c["stride"], c["train"],
+                                                             iou_loss=iou)]
         return {"output": out, "score": score.reshape(out.shape[0], -1, 1)}
     return run
 
@@ -418,7 +425,10 @@ for _i in range(len(NMS_CFGS)):
 for _i in range(len(PV3_CFGS)):
     # CUDA exp(float) is emulated with glibc expf, the oracle / HIP kernel use the correctly rounded
     # (float)exp((double)x): coordinates may differ by one ulp of a <=2^11 pixel value
-    _add("proposal_v3_%d" % _i, case_proposal_v3(_i), kind=("close", 2.5e-4), oracle_exact=False)
+    if PV3_CFGS[_i].get("iou"):  # no exp in IoUPredKernel: bit exact
+        _add("proposal_v3_%d_iou_loss" % _i, case_proposal_v3(_i))
+    else:
+        _add("proposal_v3_%d" % _i, case_proposal_v3(_i), kind=("close", 2.5e-4), oracle_exact=False)
 for _ca in (True, False):
     for _xy in (False, True):
         _add("decode_bbox_%s_%s" % ("agn" if _ca else "cls", "xyxy" if _xy else "xywh"), case_decode_bbox(_ca, _xy))

@@ -75,7 +75,7 @@ def test_proposal_v3_expf_difference_is_one_ulp_and_rare():
     """The only non-bit-exact pin: CUDA's exp(float) is glibc expf in the emulation while the oracle
     (and the HIP kernel) use the correctly rounded value; scores, order and kept set are identical
     and < 0.5 % of the coordinates move by one ulp."""
-    for name in [n for n in NAMES if n.startswith("proposal_v3_")]:
+    for name in [n for n in NAMES if n.startswith("proposal_v3_") and not n.endswith("_iou_loss")]:
         res = refcases.run_case(name, "oracle")
         want_b, want_s = ARRAYS[name + "/output"], ARRAYS[name + "/score"]
         np.testing.assert_array_equal(res["score"], want_s)
