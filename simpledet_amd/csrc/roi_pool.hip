@@ -94,15 +94,27 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(PoolArgs a) {
 // (The first version ran per-lane loops: 95% VALU-busy, 11 VALU per LDS read.)
 constexpr int kPoolChunk = 256;
 
-template <int PHc, int PWc>  // 0, 0: runtime pooled size
-__global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
-  constexpr int T = 512, CHUNK = kPoolChunk, NWAVE = T / kWave;
+// CC = 4 (round 3): the workgroup holds FOUR consecutive channel planes, interleaved per pixel
+// ([pixel][4]), so one ds_read_b128 serves four channels and the clamped column / row index of a
+// visit is computed once for them (7 -> ~4 VALU per channel visit); the four 196-byte output rows
+// of a RoI are one contiguous 784-byte run.
+// Its outputs leave as 16-byte stores: a wave stages the 4 x 49 values of a RoI in LDS and 49 lanes
+// write the 784-byte run as dwordx4 (4-byte stores cost ~6x the dwordx4 time per byte, and the two
+// outputs are 92 % of this op's traffic).  One workgroup of 1024 lanes per CU (the four planes, the
+// RoI tables and the staging rows take 110 KB).
+template <int PHc, int PWc, int CC, int T>  // PHc = PWc = 0: runtime pooled size
+__global__ __launch_bounds__(T) void roi_pool_fwd_plane_kernel(PoolArgs a) {
+  constexpr int CHUNK = kPoolChunk, NWAVE = T / kWave;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int HW = a.H * a.W;
   const int PH = PHc ? PHc : a.PH, PW = PWc ? PWc : a.PW, PP = PH * PW;
   const int ES = 4 + PH + PW;  // table words per RoI: index, valid, max extents, row / column pairs
   float* plane = smem;
-  int* tab = reinterpret_cast<int*>(smem + ((HW + 3) & ~3));
+  int* tab = reinterpret_cast<int*>(smem + ((HW * CC + 3) & ~3));
+  constexpr bool STAGE = CC == 4 && PHc * PWc > 0 && PHc * PWc <= kWave;
+  // per wave 2 x (CC x PP) floats, 16-byte aligned, behind the tables
+  float* stage = reinterpret_cast<float*>(tab + ((CHUNK * ES + 3) & ~3)) +
+                 (STAGE ? (threadIdx.x / kWave) * 2 * ((CC * PHc * PWc + 3) & ~3) : 0);
   // chunk counters, one per chunk parity: the counter of the NEXT chunk is reset after this
   // chunk's listing barrier, when no wave can still be reading it (a single counter reset at the
   // top of the loop raced with slow waves reading the previous chunk's count)
@@ -113,9 +125,16 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
   // cache lines: neighbouring channels go to the SAME XCD so that one L2 assembles whole lines
   // (channel = XCD's eighth of the range + position within it).
   const int b = blockIdx.y;
-  const int c = (a.C & 7) == 0 ? (int)(blockIdx.x & 7) * (a.C >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int G = a.C / CC;  // channel groups
+  const int c = CC * ((G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
   const float* src = a.data + ((long)b * a.C + c) * HW;
-  for (int i = tid; i < HW; i += T) plane[i] = src[i];
+  if (CC == 1) {
+    for (int i = tid; i < HW; i += T) plane[i] = src[i];
+  } else {
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc)
+      for (int i = tid; i < HW; i += T) plane[i * CC + cc] = src[(long)cc * HW + i];
+  }
 
   if (tid == 0) cnt[0] = 0;
   for (int k0 = 0, par = 0; k0 < a.K; k0 += CHUNK, par ^= 1) {
@@ -177,24 +196,57 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_plane_kernel(PoolArgs a) {
           hend = wend = 1;
         }
         const int hl = hend - 1, wl = wend - 1;
-        float maxval = -FLT_MAX;
-        int maxi = -1;
+        float maxval[CC];
+        int maxi[CC];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+          maxval[cc] = -FLT_MAX;
+          maxi[cc] = -1;
+        }
         for (int dh = 0; dh < hext; ++dh) {
           const int ib = iminr(hstart + dh, hl) * a.W;
-          const float* row = plane + ib;
+          const float* row = plane + ib * CC;
 #pragma unroll 4
           for (int dw = 0; dw < wext; ++dw) {
             const int w = iminr(wstart + dw, wl);
-            const float v = row[w];
-            if (v > maxval) {
-              maxval = v;
-              maxi = ib + w;
+            float v[CC];
+            if (CC == 4) {
+              const float4 q = *reinterpret_cast<const float4*>(row + w * 4);
+              v[0] = q.x; v[1 % CC] = q.y; v[2 % CC] = q.z; v[3 % CC] = q.w;
+            } else {
+#pragma unroll
+              for (int cc = 0; cc < CC; ++cc) v[cc] = row[w * CC + cc];
             }
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc)
+              if (v[cc] > maxval[cc]) {
+                maxval[cc] = v[cc];
+                maxi[cc] = ib + w;
+              }
           }
         }
-        if (active) {
-          a.out[obase + bin] = is_empty ? 0.f : maxval;
-          a.maxidx[obase + bin] = (float)(is_empty ? -1 : maxi);
+        if (STAGE) {
+          constexpr int RUN = (CC * PHc * PWc + 3) & ~3;
+          if (active) {
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+              stage[cc * PP + bin] = is_empty ? 0.f : maxval[cc];
+              stage[RUN + cc * PP + bin] = (float)(is_empty ? -1 : maxi[cc]);
+            }
+          }
+          // (the LDS operations of one wave complete in order: no barrier between the two halves)
+          if (lane * 4 < CC * PP) {
+            const float4 o = *reinterpret_cast<const float4*>(stage + lane * 4);
+            const float4 m = *reinterpret_cast<const float4*>(stage + RUN + lane * 4);
+            *reinterpret_cast<float4*>(a.out + obase + lane * 4) = o;
+            *reinterpret_cast<float4*>(a.maxidx + obase + lane * 4) = m;
+          }
+        } else if (active) {
+#pragma unroll
+          for (int cc = 0; cc < CC; ++cc) {
+            a.out[obase + cc * PP + bin] = is_empty ? 0.f : maxval[cc];
+            a.maxidx[obase + cc * PP + bin] = (float)(is_empty ? -1 : maxi[cc]);
+          }
         }
       }
     }
@@ -276,13 +328,22 @@ extern "C" int sd_roi_pool_v1_fwd(const float* data, const float* rois, float* o
   SD_REQUIRE(data && rois && out && maxidx, "null tensor pointer");
   PoolArgs a{data, rois, out, maxidx, B, C, H, W, K, pooled_h, pooled_w, spatial_scale};
   const size_t lds = (size_t)((((long)H * W + 3) & ~3L) + kPoolChunk * (4 + pooled_h + pooled_w)) * 4;
-  if (lds <= 64 * 1024 && H <= 32767 && W <= 32767 && B >= 1 && B <= 65535 &&
-      tuning("roi_pool_fwd", 1) == 1) {
+  // four planes + tables + per-wave staging rows (7x7 only), one workgroup of 1024 lanes per CU
+  const size_t lds4 = (size_t)((long)H * W * 4 + ((kPoolChunk * (4 + 7 + 7) + 3) & ~3) + 16 * 2 * 196) * 4;
+  const int mode = tuning("roi_pool_fwd", 1);  // 1 default (four channels per workgroup when they fit), 2 one channel, 0 per-item kernel
+  if (lds <= 64 * 1024 && H <= 32767 && W <= 32767 && B >= 1 && B <= 65535 && mode != 0) {
     // (with B == 0 every batch index is out of range: the wave-per-item kernel writes the zeros)
-    if (pooled_h == 7 && pooled_w == 7)
-      hipLaunchKernelGGL((roi_pool_fwd_plane_kernel<7, 7>), dim3(C, B), dim3(512), lds, (hipStream_t)stream, a);
-    else
-      hipLaunchKernelGGL((roi_pool_fwd_plane_kernel<0, 0>), dim3(C, B), dim3(512), lds, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1 && C % 4 == 0 && pooled_h == 7 && pooled_w == 7 && lds4 <= 150 * 1024 &&
+        (((uintptr_t)out | (uintptr_t)maxidx) & 15) == 0) {
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_pool_fwd_plane_kernel<7, 7, 4, 1024>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+      hipLaunchKernelGGL((roi_pool_fwd_plane_kernel<7, 7, 4, 1024>), dim3(C / 4, B), dim3(1024), lds4, st, a);
+    } else if (pooled_h == 7 && pooled_w == 7) {
+      hipLaunchKernelGGL((roi_pool_fwd_plane_kernel<7, 7, 1, 512>), dim3(C, B), dim3(512), lds, st, a);
+    } else {
+      hipLaunchKernelGGL((roi_pool_fwd_plane_kernel<0, 0, 1, 512>), dim3(C, B), dim3(512), lds, st, a);
+    }
     SD_LAUNCH_CHECK();
     return SD_OK;
   }

@@ -39,7 +39,7 @@ def test_roi_pool_reference_docstring_golden_on_gpu(ops):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(0, 7, 7, 1 / 32.0), (1, 7, 7, 1 / 16.0), (2, 3, 5, 1 / 32.0),
                                   (3, 14, 14, 1 / 32.0)])
-@pytest.mark.parametrize("fwd", [1, 0])  # plane in LDS (default), wave per (roi, channel)
+@pytest.mark.parametrize("fwd", [1, 2, 0])  # four planes in LDS (default), one plane, wave per (roi, channel)
 def test_roi_pool_forward_backward(ops, oracle, case, fwd):
     from simpledet_amd._lib import lib
     seed, ph, pw, scale = case
@@ -79,12 +79,13 @@ def test_roi_pool_forward_kernels_agree_at_c4_size(ops):
     bi[[7, 600]] = [[5.0], [-2.0]]
     rois = _t(np.concatenate([bi, r], 1))
     o1, i1 = ops.roi_pool_v1_forward(data, rois, (7, 7), 1 / 16.0)
-    lib().set_tuning("roi_pool_fwd", 0)
-    try:
-        o0, i0 = ops.roi_pool_v1_forward(data, rois, (7, 7), 1 / 16.0)
-    finally:
-        lib().set_tuning("roi_pool_fwd", 1)
-    assert torch.equal(o1, o0) and torch.equal(i1, i0)
+    for mode in (0, 2):
+        lib().set_tuning("roi_pool_fwd", mode)
+        try:
+            o0, i0 = ops.roi_pool_v1_forward(data, rois, (7, 7), 1 / 16.0)
+        finally:
+            lib().set_tuning("roi_pool_fwd", 1)
+        assert torch.equal(o1, o0) and torch.equal(i1, i0), mode
     assert float(o1[[7, 600]].abs().max()) == 0 and float((i1[[7, 600]] + 1).abs().max()) == 0
 
 
