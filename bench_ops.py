@@ -334,6 +334,10 @@ def run(seed=0, cpu=True, only=None):
         grads = (torch.empty_like(x), torch.empty_like(off), torch.empty_like(wt))
         ms_b = _time_gpu(lambda: ops.deform_conv_backward(dyc, x, off, wt, 1, 1, 1, 4, grads=grads),
                          iters=6, warm=2)
+        _, fws = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4, keep_col=True)
+        ms_bc = _time_gpu(lambda: ops.deform_conv_backward(dyc, x, off, wt, 1, 1, 1, 4, grads=grads, fwd_ws=fws),
+                          iters=6, warm=2)
+        del fws
         colm = ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4)
         ms_c2i = _time_gpu(lambda: ops.deform_col2im(colm, off, x.shape, (3, 3), 1, 1, 1, 4), iters=10, warm=2)
         ms_crd = _time_gpu(lambda: ops.deform_col2im_coord(colm, x, off, (3, 3), 1, 1, 1, 4), iters=20, warm=2)
@@ -346,7 +350,7 @@ def run(seed=0, cpu=True, only=None):
             "im2col_ms": ms_i, "im2col_GBs": im2col_bytes / ms_i / 1e6,
             "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
             "col2im_ms": ms_c2i, "col2im_coord_ms": ms_crd,
-            "fwd_ms": ms_f, "bwd_ms": ms_b, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
+            "fwd_ms": ms_f, "bwd_ms": ms_b, "bwd_with_forward_col_ms": ms_bc, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
             # fp32 products as three bf16 MFMA terms (hi/lo split): 3 x the flops on the bf16 pipe
             "gemm_arith": "fp32 in/out, 3 bf16 MFMA terms per product (deform_gemm_split=1)",
             "gemm_frac_of_bf16_mfma_peak": 3.0 * flops / gemm_ms / 1e9 / PEAK_BF16_MFMA_TFLOPS,

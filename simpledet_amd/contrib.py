@@ -102,7 +102,9 @@ class _DeformConv(torch.autograd.Function):
     def forward(ctx, data, offset, weight, pad, stride, dilate, dg):
         ctx.save_for_backward(data, offset, weight)
         ctx.cfg = (pad, stride, dilate, dg)
-        return ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg)
+        # the col matrix stays alive for the backward (which then skips its own im2col)
+        y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg, keep_col=True)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -111,7 +113,8 @@ class _DeformConv(torch.autograd.Function):
         need = ctx.needs_input_grad
         req = tuple("write" if n else "null" for n in need[:3])
         dx, doff, dw = ops.deform_conv_backward(dy.contiguous(), data, offset, weight, pad, stride,
-                                                dilate, dg, req=req)
+                                                dilate, dg, req=req, fwd_ws=ctx.fwd_ws)
+        ctx.fwd_ws = None
         return (dx if need[0] else None, doff if need[1] else None, dw if need[2] else None, None,
                 None, None, None)
 

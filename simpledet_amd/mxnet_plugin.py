@@ -631,6 +631,9 @@ def _build_ops(mx):
             lib().call("sd_deform_conv_fwd", _ptr(x), _ptr(off), _ptr(w), _ptr(out_data[0]), N, C, H,
                        W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"],
                        _ptr(ws), ctypes.c_size_t(n), None)
+            # training: the col matrix stays alive until this node's backward, which then skips its
+            # own im2col (the reference recomputes it; 288 GB of HBM make keeping it the cheaper side)
+            self._fwd_ws = (ws, tuple(x.shape)) if (is_train and g["cache_col"]) else None
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
@@ -639,16 +642,28 @@ def _build_ops(mx):
             g = self.g
             N, C, H, W = x.shape
             ws, n = self._ws(x)
-            lib().call("sd_deform_conv_bwd", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w),
-                       _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]), _req(req[0]),
-                       _req(req[1]), _req(req[2]), N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"],
-                       g["stride"], g["dil"], g["dg"], _ptr(ws), ctypes.c_size_t(n), None)
+            kept = getattr(self, "_fwd_ws", None)
+            self._fwd_ws = None
+            if kept is not None and kept[1] == tuple(x.shape):
+                col = lib().cdll.sd_deform_conv_col_of_workspace(_ptr(kept[0]))
+                lib().call("sd_deform_conv_bwd_cached", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w),
+                           ctypes.c_void_p(col), _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]),
+                           _req(req[0]), _req(req[1]), _req(req[2]), N, C, H, W, g["F"], g["kh"],
+                           g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], _ptr(ws),
+                           ctypes.c_size_t(n), None)
+            else:
+                lib().call("sd_deform_conv_bwd", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w),
+                           _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]), _req(req[0]),
+                           _req(req[1]), _req(req[2]), N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"],
+                           g["stride"], g["dil"], g["dg"], _ptr(ws), ctypes.c_size_t(n), None)
             _sync()
 
     class DeformConvProp(CustomOpProp):
         def __init__(self, kernel, num_filter, stride="(1,1)", dilate="(1,1)", pad="(0,0)",
                      num_group="1", num_deformable_group="1", no_bias="False", workspace="1024",
-                     layout="None"):
+                     layout="None", cache_col="True"):
+            # cache_col is this adapter's own attribute: keep the forward's col matrix for the
+            # backward of the same node (training only)
             super().__init__(need_top_grad=True)
             k, s, d, p = (_tuple(kernel, 2, int), _tuple(stride, 2, int), _tuple(dilate, 2, int),
                           _tuple(pad, 2, int))
@@ -659,7 +674,7 @@ def _build_ops(mx):
             if s[0] != s[1] or d[0] != d[1] or p[0] != p[1]:
                 raise ValueError("DeformableConvolution: square stride/dilate/pad only")
             self.g = dict(kh=k[0], kw=k[1], stride=s[0], dil=d[0], pad=p[0], F=int(num_filter),
-                          dg=int(num_deformable_group))
+                          dg=int(num_deformable_group), cache_col=_bool(cache_col))
 
         def list_arguments(self):
             return ["data", "offset", "weight"]

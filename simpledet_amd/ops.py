@@ -753,8 +753,11 @@ def _dcn_ws(x, kh, kw, pad, stride, dilate):
     return torch.empty(n, device=x.device, dtype=torch.uint8), n
 
 
-def deform_conv_forward(x, offset, weight, pad=1, stride=1, dilate=1, num_deformable_group=1):
-    """DeformableConvolution forward (num_group=1, no_bias): y (N,F,Ho,Wo)."""
+def deform_conv_forward(x, offset, weight, pad=1, stride=1, dilate=1, num_deformable_group=1,
+                        keep_col=False):
+    """DeformableConvolution forward (num_group=1, no_bias): y (N,F,Ho,Wo).  keep_col=True returns
+    (y, workspace): the workspace holds the col matrix; handed to deform_conv_backward(fwd_ws=...)
+    it saves the backward its own im2col."""
     _chk(x, "data", ndim=4)
     _chk(offset, "offset", ndim=4)
     _chk(weight, "weight", ndim=4)
@@ -770,12 +773,14 @@ def deform_conv_forward(x, offset, weight, pad=1, stride=1, dilate=1, num_deform
     ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
     lib().call("sd_deform_conv_fwd", _p(x), _p(offset), _p(weight), _p(y), N, C, H, W, F, kh, kw,
                pad, stride, dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
-    return y
+    return (y, ws) if keep_col else y
 
 
 def deform_conv_backward(out_grad, x, offset, weight, pad=1, stride=1, dilate=1,
-                         num_deformable_group=1, req=("write", "write", "write"), grads=None):
-    """-> (d_data, d_offset, d_weight)."""
+                         num_deformable_group=1, req=("write", "write", "write"), grads=None,
+                         fwd_ws=None):
+    """-> (d_data, d_offset, d_weight).  fwd_ws: the workspace deform_conv_forward(keep_col=True)
+    returned for the same (x, offset): its col matrix is reused (sd_deform_conv_bwd_cached)."""
     _chk(out_grad, "out_grad", ndim=4)
     N, C, H, W = x.shape
     F, _, kh, kw = weight.shape
@@ -783,6 +788,13 @@ def deform_conv_backward(out_grad, x, offset, weight, pad=1, stride=1, dilate=1,
     if grads is None:
         grads = (torch.empty_like(x), torch.empty_like(offset), torch.empty_like(weight))
     ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
+    if fwd_ws is not None:
+        col = (fwd_ws.data_ptr() + 255) & ~255  # sd_deform_conv_col_of_workspace
+        lib().call("sd_deform_conv_bwd_cached", _p(out_grad), _p(x), _p(offset), _p(weight),
+                   ctypes.c_void_p(col), _p(grads[0]), _p(grads[1]), _p(grads[2]), r[0], r[1], r[2], N, C,
+                   H, W, F, kh, kw, pad, stride, dilate, int(num_deformable_group), _p(ws),
+                   ctypes.c_size_t(n), _stream())
+        return grads
     lib().call("sd_deform_conv_bwd", _p(out_grad), _p(x), _p(offset), _p(weight), _p(grads[0]),
                _p(grads[1]), _p(grads[2]), r[0], r[1], r[2], N, C, H, W, F, kh, kw, pad, stride,
                dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())

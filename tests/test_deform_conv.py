@@ -289,3 +289,31 @@ def test_deform_conv_at_the_baseline_shape(ops, oracle):
     for name, got, wnt in (("d_data", dx, wdx), ("d_offset", doff, wdo), ("d_weight", dw.reshape(F, K), wdw)):
         err = float(np.abs(got - wnt).max())
         assert err <= 1e-4 * max(1.0, float(np.abs(wnt).max())), (name, err, float(np.abs(wnt).max()))
+
+
+@pytest.mark.gpu
+def test_backward_with_the_forward_col_matrix(ops):
+    """sd_deform_conv_bwd_cached: the col matrix left in the forward's workspace replaces the
+    backward's own im2col -- same bits for d_offset (a per-lane reduction), d_data and d_weight up
+    to the order of their atomic accumulations (LDS adds / adds over images: 1e-5 x max, as between
+    two runs of the plain backward); the autograd mirror uses it."""
+    import torch
+    from simpledet_amd import contrib
+    torch.manual_seed(4)
+    N, C, H, W, F = 3, 32, 20, 28, 24
+    x = torch.randn(N, C, H, W, device="cuda")
+    off = torch.randn(N, 4 * 18, H, W, device="cuda") * 1.5
+    w = torch.randn(F, C, 3, 3, device="cuda") * 0.1
+    y, fws = ops.deform_conv_forward(x, off, w, 1, 1, 1, 4, keep_col=True)
+    dy = torch.randn_like(y)
+    a = ops.deform_conv_backward(dy, x, off, w, 1, 1, 1, 4)
+    b = ops.deform_conv_backward(dy, x, off, w, 1, 1, 1, 4, fwd_ws=fws)
+    close = lambda u, v: float((u - v).abs().max()) <= 1e-5 * float(v.abs().max())
+    assert torch.equal(a[1], b[1]) and close(b[0], a[0]) and close(b[2], a[2])
+    # autograd mirror == raw calls
+    xr, offr, wr = (t.clone().requires_grad_(True) for t in (x, off, w))
+    out = contrib.DeformableConvolution(xr, offr, wr, kernel=(3, 3), pad=(1, 1), num_filter=F,
+                                        num_deformable_group=4, no_bias=True)
+    out.backward(dy)
+    assert torch.equal(out.detach(), y) and torch.equal(offr.grad, a[1])
+    assert close(xr.grad, a[0]) and close(wr.grad, a[2])
