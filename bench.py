@@ -339,7 +339,12 @@ def main():
     # correction, confirmed on the known-size hbm_stream_copy in the same profile) + WRITE_SIZE
     traffic, traffic_source, bwd_traffic = None, None, None
     import glob
-    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))[::-1]:
+    import re
+    # profiles of THIS command only (rNN<letter>_pmc_summary.json); *_ops_* are bench_ops profiles and
+    # stale_* are superseded ones
+    cands = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
+             if re.match(r"^r\d+[a-z]?_pmc_summary\.json$", os.path.basename(f))]
+    for pmc_path in sorted(cands)[::-1]:
         try:
             ks = json.load(open(pmc_path))["kernels"]
             # the step's kernel is the most-dispatched forward / backward kernel of the profile
