@@ -28,6 +28,16 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned char* am, const i
         }
       } else if (mode == 3) {
         for (int g = 0; g < 4; ++g) am[ao + g * 52 + q] = (unsigned char)q;
+      } else if (mode == 5) {
+        // RoI-wise: the 4 x 49 values of (RoI, 4 channels) as one aligned 784-byte run, 49 lanes x 16 B;
+        // a wave pass covers one RoI (instead of 9 rows), so 7 such stores carry what 4 x 7 row stores do
+        if (j == 0 && q == 0) {}
+        const int it7 = (blockIdx.x * 64 + wave * 4 + p) * 9;  // first item of this pass
+        const long n0 = items[it7 < nitems ? it7 : 0] & 0xffff;
+        for (int r = 0; r < 9; r += 7) {  // ~9/7 RoIs per pass: keep the byte count equal on average
+          const long base = ((n0 + r) % 1024 * C + ch) * 49;
+          if (lane < 49 && (r == 0 || (p & 3) < 1)) *reinterpret_cast<float4*>(out + base + lane * 4) = make_float4(v, v, v, v);
+        }
       } else if (mode == 4) {
         if (q < 4) {
           unsigned char* p0 = am + ao + q * 52;
@@ -51,7 +61,7 @@ int main() {
   hipMemcpy(d, items.data(), nitems * 4, hipMemcpyHostToDevice);
   const dim3 grid((nitems + 64 * 9 - 1) / (64 * 9), 16);  // 13 x 16 = 208 workgroups of 16 waves
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 1; mode <= 4; ++mode) {
+  for (int mode = 1; mode <= 5; ++mode) {
     for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k, grid, dim3(1024), 0, 0, out, am, d, nitems, mode, C);
     hipEventRecord(e0);
     for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL(k, grid, dim3(1024), 0, 0, out, am, d, nitems, mode, C);
