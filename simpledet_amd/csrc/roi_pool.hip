@@ -9,8 +9,10 @@
 // backward (roi_pool_bwd_lds_kernel): workgroup = (image, channel, row band) with the band of dX
 //   in LDS; the bins of the image's RoIs whose arg-max falls in the band are added with an LDS
 //   compare-and-swap and the band is written once: no zero-fill pass, no global atomics
-//   (1.71 -> 0.24 ms on the C4 shape).  roi_pool_bwd = 0 selects the reference structure
-//   (zero-fill + global atomics), also the fallback when the RoI list does not fit in LDS.
+//   (1.71 -> 0.24 ms on the C4 shape); with C % 4 == 0 four channels per workgroup and 16-byte
+//   loads (roi_pool_bwd_lds4_kernel: 0.11 ms).  roi_pool_bwd = 2 keeps one channel per workgroup,
+//   0 selects the reference structure (zero-fill + global atomics), also the fallback when the RoI
+//   list does not fit in LDS.
 #include "common.h"
 #include "../../include/simpledet_ops.h"
 #include <float.h>
@@ -313,6 +315,49 @@ __global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(PoolBwdArgs a, in
   for (int i = tid; i < band_elems; i += T) dst[i] = req_add ? dst[i] + plane[i] : plane[i];
 }
 
+// Four channels per workgroup (round 3): the arg-max and gradient rows of (RoI, c..c+3) are 784
+// contiguous, 16-byte aligned bytes, read as dwordx4 (a quarter of the load instructions, no
+// division per element); four whole planes of dX in LDS (67 KB at 50x84, two workgroups per CU).
+//   grid: x = channel quad, y = image
+__global__ __launch_bounds__(512) void roi_pool_bwd_lds4_kernel(PoolBwdArgs a, int req_add) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = 512, CC = 4;
+  const int tid = threadIdx.x;
+  const int G = a.C / CC;
+  const int c = CC * ((G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+  const int b = blockIdx.y;
+  const int HW = a.H * a.W;
+  float* plane = smem;  // [CC][HW]
+  int* list = reinterpret_cast<int*>(smem + CC * HW);
+  int* nlist = list + a.K;
+  for (int i = tid; i < CC * HW; i += T) plane[i] = 0.f;
+  if (tid == 0) *nlist = 0;
+  __syncthreads();
+  for (int n = tid; n < a.K; n += T)
+    if ((int)a.rois[(long)n * 5] == b) list[atomicAdd(nlist, 1)] = n;
+  __syncthreads();
+  const int PP = a.PP;           // CC * PP is a multiple of 4 (host)
+  const int per = CC * PP / 4;   // float4 units per RoI
+  const int nunits = *nlist * per;
+  for (int u = tid; u < nunits; u += T) {
+    const int r = u / per, L = u - r * per;
+    const long idx = ((long)list[r] * a.C + c) * PP + 4 * L;
+    const float4 am = *reinterpret_cast<const float4*>(a.maxidx + idx);
+    const float4 g = *reinterpret_cast<const float4*>(a.dy + idx);
+    const float amv[4] = {am.x, am.y, am.z, am.w}, gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = 4 * L + k;
+      const int cc = (e >= PP) + (e >= 2 * PP) + (e >= 3 * PP);
+      const int argmax = (int)amv[k];
+      if (argmax >= 0 && argmax < HW) lds_add_cas(plane + cc * HW + argmax, gv[k]);
+    }
+  }
+  __syncthreads();
+  float* dst = a.dx + ((long)b * a.C + c) * HW;  // the four planes are contiguous
+  for (int i = tid; i < CC * HW; i += T) dst[i] = req_add ? dst[i] + plane[i] : plane[i];
+}
+
 }  // namespace sd
 
 using namespace sd;
@@ -379,8 +424,17 @@ extern "C" int sd_roi_pool_v1_bwd(const float* out_grad, const float* rois, cons
     int rows = (H + nb - 1) / nb;
     nb = (H + rows - 1) / rows;
     const size_t lds = (size_t)((((long)rows * W + 3) & ~3L) * 4) + (size_t)(K + 4) * 4;
-    if (lds <= 150 * 1024 && C <= 65535 * 32 && nb <= 65535 && B <= 65535 &&
-        tuning("roi_pool_bwd", 1) == 1) {
+    const size_t lds4 = (size_t)H * W * 16 + (size_t)(K + 4) * 4;
+    const int mode = tuning("roi_pool_bwd", 1);  // 1 default, 2 one channel per workgroup, 0 global atomics
+    if (mode == 1 && C % 4 == 0 && lds4 <= 76 * 1024 && B <= 65535 &&
+        (((uintptr_t)out_grad | (uintptr_t)maxidx) & 15) == 0) {
+      if (lds4 > 64 * 1024)
+        SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_pool_bwd_lds4_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+      hipLaunchKernelGGL(roi_pool_bwd_lds4_kernel, dim3(C / 4, B), dim3(512), lds4, st, a,
+                         req_data == SD_REQ_ADD ? 1 : 0);
+      SD_LAUNCH_CHECK();
+    } else if (lds <= 150 * 1024 && C <= 65535 * 32 && nb <= 65535 && B <= 65535 && mode != 0) {
       if (lds > 64 * 1024)
         SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_pool_bwd_lds_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

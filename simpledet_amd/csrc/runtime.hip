@@ -60,7 +60,7 @@ Knob g_knobs[] = {
     {"roi_align_bwd_tch", 0, false},     // RoIs per staged coordinate-table chunk (7x7: 16/32/64, 14x14: 8/16/32)
     {"roi_align_bwd_lists", 0, false},   // workspace pre-pass: 1 RoI lists + tap tables per band unit (default), 2 lists only, 0 none
     {"roi_pool_fwd", 0, false},          // 0 wave per (roi, channel), 1 four planes in LDS per workgroup (default), 2 one plane
-    {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes (default)
+    {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes, four channels per workgroup (default), 2 one channel
     {"proposal_topk", 0, false},         // 0 by level size (default), 1 single workgroup, 2 multi-workgroup
     {"top_proposal_select", 0, false},   // 1 radix select before the sort when top_n < N (default)
     {"soft_nms_threads", 0, false},      // threads per problem: 64, 128 or 256 (default)

@@ -121,6 +121,18 @@ def test_roi_pool_backward_bands_and_fallback(ops, oracle):
     o, ix = ops.roi_pool_v1_forward(big, br, (7, 7), 1 / 16.0)
     gy = torch.rand_like(o)
     gx, _ = ops.roi_pool_v1_backward(gy, br, ix, big.shape, 1 / 16.0)
+    # (64 channels: the four-channel kernel) == the one-channel LDS kernel == the global-atomic structure,
+    # also with kAddTo
+    for mode in (2, 0):
+        lib().set_tuning("roi_pool_bwd", mode)
+        try:
+            gm, _ = ops.roi_pool_v1_backward(gy, br, ix, big.shape, 1 / 16.0)
+        finally:
+            lib().set_tuning("roi_pool_bwd", 1)
+        assert float((gm - gx).abs().max()) <= 1e-5 * float(gx.abs().max()), mode
+    ga, _ = ops.roi_pool_v1_backward(gy, br, ix, big.shape, 1 / 16.0, req_data="add", req_rois="null",
+                                     d_data=gx.clone())
+    assert float((ga - 2 * gx).abs().max()) <= 1e-5 * float(gx.abs().max())
     tot = float((gy * (ix >= 0)).double().sum())
     assert abs(float(gx.double().sum()) - tot) <= 1e-6 * max(1.0, abs(tot))
     # the pooled value is the feature at the recorded arg-max
