@@ -2493,6 +2493,65 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   }
 }
 
+// The drop-in ROIAlign_v2 backward on a map whose four channel planes fit in LDS together (the C4
+// family: (2,1024,50,84), `config/faster_r50v1c4_c5_512roi_1x.py:90-94`), round 3.  Per channel the
+// out_grad / arg-max rows of a RoI are 196 bytes at a stride of C * 196: one channel per workgroup
+// reads 196-byte fragments.  Here a workgroup owns FOUR consecutive channels of one image: the rows
+// of (RoI, c..c+3) are 784 contiguous, 16-byte aligned bytes of each of the three inputs, read as
+// dwordx4, and the four dX planes leave as one contiguous run.  The scatter is the reference's
+// (roi_align_v2.cu:35-84: every bin with an arg-max adds its four bilinear terms; the RoI geometry
+// is not read) with fp32 compare-and-swap adds in LDS.
+//   grid: x = channel quad, y = image; LDS = 4 * H * W floats
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArgs a, int lvl) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CC = 4;
+  const int tid = threadIdx.x;
+  const int G = a.C / CC;
+  const int c = CC * ((G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+  const int img = blockIdx.y;
+  const int H = a.L.H[lvl], W = a.L.W[lvl], HW = H * W, PP = a.PP;
+  float* plane = smem;  // [CC][HW]
+  for (int i = tid; i < CC * HW; i += THREADS) plane[i] = 0.f;
+  __syncthreads();
+  const int per = CC * PP / 4;  // float4 units per RoI (CC * PP is a multiple of 4)
+  const int nunits = a.R * per;
+  const long base = ((long)img * a.R * a.C + c) * PP;
+  const long roi_stride = (long)a.C * PP;
+  for (int u = tid; u < nunits; u += THREADS) {
+    const int r = u / per, L = u - r * per;
+    const long idx = base + r * roi_stride + 4 * L;
+    const float4 g4 = *reinterpret_cast<const float4*>(a.dy + idx);
+    const float4 x4 = *reinterpret_cast<const float4*>(a.ax + idx);
+    const float4 y4 = *reinterpret_cast<const float4*>(a.ay + idx);
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a_x = xx[k], a_y = yy[k];
+      if (a_x == -1.f || a_y == -1.f) continue;  // roi_align_v2.cu:53: nothing was pooled
+      const int e = 4 * L + k;
+      const int cc = (e >= PP) + (e >= 2 * PP) + (e >= 3 * PP);
+      const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+      const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+      const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+      const int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+      // (v - low) / (high - low) with high - low == 1
+      const float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow);
+      const float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft);
+      const float g = gg[k];
+      float* pl = plane + cc * HW;
+      lds_add_cas(pl + hlow * W + wleft, g * (1 - alpha) * (1 - beta));
+      lds_add_cas(pl + hlow * W + wright, g * (1 - alpha) * beta);
+      lds_add_cas(pl + hhigh * W + wleft, g * alpha * (1 - beta));
+      lds_add_cas(pl + hhigh * W + wright, g * alpha * beta);
+    }
+  }
+  __syncthreads();
+  float* dst = a.dx[lvl] + ((long)img * a.C + c) * HW;  // the four planes are contiguous
+  for (int i = tid; i < CC * HW; i += THREADS) dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
+}
+
 // levels: dx[l] / H / W / scale from a.L; returns SD_ERR_UNSUPPORTED when a level does not fit
 static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace = nullptr,
                             size_t workspace_bytes = 0) {
@@ -2504,6 +2563,18 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   const int ne = a.PP == 49 ? 3 * 14 : 3 * 28;  // sample coordinates per RoI
   a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
   if ((long)a.R * a.C * a.PP >= (1L << 31)) return SD_ERR_UNSUPPORTED;  // 32-bit lane offsets
+  // single-level float arg-max backward on a small map: four channels per workgroup
+  if (flt && !a.filter && nlvl == 1 && a.dx[0] && a.C % 4 == 0 && a.B <= 65535 &&
+      (long)a.L.H[0] * a.L.W[0] * 16 <= 72 * 1024 && tuning("roi_align_bwd_flt4", 1) == 1 &&
+      (((uintptr_t)a.dy | (uintptr_t)a.ax | (uintptr_t)a.ay) & 15) == 0) {
+    const size_t lds4 = (size_t)a.L.H[0] * a.L.W[0] * 16;
+    if (lds4 > 64 * 1024)
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_align_bwd_flt4_kernel<512>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    hipLaunchKernelGGL((roi_align_bwd_flt4_kernel<512>), dim3(a.C / 4, a.B), dim3(512), lds4, st, a, 0);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+  }
   size_t lds_max = 0;
   long work[SD_MAX_FPN_LEVELS];
   int nl = 0;

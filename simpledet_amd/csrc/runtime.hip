@@ -57,6 +57,7 @@ Knob g_knobs[] = {
     {"roi_align_bwd_order", 0, false},   // 0 longest workgroups first (default), 1 most workgroups first
     {"roi_align_bwd_threads", 0, false}, // 256 or 512 (default)
     {"roi_align_bwd_packed", 0, false},  // packed arg-max backward: 1 wide-load kernel (default), 0 per-item loads
+    {"roi_align_bwd_flt4", 0, false},    // 1 (default): single-level float arg-max backward with four channel planes per workgroup when they fit
     {"roi_align_bwd_tch", 0, false},     // RoIs per staged coordinate-table chunk (7x7: 16/32/64, 14x14: 8/16/32)
     {"roi_align_bwd_lists", 0, false},   // workspace pre-pass: 1 RoI lists + tap tables per band unit (default), 2 lists only, 0 none
     {"roi_pool_fwd", 0, false},          // 0 wave per (roi, channel), 1 four planes in LDS per workgroup (default), 2 one plane
