@@ -111,6 +111,15 @@ def run(seed=0, cpu=True, only=None):
             g = ops.proposal_mask_target(tr, tg, tp, 81, 2, 512, mask_size=28, rng_state=ops.glibc_rand_state(1))
             w = orc.proposal_mask_target(rois, gt, polys, p, 28, rng=orc.GlibcRand(1))
             res["proposal_mask_target"]["matches_oracle"] = same(g[0], w[0]) and same(g[5], w[5])
+        # output_ratio = true (mask scoring R-CNN): + two image-resolution rasters per foreground RoI
+        ms_r = _time_gpu(lambda: ops.proposal_mask_target(tr, tg, tp, 81, 2, 512, mask_size=28, rng_state=state,
+                                                          output_ratio=True))
+        res["proposal_mask_target"]["with_mask_ratio_ms"] = ms_r
+        if orc:
+            g = ops.proposal_mask_target(tr, tg, tp, 81, 2, 512, mask_size=28, rng_state=ops.glibc_rand_state(1),
+                                         output_ratio=True)
+            w = orc.proposal_mask_target(rois, gt, polys, p, 28, rng=orc.GlibcRand(1), output_ratio=True)
+            res["proposal_mask_target"]["mask_ratio_matches_oracle"] = same(g[6], w[7]) and same(g[5], w[5])
 
     # ---- RPN anchor targets: P2-P6, 267k anchors/img, <= 40 gt, 256 sampled (loader op in the reference) ----
     if want("rpn_anchor_target"):
@@ -151,6 +160,13 @@ def run(seed=0, cpu=True, only=None):
             res["nms"]["cpu_ms"] = _time_cpu(lambda: orc.nms(dets, 2000, 1000, 0.7))
             g, w = ops.nms(td, 2000, 1000, 0.7), orc.nms(dets, 2000, 1000, 0.7)
             res["nms"]["matches_oracle"] = same(g[0], w[0]) and same(g[1].reshape(w[1].shape), w[1])
+        # more rows than one LDS sort holds: radix select of the pre_nms_top_n best, then the sort
+        big = np.stack([synth.nms_dets(seed + 7 + i, 60000) for i in range(2)])
+        tb = T(big)
+        res["nms"]["n60000_pre6000_ms"] = _time_gpu(lambda: ops.nms(tb, 6000, 1000, 0.7))
+        if orc:
+            g, w = ops.nms(tb, 6000, 1000, 0.7), orc.nms(big, 6000, 1000, 0.7)
+            res["nms"]["n60000_matches_oracle"] = same(g[0], w[0]) and same(g[1].reshape(w[1].shape), w[1])
 
     # ---- Proposal_v3 over the five FPN levels + get_top_proposal ----
     if want("proposal_v3_fpn"):
