@@ -71,9 +71,14 @@ def run(seed=0, cpu=True, only=None):
         ms = _time_gpu(lambda: [ops.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
         nbytes = sum(16 * h * w * 3 for h, w in shapes)
         res["gen_anchor"] = {"ms": ms, "bytes": nbytes, "GBs": nbytes / ms / 1e6, "launches": 5}
+        ms1 = _time_gpu(lambda: ops.gen_anchor_levels(shapes, strides, [8], [0.5, 1, 2]))
+        res["gen_anchor"].update({"one_launch_ms": ms1, "one_launch_GBs": nbytes / ms1 / 1e6})
         if orc:
             res["gen_anchor"]["cpu_ms"] = _time_cpu(
                 lambda: [orc.gen_anchor(h, w, s, [8], [0.5, 1, 2]) for (h, w), s in zip(shapes, strides)])
+            res["gen_anchor"]["one_launch_matches_oracle"] = all(
+                same(g, orc.gen_anchor(h, w, st_, [8], [0.5, 1, 2]))
+                for g, ((h, w), st_) in zip(ops.gen_anchor_levels(shapes, strides, [8], [0.5, 1, 2]), zip(shapes, strides)))
             res["gen_anchor"]["matches_oracle"] = all(
                 same(ops.gen_anchor(h, w, s, [8], [0.5, 1, 2]), orc.gen_anchor(h, w, s, [8], [0.5, 1, 2]))
                 for (h, w), s in zip(shapes, strides))

@@ -222,6 +222,12 @@ int sd_roi_pool_v1_bwd(const float* out_grad, const float* rois, const float* ma
  * ---------------------------------------------------------------------------------------------- */
 int sd_gen_anchor(float* out, int H, int W, int feature_stride, const double* scales_host,
                   int n_scales, const double* ratios_host, int n_ratios, void* stream);
+/* the same for every pyramid level in ONE launch (the reference runs one GenAnchor node per level,
+ * models/FPN/builder.py; five 2.7 us kernels are launch bound): outs_host[l] = device buffer of
+ * level l (Hs[l] * Ws[l] * A rows), same scales / ratios on every level, its own stride */
+int sd_gen_anchor_levels(float* const* outs_host, const int* Hs_host, const int* Ws_host,
+                         const int* strides_host, int nlvl, const double* scales_host, int n_scales,
+                         const double* ratios_host, int n_ratios, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ProposalTarget  (mx.sym.ProposalTarget)

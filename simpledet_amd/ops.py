@@ -380,6 +380,23 @@ def gen_anchor(height, width, feature_stride, scales, ratios, device=None):
     return out
 
 
+def gen_anchor_levels(shapes, strides, scales, ratios, device=None):
+    """GenAnchor for every pyramid level in one launch: shapes [(H, W), ...], strides [...] ->
+    list of (H*W*A, 4) tensors (each equal to gen_anchor of that level)."""
+    scales, ratios = list(scales), list(ratios)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    A = len(scales) * len(ratios)
+    outs = [torch.empty((int(h) * int(w) * A, 4), device=device, dtype=torch.float32) for h, w in shapes]
+    n = len(outs)
+    ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    hs = (ctypes.c_int * n)(*[int(h) for h, _ in shapes])
+    ws = (ctypes.c_int * n)(*[int(w) for _, w in shapes])
+    st = (ctypes.c_int * n)(*[int(v) for v in strides])
+    lib().call("sd_gen_anchor_levels", ptrs, hs, ws, st, n, _darr(scales), len(scales), _darr(ratios),
+               len(ratios), _stream())
+    return outs
+
+
 # --------------------------------------------------------------------------------------------------
 # ProposalTarget  (operator_cxx/proposal_target{-inl.h,.cc})
 # --------------------------------------------------------------------------------------------------

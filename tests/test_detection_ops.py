@@ -164,6 +164,19 @@ def test_gen_anchor_fpn_levels_bit_exact(ops, oracle, stride, shape):
 
 
 @pytest.mark.gpu
+def test_gen_anchor_all_levels_in_one_launch(ops, oracle):
+    """sd_gen_anchor_levels == one sd_gen_anchor per level, bit for bit (P2-P6, the reference's
+    scales / ratios), including an empty level and more anchors per location than the one-launch
+    kernel holds (falls back to a launch per level)."""
+    shapes = [(200, 334), (100, 167), (50, 84), (25, 42), (13, 21), (0, 5)]
+    strides = [4, 8, 16, 32, 64, 128]
+    for scales, ratios in (([8], [0.5, 1.0, 2.0]), ([2, 4, 8, 16, 32], [0.5, 1.0, 2.0])):
+        got = ops.gen_anchor_levels(shapes, strides, scales, ratios)
+        for g, (h, w), st in zip(got, shapes, strides):
+            np.testing.assert_array_equal(g.cpu().numpy(), oracle.gen_anchor(h, w, st, scales, ratios))
+
+
+@pytest.mark.gpu
 def test_gen_anchor_matches_reference_numpy_twin_fixture(ops):
     g = np.load(os.path.join(GOLD, "anchors.npz"))
     for stride in (4, 8, 16, 32, 64):
