@@ -64,7 +64,11 @@ def header_abi_version(path=HEADER):
 
 
 class SimpleDetOpsError(RuntimeError):
-    pass
+    """code: the SD_ERR_* value the entry point returned (include/simpledet_ops.h)."""
+    code = 0
+
+
+SD_ERR_UNSUPPORTED = -2
 
 
 class _Lib:
@@ -103,7 +107,9 @@ class _Lib:
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
             msg = self.cdll.sd_last_error()
-            raise SimpleDetOpsError("%s failed (%d): %s" % (name, rc, (msg or b"").decode()))
+            err = SimpleDetOpsError("%s failed (%d): %s" % (name, rc, (msg or b"").decode()))
+            err.code = int(rc)
+            raise err
         return rc
 
     def set_tuning(self, key, value):

@@ -759,8 +759,7 @@ constexpr int kBandBufFloats = 16896;   // 66 KB per buffer, two buffers per wor
 constexpr int kBandHalo = 8;            // rows below a band that its items may still tap
 constexpr int kBandMaxBands = 16;
 constexpr int kBandNP = 4;              // passes a wave keeps in registers (one round)
-constexpr int kBandMaxVisits = 3;       // virtual units one workgroup works on, at most
-constexpr int kBandMaxUnits = 256;      // (level, image, band) units of one launch
+constexpr int kBandMaxUnits = 512;      // virtual units ((level, image, band) x rounds of items) of one launch
 constexpr int kBandFillCost = 140, kBandPlaneCost = 60, kBandSetupCost = 1500;  // cost model, in item times
 constexpr int kBandSub = 4;             // list segments per unit (pre-pass workgroups per (level, image))
 constexpr int kBandFallbackWGs = 0;    // (no separate exact-path blocks: the band workgroups do that work last)
@@ -1117,7 +1116,10 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     return k;  // (valid in thread 0 only)
   };
 
-  for (int visit = 0; visit < kBandMaxVisits && nvu > 0; ++visit) {
+  // A workgroup keeps visiting virtual units until every unit's channel counter has been taken past
+  // C: a unit somebody has grabbed from is finished by its visitors (they loop until the counter runs
+  // dry), so the launch is complete exactly when no unit is left with an untouched counter.
+  for (int visit = 0; nvu > 0; ++visit) {
   if (visit) {
     // the unit ran dry: move to the virtual unit with the most estimated work left (if any);
     // one wave looks (fresh counter values), one barrier
@@ -1128,8 +1130,12 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
         int left = 0;
         if (v < nvu) {
           const int done = __hip_atomic_load(&P.chan_ctr[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // (joining costs a set-up: only worth it for a few fills)
-          left = a.C - done >= 3 * P.g[level_of(v_unit[v])] ? (a.C - done) * v_cost[v] : 0;
+          // (joining costs a set-up: only worth it for a few fills -- but a unit nobody has started
+          // yet must be taken by somebody, however small it is)
+          if (done < a.C && (done == 0 || a.C - done >= 3 * P.g[level_of(v_unit[v])])) {
+            left = (a.C - done) * v_cost[v];
+            left = left < 1 ? 1 : left;
+          }
         }
         int m = left;
 #pragma unroll
@@ -2942,7 +2948,14 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     P.tail_planes = tuning("roi_align_fwd_tail_planes", 8);
     if (P.tail_planes < 1) P.tail_planes = 1;
     if (P.grab < 1) P.grab = 1;
-    if (units > kBandMaxUnits) ok = false;
+    {
+      // virtual units = sum over units of ceil(items / CAP) <= units + floor(all items / CAP), and a RoI
+      // has at most POOL items: beyond the table's size the launch goes to the tiled kernels (the
+      // kernel's table holds kBandMaxUnits entries and drops nothing below that)
+      const int np = (a.amax8 && !a.half_io) ? kBandNP : kBandNP - 1;
+      const long cap_launch = (long)np * kBandWaves * (kWave / POOL);
+      if (units + (long)nroi * POOL / cap_launch > kBandMaxUnits) ok = false;
+    }
     wg = tuning("roi_align_fwd_wgs", kNumCU);  // persistent workgroups, one per CU
     if (wg < 1) wg = 1;
     if (ok && need <= workspace_bytes) {

@@ -23,7 +23,7 @@ CustomOp's outputs as written when the callback returns (threading)
 import ctypes
 from ast import literal_eval
 
-from ._lib import lib
+from ._lib import SD_ERR_UNSUPPORTED, SimpleDetOpsError, lib
 
 REQ = {"null": 0, "write": 1, "inplace": 2, "add": 3}
 _PREFIX = "sd_"
@@ -730,11 +730,31 @@ def _build_ops(mx):
             wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, rois.shape[1])
             ws = _scratch(rois, wsb)
             fn = "sd_fpn_roi_align_fwd_packed" if self.packed else "sd_fpn_roi_align_fwd"
-            lib().call(fn + "_f16" if self.fp16 else fn, ptrs,
-                       Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois), _ptr(out_data[0]),
-                       _ptr(out_data[1]), _ptr(out_data[2]), B, C, rois.shape[1], self.pooled[0],
-                       self.pooled[1], float(self.scale0), float(self.lvl0), _ptr(ws),
-                       ctypes.c_size_t(wsb), None)
+
+            def run(name, level_ptrs, out0):
+                lib().call(name, level_ptrs, Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois),
+                           _ptr(out0), _ptr(out_data[1]), _ptr(out_data[2]), B, C, rois.shape[1],
+                           self.pooled[0], self.pooled[1], float(self.scale0), float(self.lvl0),
+                           _ptr(ws), ctypes.c_size_t(wsb), None)
+
+            if not self.fp16:
+                run(fn, ptrs, out_data[0])
+            else:
+                try:
+                    run(fn + "_f16", ptrs, out_data[0])
+                except SimpleDetOpsError as e:
+                    if e.code != SD_ERR_UNSUPPORTED:
+                        raise
+                    # a shape the band-resident kernel does not take: the casts the reference graph
+                    # carries itself (models/FPN/builder.py:581-586, 607-608) around the fp32 op
+                    f32 = [_scratch(rois, f.size * 4).reshape(f.shape) for f in feats]
+                    for f, g in zip(feats, f32):
+                        lib().call("sd_cast_f16_to_f32", _ptr(f), _ptr(g), ctypes.c_size_t(f.size), None)
+                    o32 = _scratch(rois, out_data[0].size * 4).reshape(out_data[0].shape)
+                    p32 = (ctypes.c_void_p * len(f32))(*[_ptr(g).value for g in f32])
+                    run(fn, p32, o32)
+                    lib().call("sd_cast_f32_to_f16", _ptr(o32), _ptr(out_data[0]),
+                               ctypes.c_size_t(o32.size), REQ["write"], None)
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):

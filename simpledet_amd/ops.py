@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from ._lib import lib
+from ._lib import SD_ERR_UNSUPPORTED, SimpleDetOpsError, lib
 
 REQ = {"null": 0, "write": 1, "add": 3}
 
@@ -223,10 +223,20 @@ def fpn_roi_align_forward_packed_f16(feats, rois, rcnn_stride, pooled_size, roi_
     coords = torch.empty((B, R, 9 * (ph + pw)), device=rois.device, dtype=torch.float32)
     wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, R)
     ws = torch.empty(wsb, device=rois.device, dtype=torch.uint8)
-    lib().call("sd_fpn_roi_align_fwd_packed_f16", _parr(feats), _iarr([f.shape[2] for f in feats]),
-               _iarr([f.shape[3] for f in feats]), _iarr(rcnn_stride), len(feats), _p(rois),
-               _p(out), _p(amax), _p(coords), B, C, R, ph, pw, float(roi_canonical_scale),
-               float(roi_canonical_level), _p(ws), ctypes.c_size_t(wsb), _stream())
+    try:
+        lib().call("sd_fpn_roi_align_fwd_packed_f16", _parr(feats), _iarr([f.shape[2] for f in feats]),
+                   _iarr([f.shape[3] for f in feats]), _iarr(rcnn_stride), len(feats), _p(rois),
+                   _p(out), _p(amax), _p(coords), B, C, R, ph, pw, float(roi_canonical_scale),
+                   float(roi_canonical_level), _p(ws), ctypes.c_size_t(wsb), _stream())
+    except SimpleDetOpsError as e:
+        if e.code != SD_ERR_UNSUPPORTED:
+            raise
+        # shapes the band-resident kernel does not take (too many units, W < 2, ...): the graph's own
+        # cast -> fp32 op -> cast (models/FPN/builder.py:581-586, 607-608), same bits
+        f32 = [cast_f16_to_f32(f) for f in feats]
+        o32, (amax, coords) = fpn_roi_align_forward_packed(f32, rois, rcnn_stride, pooled_size,
+                                                           roi_canonical_scale, roi_canonical_level)
+        cast_f32_to_f16(o32, out)
     return out, (amax, coords)
 
 

@@ -301,6 +301,50 @@ def test_fpn_full_size_baseline_config(ops, oracle):
         lib().set_tuning("roi_align_bwd", 2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["b8_r2000", "one_band", "few_channels"])
+def test_fpn_band_forward_many_virtual_units(ops, oracle, case):
+    """the band-resident forward cuts a unit's items into rounds ("virtual
+    units"); with many images / RoIs, or every RoI in one band, there are far more virtual units
+    than workgroups-at-start, and every one of them must still be written (float and packed)."""
+    if case == "b8_r2000":       # ~90 units + ~190-260 extra rounds
+        feats = synth.feature_maps(21, batch=8, channels=8)
+        rois = synth.random_rois(22, 8, 2000)
+    elif case == "one_band":     # 1500 small boxes inside the first rows of P2: one unit, many rounds
+        feats = synth.feature_maps(23, batch=2, channels=16)
+        rs = np.random.RandomState(24)
+        rois = np.empty((2, 1500, 4), np.float32)
+        for b in range(2):
+            cx = rs.uniform(20, 1300, 1500)
+            cy = rs.uniform(10, 110, 1500)
+            w = rs.uniform(8, 60, 1500)
+            h = rs.uniform(8, 40, 1500)
+            rois[b] = np.stack([cx - w / 2, np.maximum(cy - h / 2, 0), cx + w / 2, cy + h / 2], 1)
+    else:                        # C < 3 * planes-per-fill: units nobody starts on must still be taken
+        feats = synth.feature_maps(25, batch=4, channels=8)
+        rois = synth.level_balanced_rois(26, 4, 300)
+    want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (7, 7), nthreads=8)
+    tf = [_t(f) for f in feats]
+    got = ops.fpn_roi_align_forward(tf, _t(rois), STRIDES, (7, 7))
+    for g, w, name in zip(got, want, ("output", "maxidx_x", "maxidx_y")):
+        np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=name)
+    outp, amp = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, (7, 7))
+    np.testing.assert_array_equal(outp.cpu().numpy(), want[0])
+    # the packed arg-max names the same winners: the naive (per-element) kernel is the in-device
+    # reference for the codes, the oracle for which bins pooled nothing
+    import torch
+    from simpledet_amd._lib import lib
+    amn = ops.argmax_codes(amp[0], (7, 7))
+    np.testing.assert_array_equal(amn.cpu().numpy() == 255, want[1] == -1)
+    lib().set_tuning("roi_align_fwd", 0)
+    try:
+        out0, am0 = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, (7, 7))
+    finally:
+        lib().set_tuning("roi_align_fwd", 1)
+    assert torch.equal(out0, outp) and torch.equal(ops.argmax_codes(am0[0], (7, 7)), amn)
+    assert torch.equal(am0[1], amp[1])
+
+
 # ------------------------------------------------------------------- packed (one-byte) arg-max --
 def _decode_packed(am, rois, feats_shapes, strides, level):
     """numpy float32 restatement of the device decode (sample_coord): (ax, ay) from (k, l)."""
@@ -600,6 +644,17 @@ def test_fpn_packed_forward_fp16_io(ops, oracle, pooled, num, channels):
     lvl = ops.fpn_roi_assign(_t(rois), STRIDES)[1].reshape(-1) >= 0
     assert torch.equal(coords.reshape(lvl.numel(), -1)[lvl], c32.reshape(lvl.numel(), -1)[lvl])
     assert torch.equal(out, o32.half())
+    # where the band-resident kernel is not eligible the fp16 op still works
+    # (cast -> fp32 op -> cast instead of SD_ERR_UNSUPPORTED), with the same bits
+    from simpledet_amd._lib import lib
+    lib().set_tuning("roi_align_fwd_band", 0)
+    try:
+        out_fb, (am_fb, _) = ops.fpn_roi_align_forward_packed_f16([_t(f) for f in feats16], _t(rois),
+                                                                  STRIDES, pooled)
+    finally:
+        lib().set_tuning("roi_align_fwd_band", 1)
+    assert torch.equal(out_fb, out)
+    assert torch.equal(ops.argmax_codes(am_fb, pooled), ops.argmax_codes(am, pooled))
 
 
 @pytest.mark.gpu
