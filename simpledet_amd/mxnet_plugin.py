@@ -1057,7 +1057,70 @@ def install(mx=None):
     # the fused FPN extractor has no single reference symbol to alias: rebind the builder method
     # that emits the subgraph (no reference file is edited)
     _state["fpn_patched"] = patch_fpn_roi_align(mx=mx)
+    # ... and the mxnext wrappers the reference's builders go through, explicitly (not relying on
+    # mxnext looking `mx.sym.*` up at call time)
+    _state["mxnext_patched"] = patch_mxnext(mx=mx)
     return props
+
+
+def patch_mxnext(mxnext=None, mx=None):
+    """Point the mxnext wrappers on the hot path at the aliased symbol constructors, by name, so that
+    the routing does not depend on how mxnext binds `mx.sym.*` internally.  mxnext
+    (github.com/RogerChern/mxnext) is not part of the reference tree; the signatures are the ones the
+    reference's call sites use:
+        X.roi_align(feat, rois=, out_size=, stride=, name=)      symbol/builder.py:885, models/FPN/builder.py:592
+        X.proposal_target(rois=, gt_boxes=, ..., name=)           symbol/builder.py:304, models/FPN/builder.py:347
+        X.proposal(cls_prob=, bbox_pred=, im_info=, ..., iou_loss=, output_score=)   symbol/builder.py:241
+        X.decode_bbox(rois=, bbox_pred=, im_info=, ..., name=)    symbol/builder.py:384
+        mxnext.tvm.get_top_proposal.get_top_proposal(F, bbox=, score=, top_n=, batch_size=)
+                                                                  models/FPN/builder.py:319-321
+    (mxnext.tvm.proposal -- the "nnvm" proposal some configs select for the fine levels -- is left
+    alone: it is un-vendored and nothing in the reference tree pins its results.)
+    Returns the list of patched names ([] when mxnext is not importable)."""
+    mx = mx or _state["mx"]
+    if mxnext is None:
+        try:
+            import importlib
+            mxnext = importlib.import_module("mxnext")
+        except Exception:
+            return []
+    done = []
+
+    def roi_align(feat, rois, out_size, stride, name=None, **kw):
+        return mx.sym.contrib.ROIAlign_v2(data=feat, rois=rois, pooled_size=(int(out_size), int(out_size)),
+                                          spatial_scale=1.0 / stride, name=name, **kw)
+
+    def proposal_target(**kw):
+        return mx.sym.ProposalTarget(**kw)
+
+    def proposal(**kw):
+        return mx.sym.contrib.Proposal_v3(**kw)
+
+    def decode_bbox(**kw):
+        return mx.sym.contrib.DecodeBBox(**kw)
+
+    for attr, fn in (("roi_align", roi_align), ("proposal_target", proposal_target),
+                     ("proposal", proposal), ("decode_bbox", decode_bbox)):
+        try:
+            setattr(mxnext, "_sd_reference_" + attr, getattr(mxnext, attr, None))
+            setattr(mxnext, attr, fn)
+            done.append("mxnext." + attr)
+        except Exception:
+            pass
+    try:
+        import importlib
+        m = importlib.import_module("mxnext.tvm.get_top_proposal")
+
+        def get_top_proposal(F, bbox, score, top_n, batch_size=None, name="get_top_proposal", **kw):
+            sym = mx.sym.Custom(bbox=bbox, score=score, op_type=_PREFIX + "get_top_proposal",
+                                top_n=_param_str(top_n), name=name)
+            return mx.sym.Group([sym[0], sym[1]])
+        m._sd_reference_get_top_proposal = m.get_top_proposal
+        m.get_top_proposal = get_top_proposal
+        done.append("mxnext.tvm.get_top_proposal.get_top_proposal")
+    except Exception:
+        pass
+    return done
 
 
 def patch_fpn_roi_align(builder_module=None, mx=None):
