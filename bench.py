@@ -11,12 +11,16 @@ N > 1 without a torchrun environment re-launches itself as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
 (one rank per GPU, RCCL); started by torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
 
-Prints ONE JSON line on rank 0.  `value` = images/s over all ranks (weak scaling: every rank
-processes its own images; the path has no data-path collective -- RoIs/images are independent,
-SURVEY 8(e)).  For N > 1 every step also all-reduces an fp32 gradient buffer over RCCL (default
-165 MB = the R50-FPN gradients of the reference's only inter-GPU exchange, detection_train.py:
-42-43,266), started when the step's kernels have been enqueued and joined at the end of the step,
-i.e. overlapped with the RoIAlign work the way a data-parallel backward overlaps it.
+Prints ONE JSON line on rank 0.  `value` = images/s over all ranks of THE PATH ITSELF (weak scaling:
+every rank processes its own images; the path has no data-path collective and no parameters -- RoIs /
+images are independent): the timed loop of K steps contains the hot path only, on every
+rank, bracketed by barrier + synchronize, max over ranks.  The reference's one inter-GPU exchange --
+the KVStore `nccl` all-reduce of the model's gradients (detection_train.py:42-43,266; 165 MB of
+fp32 for R50-FPN) -- is NOT part of this path; for N > 1 it is measured in the same invocation as
+separate legs and reported under `grad_allreduce` (alone: bus bandwidth; composite: every step
+starts it behind the forward and joins it at the end of the step, the way a data-parallel backward
+overlaps it -- a 0.2 ms step cannot hide a 165 MB all-reduce, a real step hides it under ~100 ms of
+backbone backward).
 
 roofline: ALGORITHMIC bytes of one forward launch (N*S_F + 16*N*R + 3*N*S_O
 = 335.9 MB at N=2) / the forward kernel's average duration measured with HIP events on the launch
@@ -92,14 +96,9 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def scaling_legs(ops_only_step, reducer, barrier, max_over_ranks, args, world, rank, grad_mb, device):
-    """What the N > 1 line is made of, measured in the same invocation (K steps each):
-      (a) rank 0 alone, the others idle            -> the N = 1 figure of this box
-      (b) every rank, ops only (no collective)     -> weak scaling of the hot path itself
-      (c) the gradient all-reduce alone            -> its bus bandwidth over xGMI
-    The timed loop of the line (`value`) is (d) = ops + the all-reduce started behind the forward.
-    A 0.2 ms step cannot hide a 165 MB all-reduce (a real training step hides it under ~100 ms of
-    backbone backward): (d) - (b), reported as allreduce_ms_exposed, is what stays exposed here."""
+def leg_single_rank(step, barrier, args, rank, device):
+    """rank 0 alone, the other ranks idle: the N = 1 figure of this box in this invocation (seconds
+    for K steps, the same on every rank)"""
     import torch
     import torch.distributed as dist
     sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
@@ -107,44 +106,45 @@ def scaling_legs(ops_only_step, reducer, barrier, max_over_ranks, args, world, r
     t0 = time.perf_counter()
     if rank == 0:
         for _ in range(args.steps):
-            ops_only_step()
+            step()
         sync()
     ts = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
     dist.broadcast(ts, 0)
-    t_single = float(ts.item())
+    return float(ts.item())
+
+
+def legs_grad_allreduce(step, reducer, barrier, max_over_ranks, args, world, grad_mb, t_single, t_ops):
+    """The reference's data-parallel exchange next to the path, K steps each, every rank:
+      alone      the gradient all-reduce by itself          -> its bus bandwidth over xGMI
+      composite  hot path + the all-reduce started behind the forward, joined at the end of the step
+    t_single / t_ops: seconds of K steps of rank 0 alone / of the timed loop (`value`)."""
+    for _ in range(2):
+        reducer.start()
+        reducer.finish()
+    nar = max(3, min(args.steps, 10))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(nar):
+        reducer.start()
+        reducer.finish()
+    barrier()
+    t_ar, _ = max_over_ranks(time.perf_counter() - t0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ops_only_step()
+        step(reducer=reducer)
     barrier()
-    t_ops, _ = max_over_ranks(time.perf_counter() - t0)
-    out = {"n1_ms_per_step_same_invocation": t_single * 1e3 / args.steps,
-           "ops_only_ms_per_step": t_ops * 1e3 / args.steps,
-           "value_ops_only": args.images * world * args.steps / t_ops,
-           "weak_scaling_eff_ops_only": t_single / t_ops}
-    if reducer is not None:
-        for _ in range(2):
-            reducer.start()
-            reducer.finish()
-        nar = max(3, min(args.steps, 10))
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(nar):
-            reducer.start()
-            reducer.finish()
-        barrier()
-        t_ar, _ = max_over_ranks(time.perf_counter() - t0)
-        out["allreduce_alone_ms"] = t_ar * 1e3 / nar
-        out["allreduce_busbw_GBs"] = (2.0 * (world - 1) / world) * grad_mb * 1e6 / (t_ar / nar) / 1e9
-    return out
-
-
-def finish_scaling(scaling, elapsed, steps):
-    """the keys that need the timed loop (d) of the line"""
-    ms = elapsed * 1e3 / steps
-    scaling["allreduce_ms_exposed"] = max(0.0, ms - scaling["ops_only_ms_per_step"])
-    scaling["weak_scaling_eff_with_allreduce"] = scaling["n1_ms_per_step_same_invocation"] / ms
-    return scaling
+    t_both, _ = max_over_ranks(time.perf_counter() - t0)
+    ms_ops, ms_both = t_ops * 1e3 / args.steps, t_both * 1e3 / args.steps
+    return {"mb_per_step": grad_mb,
+            "alone_ms": t_ar * 1e3 / nar,
+            "busbw_GBs": (2.0 * (world - 1) / world) * grad_mb * 1e6 / (t_ar / nar) / 1e9,
+            "ops_plus_allreduce_ms_per_step": ms_both,
+            "value_ops_plus_allreduce": args.images * world * args.steps / t_both,
+            "exposed_ms": max(0.0, ms_both - ms_ops),
+            "weak_scaling_eff_with_allreduce": t_single / t_both,
+            "what": "NOT in `value`: the reference's KVStore all-reduce of the model gradients, started behind "
+                    "the forward and joined at the end of the step; a 0.2 ms step cannot hide it"}
 
 
 def main():
@@ -202,7 +202,7 @@ def main():
 
     state = {}
 
-    def step(ev=None):
+    def step(ev=None, reducer=None):
         if ev:
             ev[0].record()
         if args.float_argmax:
@@ -250,18 +250,7 @@ def main():
         vals = [float(v.item()) for v in allt]
         return max(vals), vals
 
-    scaling = {}
-    if world > 1:
-        def ops_only_step():
-            nonlocal reducer
-            saved, reducer = reducer, None
-            try:
-                step()
-            finally:
-                reducer = saved
-        scaling = scaling_legs(ops_only_step, reducer, barrier, max_over_ranks, args, world, rank, grad_mb,
-                               torch.device("cuda"))
-
+    # ---- THE timed region: exactly K steps of the path on every rank, nothing else in it ----
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -271,8 +260,16 @@ def main():
     elapsed_local = time.perf_counter() - t0
     elapsed, vals = max_over_ranks(elapsed_local)
     per_rank_ms = [v * 1e3 / args.steps for v in vals]
+    scaling = {}
     if world > 1:
-        finish_scaling(scaling, elapsed, args.steps)
+        # afterwards, outside the timed region: rank 0 alone (the N = 1 figure of this box in this
+        # invocation), then the reference's gradient all-reduce beside the path
+        t_single = leg_single_rank(step, barrier, args, rank, torch.device("cuda"))
+        scaling = {"n1_ms_per_step_same_invocation": t_single * 1e3 / args.steps,
+                   "weak_scaling_eff_same_invocation": t_single / elapsed}
+        if reducer is not None:
+            scaling["grad_allreduce"] = legs_grad_allreduce(step, reducer, barrier, max_over_ranks, args, world,
+                                                            grad_mb, t_single, elapsed)
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
@@ -511,7 +508,8 @@ def main():
             "rois_per_image": args.rois,
             "argmax_state": "fp32 x,y planes" if args.float_argmax else "packed u8 (decoded in backward)",
             "sharding": "images across ranks, no data-path collective",
-            "grad_allreduce_mb_per_step": grad_mb if reducer is not None else 0.0,
+            "collectives_in_value": "none (the path has no exchange step; see grad_allreduce for the "
+                                    "reference's gradient all-reduce measured beside it)",
         },
         "rccl_ranks": rccl_ranks,
         "per_rank_ms_per_step": per_rank_ms,
@@ -557,27 +555,32 @@ def launcher_selftest(args, rank, world):
         vals = [float(v.item()) for v in allt]
         return max(vals), vals
 
-    scaling = {}
-    if world > 1:
-        scaling = scaling_legs(ops_only_step, reducer, barrier, max_over_ranks, args, world, rank, grad_mb,
-                               torch.device("cpu"))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    def step(reducer=None):
         ops_only_step()
         if reducer is not None:
             reducer.buf.fill_(float(rank + 1))
             reducer.start()
             reducer.finish()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
     barrier()
     elapsed, vals = max_over_ranks(time.perf_counter() - t0)
+    scaling = {}
     if world > 1:
-        finish_scaling(scaling, elapsed, args.steps)
+        t_single = leg_single_rank(step, barrier, args, rank, torch.device("cpu"))
+        scaling = {"n1_ms_per_step_same_invocation": t_single * 1e3 / args.steps,
+                   "weak_scaling_eff_same_invocation": t_single / elapsed}
+        if reducer is not None:
+            scaling["grad_allreduce"] = legs_grad_allreduce(step, reducer, barrier, max_over_ranks, args, world,
+                                                            grad_mb, t_single, elapsed)
     ok = reducer is None or bool(torch.allclose(reducer.buf, torch.full_like(reducer.buf, (world + 1) / 2.0)))
     if rank == 0:
         line = {"metric": "launcher self-test (no GPU kernels)", "value": None, "n_gpus": world,
                 "steps": args.steps, "rccl_ranks": int(one.item()), "backend": "gloo",
-                "grad_allreduce_mb_per_step": grad_mb if reducer is not None else 0.0,
+                "ms_per_step": elapsed * 1e3 / max(1, args.steps),
                 "allreduce_correct": ok,
                 "per_rank_ms_per_step": [v * 1e3 / max(1, args.steps) for v in vals]}
         line.update(scaling)

@@ -143,12 +143,15 @@ def test_bench_self_launch_two_ranks_gloo():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["allreduce_correct"] is True
-    # the N > 1 line says what it is made of: the N = 1 figure of the same invocation, the ops-only
-    # loop, the all-reduce alone and what of it stays exposed in the timed loop
-    for k in ("n1_ms_per_step_same_invocation", "ops_only_ms_per_step", "value_ops_only",
-              "weak_scaling_eff_ops_only", "weak_scaling_eff_with_allreduce", "allreduce_alone_ms",
-              "allreduce_busbw_GBs", "allreduce_ms_exposed"):
-        assert k in d and d[k] is not None and d[k] >= 0, k
-    # (ratios of sub-millisecond CPU timings under gloo: only their sign and finiteness mean anything here)
-    assert 0 < d["weak_scaling_eff_ops_only"] < 1e4 and 0 < d["weak_scaling_eff_with_allreduce"] < 1e4
-    assert d["grad_allreduce_mb_per_step"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    # `value`'s timed loop is the path alone (it has no collective); the line carries the N = 1 figure of
+    # the same invocation, and the reference's gradient all-reduce as separate legs under their own key
+    assert d["ms_per_step"] > 0 and d["n1_ms_per_step_same_invocation"] > 0
+    assert 0 < d["weak_scaling_eff_same_invocation"] < 1e4   # (sub-millisecond CPU timings under gloo)
+    ga = d["grad_allreduce"]
+    for k in ("alone_ms", "busbw_GBs", "ops_plus_allreduce_ms_per_step", "exposed_ms",
+              "weak_scaling_eff_with_allreduce"):
+        assert k in ga and ga[k] is not None and ga[k] >= 0, k
+    assert ga["mb_per_step"] == 2 and "NOT in `value`" in ga["what"]
+    # the composite leg contains the path's steps plus the collective: it cannot be faster than ~the path
+    assert ga["ops_plus_allreduce_ms_per_step"] >= 0.2 * d["ms_per_step"]
+    assert len(d["per_rank_ms_per_step"]) == 2

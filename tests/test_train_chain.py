@@ -58,7 +58,10 @@ def gpu_chain(ops, t_rpn, t_gt, t_polys, t_feats, t_dy, t_dy14, rng, rng_mask):
 
 @pytest.mark.gpu
 def test_train_chain_composes_and_needs_no_host_sync(ops, oracle):
+    import os
     import torch
+    if os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") == "1":
+        pytest.skip("stream capture forbids hipMalloc: the harness's allocations need the caching allocator")
     C = 32
     rpn, gt, polys, feats = _inputs(11, C)
     t_rpn = [(_t(c), _t(b), _t(i)) for c, b, i in rpn]
