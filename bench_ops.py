@@ -243,11 +243,11 @@ def run(seed=0, cpu=True, only=None):
             res["soft_nms"]["cpu_problems_per_s_1core"] = 1e3 / t
             od, oi, oc = [N_(x) for x in ops.soft_nms_batched(tsd, None, 0.5, 0.5, 0.001, 1)]
             okk = True
-            for q in (0, 1, P // 2, P - 1):
+            for q in range(P):   # every problem (the C oracle needs ~1 ms each)
                 wb, wi = orc.soft_nms(sd[q], 0.5, 0.5, 0.001, 1)
                 okk = okk and oc[q] == len(wi) and np.array_equal(od[q, :oc[q]], wb) and np.array_equal(oi[q, :oc[q]], wi)
             res["soft_nms"]["matches_oracle"] = bool(okk)
-            res["soft_nms"]["matches_oracle_scope"] = "4 of the 1280 problems"
+            res["soft_nms"]["matches_oracle_scope"] = "all %d problems" % P
             try:  # the reference's own Cython soft_nms (oracle/_ref, built from /root/reference)
                 from oracle._ref import cpu_nms as _ref_nms
                 t0 = time.perf_counter()
@@ -372,15 +372,19 @@ def run(seed=0, cpu=True, only=None):
             "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
             "col2im_ms": ms_c2i, "col2im_coord_ms": ms_crd,
             "fwd_ms": ms_f, "bwd_ms": ms_b, "bwd_with_forward_col_ms": ms_bc, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
-            # fp32 products as three bf16 MFMA terms (hi/lo split): 3 x the flops on the bf16 pipe
-            "gemm_arith": "fp32 in/out, 3 bf16 MFMA terms per product (deform_gemm_split=1)",
+            # fp32 products as three fp16 MFMA terms (scaled hi/lo split): 3 x the flops on the f16 pipe
+            "gemm_arith": "fp32 in/out, 3 f16 MFMA terms per product of a scaled hi/lo split (deform_gemm_split=2)",
             "gemm_frac_of_bf16_mfma_peak": 3.0 * flops / gemm_ms / 1e9 / PEAK_BF16_MFMA_TFLOPS,
             "gemm_vs_f32_mfma_peak": flops / gemm_ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
             "config": "x (16,256,50,84), 3x3 pad 1, 4 deformable groups, 256 filters, fp32"}
         if orc:
-            wy = orc.deform_conv_fwd(N_(x[:1]), N_(off[:1]), N_(wt), 1, 1, 1, 4)
-            err = float(np.abs(N_(y[:1]) - wy).max())
-            res["deform_conv"]["fwd_max_abs_err_image0"] = err
-            res["deform_conv"]["matches_oracle"] = bool(err <= 1e-4 * max(1.0, float(np.abs(wy).max())))
-            res["deform_conv"]["matches_oracle_scope"] = "forward of image 0, 1e-4 x max|y| (GEMM summation order)"
+            # every image of the batch against the oracle, north_star's ABSOLUTE bar: 1e-4 wherever the
+            # values stay within |y| <= 32, scaled with the magnitude above that (tests/test_deform_conv.py)
+            wy = orc.deform_conv_fwd(N_(x), N_(off), N_(wt), 1, 1, 1, 4)
+            errs = np.abs(N_(y) - wy).reshape(N, -1).max(1)
+            bar = 1e-4 * max(1.0, float(np.abs(wy).max()) / 32.0)
+            res["deform_conv"]["fwd_max_abs_err"] = float(errs.max())
+            res["deform_conv"]["fwd_abs_bar"] = bar
+            res["deform_conv"]["matches_oracle"] = bool(float(errs.max()) <= bar)
+            res["deform_conv"]["matches_oracle_scope"] = "forward of all %d images, absolute bar" % N
     return res

@@ -50,9 +50,11 @@ const char* sd_last_error(void);
  * and 4-byte aligned; 3 sd_fpn_roi_align_workspace_bytes grew (the forward's band lists / tap
  * entries live in the workspace; with a smaller or NULL workspace the forward still runs, on the
  * slower tiled kernels); 4 sd_gemm_f32 computes products as three bf16 MFMA terms by default
- * (same signature, documented error model), sd_proposal_mask_target_ratio / sd_cast_* / *_f16 added.
+ * (same signature, documented error model), sd_proposal_mask_target_ratio / sd_cast_* / *_f16 added;
+ * 5 sd_gemm_f32_ws, the DCN products default to the scaled fp16 split (fp32-path accuracy), plain
+ * sd_gemm_f32 to exact fp32.
  * sd_abi_version() returns the library's value; compare with this macro. */
-#define SD_ABI_VERSION 4
+#define SD_ABI_VERSION 5
 int sd_abi_version(void);
 /* kernel-variant knobs for A/B measurements (bench.py, tests); every variant computes the same
  * result.  Unknown keys are an error.  Knobs that disable parts of a kernel for profiling exist
@@ -406,17 +408,30 @@ int sd_deform_col2im_coord(const float* col, const float* x, const float* offset
  * strideC = 0).  Replaces the linalg_gemm calls of deformable_convolution-inl.h (cuBLAS sgemm in
  * the reference).
  * Arithmetic (tuning key `deform_gemm_split`):
- *   1 (default)  every operand is split into two bf16 parts (hi = RNE(x), lo = RNE(x - hi)) and a
- *      product is a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate:
- *      relative error <= 2^-16 per product; measured 4.5e-6 x max|C| on the DCN products (K = 2304)
- *      against fp64, a twentieth of the 1e-4 parity bar.  Non-finite inputs give NaN.  When the
- *      last round of resident workgroups would be under half full its tiles are cut into k slices
- *      that add atomically (those tiles' last bits then depend on the order; key
- *      `deform_gemm_ksplit` = 0 turns that off).
- *   0  v_mfma_f32_32x32x2_f32: exact fp32 products, 5e-7 x max|C|, ~2.5x slower. */
+ *   2 (default)  scaled fp16 split: a pre-pass takes max|A| and max|B|, each operand is scaled by the
+ *      power of two that brings its maximum into [2^13, 2^14) and split into two fp16 parts
+ *      (hi = RNE(x s), lo = RNE(x s - hi): 22 mantissa bits), a product is a_hi*b_hi + a_hi*b_lo +
+ *      a_lo*b_hi on v_mfma_f32_32x32x16_f16 (hi*hi exact in the fp32 accumulator), the result is scaled
+ *      back exactly.  Error against fp64 = that of the fp32 MFMA path (measured 5e-7 x max|C| at K =
+ *      2304; tests hold it to <= 2x the exact path's).  Elements below 2^-17 of their operand's maximum
+ *      lose relative (not absolute) precision; non-finite inputs give NaN.  Needs the maxima, i.e. a
+ *      workspace: sd_gemm_f32_ws and the sd_deform_conv_* entry points; plain sd_gemm_f32 runs the exact
+ *      path (0) instead.
+ *   1  bf16 split, no pre-pass: hi = RNE(x), lo = RNE(x - hi) in bf16, 16 mantissa bits: 4.5e-6 x
+ *      max|C| (nine times the exact path's error); opt-in.
+ *   0  v_mfma_f32_32x32x2_f32: exact fp32 products, 5e-7 x max|C|, ~2.5x slower.
+ *   Split paths: when the last round of resident workgroups would be under half full its tiles are cut
+ *   into k slices that add atomically (those tiles' last bits then depend on the order; key
+ *   `deform_gemm_ksplit` = 0 turns that off). */
 int sd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, long strideA,
                 const float* B, int ldb, long strideB, float* C, int ldc, long strideC, int batch,
                 int accumulate, void* stream);
+/* the same with a workspace of sd_gemm_f32_workspace_bytes() bytes for the operand maxima (two extra
+ * small launches that read A and B once) */
+size_t sd_gemm_f32_workspace_bytes(void);
+int sd_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, long strideA,
+                   const float* B, int ldb, long strideB, float* C, int ldc, long strideC, int batch,
+                   int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t sd_deform_conv_workspace_bytes(int N, int C, int H, int W, int kh, int kw, int pad,
                                       int stride, int dil);
 /* forward = im2col + GEMM, num_group = 1, no bias (the reference's configuration) */

@@ -696,6 +696,7 @@ struct GemmArgs {
   long dbg_cap;
   int whole, whole_blocks, ksplit;  // split kernel: tiles run whole, their blocks (padded), k slices of the rest
   int ablate;  // profiling build only: bit 0 skip the A prefetch, bit 1 skip the B prefetch
+  const unsigned* amax;  // f16 split: bit patterns of max|A|, max|B| (upper bounds), device memory
 };
 
 constexpr int BM = 128;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
@@ -867,16 +868,54 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 constexpr int SBM = 128, SBN = 128, SBK = 64;
 constexpr int kSplitPlane = 128 * 128;  // bytes per LDS plane
 
-// hi / lo bf16 parts of two floats, packed (element 0 in the low half).  PK = false keeps the two
+// ---- split arithmetic ------------------------------------------------------------------------------
+// kSplitBF16: hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits kept, any fp32 magnitude.  Error of a
+//   K = 2304 product sum ~4.5e-6 x max|C| (nine times the fp32 MFMA path's).
+// kSplitF16 (default for the DCN layer): the operand is first scaled by a power of two s so that
+//   max|x| * s lies in [2^13, 2^14) (s from a max|x| pre-pass over the operand -- or an upper bound of
+//   it), then hi = f16(x * s), lo = f16(x * s - hi): 22 mantissa bits kept wherever |x| >= 2^-17 max|x|,
+//   an absolute error below 2^-38 max|x| elsewhere (fp16 subnormals).  hi*hi products are exact in
+//   the fp32 accumulator; the dropped lo*lo term is <= 2^-22 of a product.  The accumulator is scaled
+//   back by 1/s_a and 1/s_b (exact) on the way out.  Measured: the error of the DCN products against
+//   fp64 is that of the fp32 MFMA path (tests/test_deform_conv.py).
+constexpr int kSplitBF16 = 1, kSplitF16 = 2;
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+
+// power-of-two scale of an operand from the bit pattern of (an upper bound of) its max|x|, and its
+// inverse; zero, inf and nan maxima scale by 1
+__device__ __forceinline__ void f16_split_scale(unsigned max_bits, float& s, float& inv) {
+  const int e = (int)((max_bits >> 23) & 255);
+  int es = 267 - e;  // biased exponent of s = 2^(13 - (e - 127))
+  if ((max_bits & 0x7fffffffu) == 0u || e == 255) es = 127;
+  es = es > 254 ? 254 : es;
+  s = __uint_as_float((unsigned)es << 23);
+  inv = 1.0f / s;  // exact: a power of two within the normal / subnormal range
+}
+
+// hi / lo parts of two floats, packed (element 0 in the low half).  PK = false keeps the two
 // subtractions scalar: a packed v_pk_add_f32 wants its operands in adjacent registers, and for
 // values that come out of two different loads the compiler then shuffles registers right behind
 // the loads -- i.e. waits for the prefetch it was supposed to leave in flight.
-template <bool PK>
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const floatx2 v = {x0, x1};
-  const bf16x2 h = __builtin_convertvector(v, bf16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  const float f0 = __builtin_bit_cast(float, hi << 16), f1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+template <bool PK, int MODE>
+__device__ __forceinline__ void split2(float x0, float x1, float scale, unsigned& hi, unsigned& lo) {
+  float f0, f1;
+  if (MODE == kSplitF16) {
+    x0 *= scale;
+    x1 *= scale;
+    const floatx2 v = {x0, x1};
+    const halfx2 h = __builtin_convertvector(v, halfx2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const floatx2 back = __builtin_convertvector(h, floatx2);
+    f0 = back.x;
+    f1 = back.y;
+  } else {
+    const floatx2 v = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    f0 = __builtin_bit_cast(float, hi << 16);
+    f1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+  }
   floatx2 r;
   if (PK) {
     r = floatx2{x0 - f0, x1 - f1};
@@ -886,7 +925,16 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
     asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(x1), "v"(f1));
     r = floatx2{r0, r1};
   }
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  if (MODE == kSplitF16) lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, halfx2));
+  else lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+// one 32x32x16 matrix-core step on packed 16-bit operands of either kind
+template <int MODE>
+__device__ __forceinline__ floatx16 mfma16(uint4 a, uint4 b, floatx16 c) {
+  if (MODE == kSplitF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // Operand tile of 128 rows x 64 k.  Global element (r, k) at base[r*sr + k*sk], one stride = 1.
@@ -946,7 +994,8 @@ struct SplitIO {
   }
 
   // hi plane at T, lo plane at T + kSplitPlane (bytes)
-  static __device__ __forceinline__ void store(char* __restrict__ T, int tid, const float (&v)[NV]) {
+  template <int MODE>
+  static __device__ __forceinline__ void store(char* __restrict__ T, int tid, const float (&v)[NV], float scale) {
 #pragma unroll
     for (int t = 0; t < NV / 8; ++t) {
       int r, gk;
@@ -955,17 +1004,17 @@ struct SplitIO {
         const int u = tid + t * 256;
         r = u >> 3;
         gk = u & 7;
-        split2<true>(v[t * 8 + 0], v[t * 8 + 1], h.x, l.x);
-        split2<true>(v[t * 8 + 2], v[t * 8 + 3], h.y, l.y);
-        split2<true>(v[t * 8 + 4], v[t * 8 + 5], h.z, l.z);
-        split2<true>(v[t * 8 + 6], v[t * 8 + 7], h.w, l.w);
+        split2<true, MODE>(v[t * 8 + 0], v[t * 8 + 1], scale, h.x, l.x);
+        split2<true, MODE>(v[t * 8 + 2], v[t * 8 + 3], scale, h.y, l.y);
+        split2<true, MODE>(v[t * 8 + 4], v[t * 8 + 5], scale, h.z, l.z);
+        split2<true, MODE>(v[t * 8 + 6], v[t * 8 + 7], scale, h.w, l.w);
       } else {  // row t of the quad: element k = e sits at v[4*e + t]
         r = (tid & 31) * 4 + t;
         gk = tid >> 5;
-        split2<false>(v[t + 0], v[t + 4], h.x, l.x);
-        split2<false>(v[t + 8], v[t + 12], h.y, l.y);
-        split2<false>(v[t + 16], v[t + 20], h.z, l.z);
-        split2<false>(v[t + 24], v[t + 28], h.w, l.w);
+        split2<false, MODE>(v[t + 0], v[t + 4], scale, h.x, l.x);
+        split2<false, MODE>(v[t + 8], v[t + 12], scale, h.y, l.y);
+        split2<false, MODE>(v[t + 16], v[t + 20], scale, h.z, l.z);
+        split2<false, MODE>(v[t + 24], v[t + 28], scale, h.w, l.w);
       }
       const int off = r * 128 + ((gk ^ ((r >> 1) & 7)) << 4);
       *reinterpret_cast<uint4*>(T + off) = h;
@@ -974,8 +1023,8 @@ struct SplitIO {
   }
 };
 
-template <bool AK, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmArgs a) {
+template <bool AK, bool BKC, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
   using TA = SplitIO<AK>;
   using TB = SplitIO<BKC>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1024,27 +1073,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmArgs a)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int go = ((2 * s + fg) ^ fsw) << 4;
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      uint4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(As + a_off + i * 32 * 128 + go);
-        al[i] = *reinterpret_cast<const bf16x8*>(As + kSplitPlane + a_off + i * 32 * 128 + go);
-        bh[i] = *reinterpret_cast<const bf16x8*>(Bs + b_off + i * 32 * 128 + go);
-        bl[i] = *reinterpret_cast<const bf16x8*>(Bs + kSplitPlane + b_off + i * 32 * 128 + go);
+        ah[i] = *reinterpret_cast<const uint4*>(As + a_off + i * 32 * 128 + go);
+        al[i] = *reinterpret_cast<const uint4*>(As + kSplitPlane + a_off + i * 32 * 128 + go);
+        bh[i] = *reinterpret_cast<const uint4*>(Bs + b_off + i * 32 * 128 + go);
+        bl[i] = *reinterpret_cast<const uint4*>(Bs + kSplitPlane + b_off + i * 32 * 128 + go);
       }
       // small terms first, so that the large one meets the running sum last
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<MODE>(al[i], bh[j], acc[i][j]);
+          acc[i][j] = mfma16<MODE>(ah[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma16<MODE>(ah[i], bh[j], acc[i][j]);
         }
     }
   };
   const long sra = AK ? a.sam : 1, ska = AK ? 1 : a.sak, srb = BKC ? a.sbn : 1, skb = BKC ? 1 : a.sbk;
   float ra[32], rb[32];
+  float sa = 1.f, sb = 1.f, inva = 1.f, invb = 1.f;
+  if (MODE == kSplitF16) {
+    f16_split_scale(a.amax[0], sa, inva);
+    f16_split_scale(a.amax[1], sb, invb);
+  }
 #ifdef SD_PROFILING
   long long p_vm = 0, p_cvt = 0, p_mfma = 0, p_ld = 0;
   const long long p_begin = __builtin_readcyclecounter();
@@ -1061,8 +1115,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmArgs a)
       const long long c1 = __builtin_readcyclecounter();
 #endif
       __syncthreads();
-      TA::store(As, tid, ra);
-      TB::store(Bs, tid, rb);
+      TA::template store<MODE>(As, tid, ra, sa);
+      TB::template store<MODE>(Bs, tid, rb, sb);
       __syncthreads();
 #ifdef SD_PROFILING
       const long long c2 = __builtin_readcyclecounter();
@@ -1113,8 +1167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmArgs a)
     TA::template load<false>(A, sra, ska, m0, k0, a.M, a.K, tid, ra);
     TB::template load<false>(B, srb, skb, n0, k0, a.N, a.K, tid, rb);
     __syncthreads();
-    TA::store(As, tid, ra);
-    TB::store(Bs, tid, rb);
+    TA::template store<MODE>(As, tid, ra, sa);
+    TB::template store<MODE>(Bs, tid, rb, sb);
     __syncthreads();
     mfma_step();
   }
@@ -1129,7 +1183,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmArgs a)
         const int row = m0 + wm + i * 32 + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3);
         if (row < a.M && col < a.N) {
           float* c = C + (long)row * a.ldc + col;
-          const float v = acc[i][j][e];
+          float v = acc[i][j][e];
+          if (MODE == kSplitF16) v = (v * inva) * invb;  // exact (powers of two)
           if (piece || a.mode == 2) atomicAdd(c, v);
           else if (a.mode == 0) *c = v;
           else *c += v;
@@ -1151,16 +1206,21 @@ __global__ __launch_bounds__(256) void gemm_zero_tiles_kernel(GemmArgs a) {
   }
 }
 
-template <bool AK, bool BKC>
-static int launch_gemm_split(const GemmArgs& g, dim3 grid, hipStream_t st) {
+template <bool AK, bool BKC, int MODE>
+static int launch_gemm_split_m(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f32_split_bf16_kernel<AK, BKC>,
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f32_split_kernel<AK, BKC, MODE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSplitPlane));
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC>), grid, dim3(256), 4 * kSplitPlane, st, g);
+  hipLaunchKernelGGL((gemm_f32_split_kernel<AK, BKC, MODE>), grid, dim3(256), 4 * kSplitPlane, st, g);
   return SD_OK;
+}
+template <bool AK, bool BKC>
+static int launch_gemm_split(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  return g.amax ? launch_gemm_split_m<AK, BKC, kSplitF16>(g, grid, st)
+                : launch_gemm_split_m<AK, BKC, kSplitBF16>(g, grid, st);
 }
 
 // Tile width by wave quantisation: the grid is only a few tiles per CU (4.1 for the DCN forward
@@ -1180,7 +1240,13 @@ static void launch_gemm_j(const GemmArgs& g, int J, dim3 grid, hipStream_t st) {
 
 static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return SD_OK;
-  if (tuning("deform_gemm_split", 1) == 1) {
+  // deform_gemm_split: 2 (default) scaled fp16 hi/lo split -- needs the operand maxima (g.amax: the
+  // DCN entry points and sd_gemm_f32_ws provide them), without them the exact fp32 path runs;
+  // 1 bf16 hi/lo split (no maxima needed, 9x the error); 0 fp32 MFMA
+  int split = tuning("deform_gemm_split", 2);
+  if (split == 2 && !g.amax) split = 0;
+  if (split != 2) g.amax = nullptr;
+  if (split >= 1) {
     const bool ak = g.sak == 1, bk = g.sbk == 1;
     SD_REQUIRE(ak || g.sam == 1, "GEMM: A needs a unit stride");
     SD_REQUIRE(bk || g.sbn == 1, "GEMM: B needs a unit stride");
@@ -1256,6 +1322,44 @@ static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
   else launch_gemm_j<false, false>(g, J, grid, st);
   SD_LAUNCH_CHECK();
   return SD_OK;
+}
+
+// max|x| of a (batch, rows, cols) operand with row stride ld and batch stride bstride, as the bit
+// pattern of the largest |x| (non-negative floats order like unsigned integers; a NaN wins, and the
+// split then scales by 1): atomicMax into *out, which the caller zeroed.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, long rows, int cols,
+                                                     long ld, long bstride, int batch, unsigned* out) {
+  const long per = rows * cols, n = per * batch;
+  unsigned m = 0;
+  const bool dense = ld == cols && (bstride == per || batch == 1) && (((uintptr_t)p & 15) == 0);
+  if (dense) {
+    const long n4 = n >> 2;
+    const uint4* p4 = reinterpret_cast<const uint4*>(p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      const uint4 v = p4[i];
+      m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+      m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      const long b = i / per, r = (i - b * per) / cols;
+      const int c = (int)(i - b * per - r * cols);
+      m = max(m, __float_as_uint(p[b * bstride + r * ld + c]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+static void launch_absmax(const float* p, long rows, int cols, long ld, long bstride, int batch, unsigned* out,
+                          hipStream_t st) {
+  const long n = rows * cols * batch;
+  if (n <= 0) return;
+  long blocks = (n + 256 * 16 - 1) / (256 * 16);   // ~16 floats per lane
+  if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, rows, cols, ld, bstride, batch, out);
 }
 
 static int make_geom(DcnGeom& g, int N, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
@@ -1397,9 +1501,9 @@ extern "C" int sd_deform_col2im_coord(const float* col, const float* x, const fl
   return SD_OK;
 }
 
-extern "C" int sd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
-                           long strideA, const float* B, int ldb, long strideB, float* C, int ldc,
-                           long strideC, int batch, int accumulate, void* stream) {
+static int gemm_f32_impl(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                         long strideA, const float* B, int ldb, long strideB, float* C, int ldc,
+                         long strideC, int batch, int accumulate, const unsigned* amax, void* stream) {
   SD_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative dimension");
   SD_REQUIRE(accumulate >= 0 && accumulate <= 2, "accumulate must be 0, 1 or 2");
   if (M == 0 || N == 0 || batch == 0) return SD_OK;
@@ -1411,6 +1515,7 @@ extern "C" int sd_gemm_f32(int transA, int transB, int M, int N, int K, const fl
   g.sbk = transB ? 1 : ldb; g.sbn = transB ? ldb : 1;
   g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
   g.mode = accumulate;
+  g.amax = amax;
   if (K == 0) {
     if (accumulate == 0)
       for (int b = 0; b < batch; ++b)
@@ -1421,6 +1526,35 @@ extern "C" int sd_gemm_f32(int transA, int transB, int M, int N, int K, const fl
   return launch_gemm(g, batch, (hipStream_t)stream);
 }
 
+extern "C" int sd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                           long strideA, const float* B, int ldb, long strideB, float* C, int ldc,
+                           long strideC, int batch, int accumulate, void* stream) {
+  return gemm_f32_impl(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch,
+                       accumulate, nullptr, stream);
+}
+
+extern "C" size_t sd_gemm_f32_workspace_bytes(void) { return 64; }
+
+extern "C" int sd_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                              long strideA, const float* B, int ldb, long strideB, float* C, int ldc,
+                              long strideC, int batch, int accumulate, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  unsigned* amax = nullptr;
+  if (workspace && workspace_bytes >= 32 && M > 0 && N > 0 && K > 0 && batch > 0 && A && B &&
+      tuning("deform_gemm_split", 2) == 2) {
+    amax = reinterpret_cast<unsigned*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    hipStream_t st = (hipStream_t)stream;
+    SD_HIP_CHECK(hipMemsetAsync(amax, 0, 8, st));
+    // storage of op(A) (M x K): rows x cols = transA ? K x M : M x K, row stride lda; B likewise.
+    // A batch stride of 0 is one shared matrix.
+    launch_absmax(A, transA ? K : M, transA ? M : K, lda, strideA, strideA == 0 ? 1 : batch, amax, st);
+    launch_absmax(B, transB ? N : K, transB ? K : N, ldb, strideB, strideB == 0 ? 1 : batch, amax + 1, st);
+    SD_LAUNCH_CHECK();
+  }
+  return gemm_f32_impl(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch,
+                       accumulate, amax, stream);
+}
+
 extern "C" size_t sd_deform_conv_workspace_bytes(int N, int C, int H, int W, int kh, int kw,
                                                  int pad, int stride, int dil) {
   if (N <= 0 || C <= 0) return 256;
@@ -1428,6 +1562,12 @@ extern "C" size_t sd_deform_conv_workspace_bytes(int N, int C, int H, int W, int
   const long Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 256;
   return (size_t)N * C * kh * kw * Ho * Wo * sizeof(float) + 512;
+}
+
+// three words behind the (256-byte aligned) col matrix of a DCN workspace: the workspace size
+// contract (sd_deform_conv_workspace_bytes) leaves 512 bytes for the alignment and these
+static unsigned* dcn_amax_slots(float* col, size_t col_floats) {
+  return reinterpret_cast<unsigned*>(((uintptr_t)(col + col_floats) + 15) & ~(uintptr_t)15);
 }
 
 extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const float* weight,
@@ -1448,9 +1588,17 @@ extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const flo
                                dil, dgroup, stream))
     return e;
   const int K = C * kh * kw, P = g.Ho * g.Wo;
+  // operand maxima for the scaled fp16 split, behind the col matrix: {max|W|, max|x|}.  A col value is
+  // a convex combination of four x values (bilinear weights sum to 1 up to rounding: the split keeps
+  // a factor 4 of headroom), so max|x| bounds max|col| without a pass over the 620 MB of col.
+  unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
+  hipStream_t st = (hipStream_t)stream;
+  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
+  launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
+  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 1, st);
   // y[n] (F x P) = W (F x K) . col[n] (K x P)
-  return sd_gemm_f32(0, 0, F, P, K, weight, K, 0, col, P, (long)K * P, y, P, (long)F * P, N, 0,
-                     stream);
+  return gemm_f32_impl(0, 0, F, P, K, weight, K, 0, col, P, (long)K * P, y, P, (long)F * P, N, 0, amax,
+                       stream);
 }
 
 // `fwd_col`: the col matrix a forward of the same (x, offset) left in ITS workspace
@@ -1476,10 +1624,16 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
   float* col = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const int K = C * kh * kw, P = g.Ho * g.Wo;
   hipStream_t st = (hipStream_t)stream;
+  // operand maxima for the scaled fp16 split: {max|W|, max|dY|, max|x| >= max|col|}
+  unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
+  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
+  launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
+  launch_absmax(out_grad, (long)N * F, P, P, 0, 1, amax + 1, st);
+  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 2, st);
   if (req_x != SD_REQ_NULL || req_offset != SD_REQ_NULL) {
     // dcol[n] (K x P) = W^T (K x F) . dY[n] (F x P)
-    if (int e = sd_gemm_f32(1, 0, K, P, F, weight, K, 0, out_grad, P, (long)F * P, col, P,
-                            (long)K * P, N, 0, stream))
+    if (int e = gemm_f32_impl(1, 0, K, P, F, weight, K, 0, out_grad, P, (long)F * P, col, P,
+                              (long)K * P, N, 0, amax, stream))
       return e;
     if (int e = sd_deform_col2im_coord(col, x, offset, d_offset, req_offset, N, C, H, W, kh, kw, pad,
                                        pad, stride, stride, dil, dil, dgroup, stream))
@@ -1499,8 +1653,8 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
     if (req_weight == SD_REQ_WRITE)
       SD_HIP_CHECK(hipMemsetAsync(d_weight, 0, sizeof(float) * (size_t)F * K, st));
     // dW (F x K) += sum_n dY[n] (F x P) . col[n]^T (P x K): images in grid.z, atomic accumulate
-    return sd_gemm_f32(0, 1, F, K, P, out_grad, P, (long)F * P, col, P, (long)K * P, d_weight, K, 0,
-                       N, 2, stream);
+    return gemm_f32_impl(0, 1, F, K, P, out_grad, P, (long)F * P, col, P, (long)K * P, d_weight, K, 0,
+                         N, 2, amax + 1, stream);
   }
   return SD_OK;
 }

@@ -757,8 +757,9 @@ def deform_col2im_coord(col, x, offset, kernel=(3, 3), pad=1, stride=1, dilate=1
 
 def gemm_f32(a, b, trans_a=False, trans_b=False, out=None, accumulate=0):
     """Batched fp32-in / fp32-out matrix-core GEMM: a (Bt,M,K) or its transpose, b (Bt,K,N) or its
-    transpose.  Products are three bf16 MFMA terms of a hi/lo split (4.5e-6 x max|C|) unless the
-    tuning key `deform_gemm_split` is 0 (fp32 MFMA); see include/simpledet_ops.h."""
+    transpose.  Default arithmetic: scaled fp16 hi/lo split on the f16 matrix cores after a max|.|
+    pre-pass over both operands (accuracy of the fp32 MFMA path); tuning key `deform_gemm_split` = 1:
+    bf16 split (4.5e-6 x max|C|), 0: fp32 MFMA; see include/simpledet_ops.h."""
     _chk(a, "a", ndim=3)
     _chk(b, "b", ndim=3)
     Bt = a.shape[0]
@@ -768,9 +769,10 @@ def gemm_f32(a, b, trans_a=False, trans_b=False, out=None, accumulate=0):
         raise ValueError("GEMM shape mismatch")
     if out is None:
         out = torch.empty((Bt, M, N), device=a.device, dtype=torch.float32)
-    lib().call("sd_gemm_f32", int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[2],
+    ws = torch.empty(64, device=a.device, dtype=torch.uint8)
+    lib().call("sd_gemm_f32_ws", int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[2],
                a.shape[1] * a.shape[2], _p(b), b.shape[2], b.shape[1] * b.shape[2], _p(out), N,
-               M * N, Bt, int(accumulate), _stream())
+               M * N, Bt, int(accumulate), _p(ws), ctypes.c_size_t(64), _stream())
     return out
 
 
