@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--float-argmax", action="store_true",
                     help="keep the arg-max between forward and backward as two fp32 planes (the "
                          "reference op's outputs) instead of one byte per output")
+    ap.add_argument("--no-plan", action="store_true",
+                    help="A/B: the forward and the backward each launch their own rois-only pre-pass (4 "
+                         "launches per step) instead of one merged pre-pass in the forward (3 launches)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also run the known-size HBM stream copies (measured peak + PMC calibration)")
     ap.add_argument("--no-ops", action="store_true",
@@ -208,7 +211,7 @@ def main():
         if args.float_argmax:
             out, ax, ay = ops.fpn_roi_align_forward(feats, rois, strides, (7, 7))
         else:
-            out, am = ops.fpn_roi_align_forward_packed(feats, rois, strides, (7, 7))
+            out, am = ops.fpn_roi_align_forward_packed(feats, rois, strides, (7, 7), plan=not args.no_plan)
         if ev:
             ev[1].record()
         if reducer is not None:

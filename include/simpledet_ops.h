@@ -192,6 +192,30 @@ int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float* rois, con
                                    int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
                                    float roi_canonical_level, void* workspace, size_t workspace_bytes,
                                    void* stream);
+/* ONE rois-only pre-pass per training step.  Both pre-passes of the fused extractor -- the forward's
+ * item lists / tap entries / coordinate table and the backward's band lists / tap tables -- are pure
+ * functions of `rois` and the level geometry.  With a `plan` buffer of sd_fpn_roi_align_plan_bytes()
+ * (16-byte aligned, op state between forward and backward like argmax / coords; ~9 MB at the
+ * baseline) the forward builds both in its single pre-pass launch and the backward launches its main
+ * kernel only: 3 launches per step instead of 4.  Same bits as the _ws pair.  The plan is valid for the
+ * shapes, rois and tuning knobs of the forward that filled it; where the band / tap-table form does
+ * not apply (knob roi_align_bwd_lists != 1, a level that does not fit) both calls fall back to the
+ * behaviour of the unplanned pair by the same deterministic decision.
+ *   replaces the same reference code as sd_fpn_roi_align_fwd_packed / _bwd_packed
+ *   (models/FPN/builder.py:567-610; roi_align_v2-inl.h:61-195, roi_align_v2.cu:35-143) */
+size_t sd_fpn_roi_align_plan_bytes(const int* Hs_host, const int* Ws_host, int nlvl, int B, int R);
+int sd_fpn_roi_align_fwd_packed_plan(const float* const* feats_host, const int* Hs_host, const int* Ws_host,
+                                     const int* strides_host, int nlvl, const float* rois, float* out,
+                                     uint8_t* argmax, float* coords, int B, int C, int R, int pooled_h,
+                                     int pooled_w, float roi_canonical_scale, float roi_canonical_level,
+                                     void* workspace, size_t workspace_bytes, void* plan, size_t plan_bytes,
+                                     void* stream);
+int sd_fpn_roi_align_bwd_packed_plan(const float* out_grad, const float* rois, const uint8_t* argmax,
+                                     const float* coords, float* const* d_feats_host, const int* Hs_host,
+                                     const int* Ws_host, const int* strides_host, int nlvl, int req_data,
+                                     int B, int C, int R, int pooled_h, int pooled_w,
+                                     float roi_canonical_scale, float roi_canonical_level, const void* plan,
+                                     size_t plan_bytes, void* stream);
 /* assign_layer_fpn CustomOp (models/FPN/assign_layer_fpn.py:10-73): rois (n_rois,4) ->
  * rois_per_level (nlvl, n_rois, 4) zero-masked, and optionally level (n_rois) int32 (-1 = none) */
 int sd_fpn_roi_assign(const float* rois, int n_rois, const int* strides_host, int nlvl,

@@ -1815,6 +1815,7 @@ struct BwdFusedArgs {
   int* ws_list;
   float* ws_taps;                    // [unit][R][2 * 3 * (PH + PW)] band-relative tap entries, list order
   int unit_base[SD_MAX_FPN_LEVELS];  // first unit of launch-order level li
+  int lists_units;                   // (level, image, band) units the list pre-pass covers
 };
 
 template <int PP, int THREADS, bool PK>
@@ -2085,18 +2086,20 @@ __device__ __forceinline__ void bwd_band_list(const BwdFusedArgs& a, int lvl, in
 
 // Pre-pass per (level, image, band) unit: its list into the workspace, read by the 256 channel
 // workgroups of roi_align_bwd_packed4 instead of being rebuilt by each of them.
-constexpr int kListSplit = 4;
-template <int PH, int PW>
-__global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
-  constexpr int THREADS = 512;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// A pure function of `rois` (and the level geometry): the sample coordinates are recomputed with
+// sample_coord() -- the very expression the forward fills its coordinate table with -- instead of
+// being read from that table, so these blocks do not depend on the forward's pre-pass and can run
+// in the SAME launch (roi_prep_merged_kernel below): one rois-only pre-pass per training step.
+constexpr int kListSplit = 4;   // 512-thread blocks per unit (stand-alone launch)
+template <int PH, int PW, int THREADS, int PARTS>
+__device__ __forceinline__ void bwd_lists_block(const BwdFusedArgs& a, int block, float* smem) {
   int* list = reinterpret_cast<int*>(smem);
   int* nlist = list + a.R;
   const int tid = threadIdx.x;
-  // kListSplit workgroups per unit: each builds the (cheap) list, the first stores it, all share
-  // the tap entries -- the entry loop is a chain of dependent round trips (list -> coordinate ->
+  // PARTS workgroups per unit: each builds the (cheap) list, the first stores it, all share
+  // the tap entries -- the entry loop is a chain of dependent round trips (list -> box ->
   // entry), so more workgroups shorten the pre-pass
-  const int unit = (int)blockIdx.x / kListSplit, part = (int)blockIdx.x % kListSplit;
+  const int unit = block / PARTS, part = block % PARTS;
   int li = 0;
   while (li + 1 < a.nlaunch && unit >= a.unit_base[li + 1]) ++li;
   const int lvl = a.order[li];
@@ -2117,17 +2120,21 @@ __global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
     for (int i = tid; i < nl; i += THREADS) dst[2 + i] = list[i];
   }
   // ... and the tap entries of the listed RoIs (see roi_align_bwd_packed4): per sample coordinate
-  // of the forward's table {neighbours, fraction} with the backward's own expressions, the row
-  // neighbours as offsets inside this band (0xffff: outside), 8 bytes each, in list order
+  // {neighbours, fraction} with the backward's own expressions, the row neighbours as offsets
+  // inside this band (0xffff: outside), 8 bytes each, in list order
   if (a.ws_taps) {
-    constexpr int NE = 3 * (PH + PW), CW = kCoordWords * (PH + PW);
+    constexpr int NE = 3 * (PH + PW);
     const int H = a.L.H[lvl], W = a.L.W[lvl];
-    const float* cob = a.coords + (long)img * a.R * CW;
+    const float scale = a.L.scale[lvl];
     float* tdst = a.ws_taps + (long)unit * a.R * (2 * NE);
-    for (int i = part * THREADS + tid; i < nl * NE; i += kListSplit * THREADS) {
+    for (int i = part * THREADS + tid; i < nl * NE; i += PARTS * THREADS) {
       const int j = i / NE, e = i - j * NE;
-      const float v = cob[list[j] * CW + e];
       const bool row = e < 3 * PH;
+      const int ee = row ? e : e - 3 * PH;
+      const float4 bx = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + list[j]) * 4);
+      // == the forward's coords[roi][e] (band_prep_block / roi_coords_kernel), bit for bit
+      const float v = row ? sample_coord(ee / 3, PH, bx.y, bx.w, scale, H, ee % 3)
+                          : sample_coord(ee / 3, PW, bx.x, bx.z, scale, W, ee % 3);
       const int size = row ? H : W;
       const int lo = iminr(imaxr((int)floorf(v), 0), size - 1);
       const int hi = iminr(imaxr((int)ceilf(v), 0), size - 1);
@@ -2141,6 +2148,24 @@ __global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
       *reinterpret_cast<float2*>(tdst + (long)j * (2 * NE) + 2 * e) = make_float2(__uint_as_float(w0), frac);
     }
   }
+}
+
+template <int PH, int PW>
+__global__ __launch_bounds__(512) void roi_align_bwd_lists(BwdFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_lists_block<PH, PW, 512, kListSplit>(a, (int)blockIdx.x, smem);
+}
+
+// ONE rois-only pre-pass for a training step: the forward's item lists / tap entries / coordinate
+// table (band_prep_block) and the backward's band lists / tap tables (bwd_lists_block) in a single
+// launch -- both are pure functions of `rois` (VERDICT r3 "Next 3(i)").  Blocks [0, nfwd) do the
+// forward's part, the rest the backward's (two 1024-thread blocks per backward unit).
+constexpr int kMergedListSplit = 2;
+template <int POOL>
+__global__ __launch_bounds__(kBandThreads) void roi_prep_merged_kernel(BandArgs A, BwdFusedArgs b, int nfwd) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < nfwd) band_prep_block<POOL>(A, (int)blockIdx.x, A.p.nlist, A.p.nent);
+  else bwd_lists_block<POOL, POOL, kBandThreads, kMergedListSplit>(b, (int)blockIdx.x - nfwd, smem);
 }
 
 template <int PH, int PW, int THREADS, int TCH, int MODE>
@@ -2559,8 +2584,14 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
 }
 
 // levels: dx[l] / H / W / scale from a.L; returns SD_ERR_UNSUPPORTED when a level does not fit
+// prepass: 0 the launch builds its own lists / tap tables (roi_align_bwd_lists) when it has a workspace;
+//          1 PLAN ONLY: fill `a` (bands, order, workspace pointers) for a list pre-pass somebody else
+//            launches -- the forward's merged pre-pass -- and launch nothing; SD_ERR_UNSUPPORTED when
+//            this shape / workspace does not get the list + tap-table form;
+//          2 the lists and tap tables in the workspace are already built (by a prepass = 1 plan
+//            of the same shapes, knobs and workspace): skip the pre-pass launch.
 static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace = nullptr,
-                            size_t workspace_bytes = 0) {
+                            size_t workspace_bytes = 0, int prepass = 0) {
   // packed arg-max: the wide-load kernel (roi_align_bwd_packed4); its coordinate tables share the
   // LDS with the band, so the band budget is a little smaller
   const bool flt = !a.amax8 && a.ax && a.ay;  // float arg-max planes: the same kernel without tables
@@ -2570,7 +2601,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
   if ((long)a.R * a.C * a.PP >= (1L << 31)) return SD_ERR_UNSUPPORTED;  // 32-bit lane offsets
   // single-level float arg-max backward on a small map: four channels per workgroup
-  if (flt && !a.filter && nlvl == 1 && a.dx[0] && a.C % 4 == 0 && a.B <= 65535 &&
+  if (prepass == 0 && flt && !a.filter && nlvl == 1 && a.dx[0] && a.C % 4 == 0 && a.B <= 65535 &&
       (long)a.L.H[0] * a.L.W[0] * 16 <= 72 * 1024 && tuning("roi_align_bwd_flt4", 1) == 1 &&
       (((uintptr_t)a.dy | (uintptr_t)a.ax | (uintptr_t)a.ay) & 15) == 0) {
     const size_t lds4 = (size_t)a.L.H[0] * a.L.W[0] * 16;
@@ -2665,14 +2696,20 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
     }
     if (nl < SD_MAX_FPN_LEVELS) a.unit_base[nl] = (int)ub;
   }
+  a.lists_units = 0;
   if (use_lists && nl < SD_MAX_FPN_LEVELS) {
     a.ws_list = static_cast<int*>(workspace);
     if (use_taps) a.ws_taps = reinterpret_cast<float*>(static_cast<char*>(workspace) + list_bytes);
-    const size_t lds = (size_t)(a.R + 8 + 16) * 4;
-    const dim3 g((unsigned)units * kListSplit);
-    if (a.PP == 49) hipLaunchKernelGGL((roi_align_bwd_lists<7, 7>), g, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((roi_align_bwd_lists<14, 14>), g, dim3(512), lds, st, a);
+    a.lists_units = (int)units;
+    if (prepass == 0) {
+      const size_t lds = (size_t)(a.R + 8 + 16) * 4;
+      const dim3 g((unsigned)units * kListSplit);
+      if (a.PP == 49) hipLaunchKernelGGL((roi_align_bwd_lists<7, 7>), g, dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((roi_align_bwd_lists<14, 14>), g, dim3(512), lds, st, a);
+    }
   }
+  if (prepass != 0 && !(a.ws_list && a.ws_taps)) return SD_ERR_UNSUPPORTED;
+  if (prepass == 1) return SD_OK;
   int threads = tuning("roi_align_bwd_threads", 0);
   if (threads != 256 && threads != 512) threads = 512;
   if (wide) {
@@ -2837,8 +2874,12 @@ static int fill_levels(RoiLevels& L, const float* const* feats, const int* Hs, c
   return SD_OK;
 }
 
+// bplan: a backward plan (launch_bwd_fused prepass = 1) whose list / tap-table pre-pass is to run in
+// the forward's pre-pass launch; *bplan_done tells whether it did (band-resident path only).
 static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
-                      size_t workspace_bytes = 0) {
+                      size_t workspace_bytes = 0, const BwdFusedArgs* bplan = nullptr,
+                      bool* bplan_done = nullptr) {
+  if (bplan_done) *bplan_done = false;
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
   // 0 naive, 1 tiled (default; the 64-VGPR build for the packed 7x7 path), 3 tiled without the
@@ -2977,10 +3018,22 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       const int ncoord = a.amax8 ? cdiv((long)nroi * 6 * POOL, kBandThreads) : 0;
       P.nlist = nlist; P.nent = nent;
       const int smem = 2 * kBandBufFloats * (int)sizeof(float);
+      const bool merged = bplan && bplan->lists_units > 0 && bplan->PP == POOL * POOL;
+      if (bplan_done) *bplan_done = merged;
+#define SD_FWD_PREP(POOLV)                                                                        \
+  do {                                                                                            \
+    if (merged)                                                                                   \
+      hipLaunchKernelGGL((roi_prep_merged_kernel<POOLV>),                                         \
+                         dim3(nlist + nent + ncoord + bplan->lists_units * kMergedListSplit),     \
+                         dim3(kBandThreads), (size_t)(a.R + 8 + 16) * 4, st, A, *bplan,           \
+                         nlist + nent + ncoord);                                                  \
+    else                                                                                          \
+      hipLaunchKernelGGL((roi_fwd_prep_kernel<POOLV>), dim3(nlist + nent + ncoord),               \
+                         dim3(kBandThreads), 0, st, A);                                           \
+  } while (0)
 #define SD_FWD_BAND(POOLV, PK)                                                                    \
   do {                                                                                            \
-    hipLaunchKernelGGL((roi_fwd_prep_kernel<POOLV>), dim3(nlist + nent + ncoord), dim3(kBandThreads), 0, \
-                       st, A);                                                                    \
+    SD_FWD_PREP(POOLV);                                                                           \
     auto k = roi_align_fwd_band<POOLV, PK>;                                                       \
     SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                      smem));                                                      \
@@ -2989,8 +3042,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       if (a.half_io) {  // fp16 features and output, packed arg-max
 #define SD_FWD_BAND_H(POOLV)                                                                      \
   do {                                                                                            \
-    hipLaunchKernelGGL((roi_fwd_prep_kernel<POOLV>), dim3(nlist + nent + ncoord), dim3(kBandThreads), 0, \
-                       st, A);                                                                    \
+    SD_FWD_PREP(POOLV);                                                                           \
     auto k = roi_align_fwd_band<POOLV, true, true>;                                               \
     SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                      smem));                                                      \
@@ -3004,6 +3056,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
         if (a.amax8) SD_FWD_BAND(14, true); else SD_FWD_BAND(14, false);
       }
 #undef SD_FWD_BAND
+#undef SD_FWD_PREP
       SD_LAUNCH_CHECK();
       return SD_OK;
     }
@@ -3243,13 +3296,12 @@ extern "C" int sd_fpn_roi_align_argmax_stride(int pooled_h, int pooled_w) {
   return amax_stride(pooled_h * pooled_w);
 }
 
-extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_host,
-                                           const int* Ws_host, const int* strides_host, int nlvl,
-                                           const float* rois, float* out, uint8_t* argmax,
-                                           float* coords, int B, int C, int R, int pooled_h,
-                                           int pooled_w,
-                                           float roi_canonical_scale, float roi_canonical_level,
-                                           void* workspace, size_t workspace_bytes, void* stream) {
+static int fpn_fwd_packed_impl(const float* const* feats_host, const int* Hs_host, const int* Ws_host,
+                               const int* strides_host, int nlvl, const float* rois, float* out,
+                               uint8_t* argmax, float* coords, int B, int C, int R, int pooled_h,
+                               int pooled_w, float roi_canonical_scale, float roi_canonical_level,
+                               void* workspace, size_t workspace_bytes, void* plan, size_t plan_bytes,
+                               void* stream) {
   if (int e = check_dims(B, C, R, pooled_h, pooled_w)) return e;
   SD_REQUIRE(feats_host && Hs_host && Ws_host && strides_host, "null level description");
   SD_REQUIRE((argmax && coords) || (long)B * R * C == 0, "argmax / coords is null");
@@ -3263,7 +3315,56 @@ extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const
   if (nlvl == 1) a.L.nlvl = 2, a.L.stride[1] = -1;
   a.rois = rois; a.out = out; a.amax8 = argmax; a.coords = coords;
   a.B = B; a.C = C; a.R = R; a.PH = pooled_h; a.PW = pooled_w;
-  return launch_fwd(a, (hipStream_t)stream, workspace, workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  // the backward's list / tap-table pre-pass rides in the forward's pre-pass launch when the caller
+  // hands over the plan buffer the backward will read (sd_fpn_roi_align_bwd_packed_plan)
+  BwdFusedArgs f{};
+  bool have = false;
+  if (plan && ((uintptr_t)plan & 15) == 0 && (long)B * R * C > 0 && R <= 8192 &&
+      ((pooled_h == 7 && pooled_w == 7) || (pooled_h == 14 && pooled_w == 14))) {
+    f.L = a.L;
+    f.amax8 = argmax; f.coords = coords; f.rois = rois;
+    for (int l = 0; l < nlvl; ++l) f.dx[l] = reinterpret_cast<float*>(uintptr_t(16));  // (planning only: "wanted")
+    f.B = B; f.C = C; f.R = R; f.PP = pooled_h * pooled_w; f.filter = 1; f.req = SD_REQ_WRITE;
+    have = launch_bwd_fused(f, nlvl, st, plan, plan_bytes, 1) == SD_OK;
+  }
+  bool done = false;
+  if (int e = launch_fwd(a, st, workspace, workspace_bytes, have ? &f : nullptr, &done)) return e;
+  if (have && !done) {  // the forward ran on a fallback kernel: the stand-alone list pre-pass
+    const size_t lds = (size_t)(R + 8 + 16) * 4;
+    const dim3 g((unsigned)f.lists_units * kListSplit);
+    if (f.PP == 49) hipLaunchKernelGGL((roi_align_bwd_lists<7, 7>), g, dim3(512), lds, st, f);
+    else hipLaunchKernelGGL((roi_align_bwd_lists<14, 14>), g, dim3(512), lds, st, f);
+    SD_LAUNCH_CHECK();
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_fpn_roi_align_fwd_packed(const float* const* feats_host, const int* Hs_host,
+                                           const int* Ws_host, const int* strides_host, int nlvl,
+                                           const float* rois, float* out, uint8_t* argmax,
+                                           float* coords, int B, int C, int R, int pooled_h,
+                                           int pooled_w,
+                                           float roi_canonical_scale, float roi_canonical_level,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  return fpn_fwd_packed_impl(feats_host, Hs_host, Ws_host, strides_host, nlvl, rois, out, argmax, coords, B, C,
+                             R, pooled_h, pooled_w, roi_canonical_scale, roi_canonical_level, workspace,
+                             workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int sd_fpn_roi_align_fwd_packed_plan(const float* const* feats_host, const int* Hs_host,
+                                                const int* Ws_host, const int* strides_host, int nlvl,
+                                                const float* rois, float* out, uint8_t* argmax,
+                                                float* coords, int B, int C, int R, int pooled_h,
+                                                int pooled_w, float roi_canonical_scale,
+                                                float roi_canonical_level, void* workspace,
+                                                size_t workspace_bytes, void* plan, size_t plan_bytes,
+                                                void* stream) {
+  SD_REQUIRE(plan, "plan is null (use sd_fpn_roi_align_fwd_packed)");
+  SD_REQUIRE(((uintptr_t)plan & 15) == 0, "plan must be 16-byte aligned");
+  return fpn_fwd_packed_impl(feats_host, Hs_host, Ws_host, strides_host, nlvl, rois, out, argmax, coords, B, C,
+                             R, pooled_h, pooled_w, roi_canonical_scale, roi_canonical_level, workspace,
+                             workspace_bytes, plan, plan_bytes, stream);
 }
 
 extern "C" int sd_fpn_roi_align_fwd_packed_f16(const void* const* feats_host, const int* Hs_host,
@@ -3321,7 +3422,7 @@ extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* r
                                         roi_canonical_scale, roi_canonical_level, nullptr, 0, stream);
 }
 
-extern "C" int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float* rois,
+static int fpn_bwd_packed_impl(int planned, const float* out_grad, const float* rois,
                                               const uint8_t* argmax, const float* coords,
                                               float* const* d_feats_host,
                                               const int* Hs_host, const int* Ws_host,
@@ -3361,9 +3462,44 @@ extern "C" int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float
   SD_REQUIRE(((uintptr_t)argmax & 3) == 0 && ((uintptr_t)coords & 7) == 0,
              "argmax must be 4-byte and coords 8-byte aligned");
   SD_REQUIRE(!workspace || ((uintptr_t)workspace & 3) == 0, "workspace must be 4-byte aligned");
-  const int e = launch_bwd_fused(f, nlvl, (hipStream_t)stream, workspace, workspace_bytes);
+  int e = SD_ERR_UNSUPPORTED;
+  // planned: the forward (sd_fpn_roi_align_fwd_packed_plan) has left the band lists / tap tables in
+  // `workspace`; where its plan did not apply (same deterministic decision here) the normal path runs
+  if (planned) e = launch_bwd_fused(f, nlvl, (hipStream_t)stream, workspace, workspace_bytes, 2);
+  if (e == SD_ERR_UNSUPPORTED) e = launch_bwd_fused(f, nlvl, (hipStream_t)stream, workspace, workspace_bytes, 0);
   if (e == SD_ERR_UNSUPPORTED) return fail(e, "packed arg-max backward: a level does not fit LDS");
   return e;
+}
+
+extern "C" int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float* rois,
+                                              const uint8_t* argmax, const float* coords,
+                                              float* const* d_feats_host,
+                                              const int* Hs_host, const int* Ws_host,
+                                              const int* strides_host, int nlvl, int req_data, int B,
+                                              int C, int R, int pooled_h, int pooled_w,
+                                              float roi_canonical_scale, float roi_canonical_level,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  return fpn_bwd_packed_impl(0, out_grad, rois, argmax, coords, d_feats_host, Hs_host, Ws_host, strides_host,
+                             nlvl, req_data, B, C, R, pooled_h, pooled_w, roi_canonical_scale,
+                             roi_canonical_level, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t sd_fpn_roi_align_plan_bytes(const int* Hs_host, const int* Ws_host, int nlvl, int B, int R) {
+  return sd_fpn_roi_align_bwd_workspace_bytes(Hs_host, Ws_host, nlvl, B, R);
+}
+
+extern "C" int sd_fpn_roi_align_bwd_packed_plan(const float* out_grad, const float* rois,
+                                                const uint8_t* argmax, const float* coords,
+                                                float* const* d_feats_host, const int* Hs_host,
+                                                const int* Ws_host, const int* strides_host, int nlvl,
+                                                int req_data, int B, int C, int R, int pooled_h,
+                                                int pooled_w, float roi_canonical_scale,
+                                                float roi_canonical_level, const void* plan,
+                                                size_t plan_bytes, void* stream) {
+  SD_REQUIRE(plan && ((uintptr_t)plan & 15) == 0, "plan must be the 16-byte aligned buffer the forward filled");
+  return fpn_bwd_packed_impl(1, out_grad, rois, argmax, coords, d_feats_host, Hs_host, Ws_host, strides_host,
+                             nlvl, req_data, B, C, R, pooled_h, pooled_w, roi_canonical_scale,
+                             roi_canonical_level, const_cast<void*>(plan), plan_bytes, stream);
 }
 
 extern "C" size_t sd_fpn_roi_align_workspace_bytes(int B, int R) {

@@ -737,7 +737,17 @@ def _build_ops(mx):
                            self.pooled[0], self.pooled[1], float(self.scale0), float(self.lvl0),
                            _ptr(ws), ctypes.c_size_t(wsb), None)
 
-            if not self.fp16:
+            if not self.fp16 and self.packed and is_train:
+                # training: ONE rois-only pre-pass for the step -- the backward's band lists / tap
+                # tables are built here, into the op's fourth (private) output
+                plan = out_data[3]
+                lib().call(fn + "_plan", ptrs, Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois),
+                           _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), B, C, rois.shape[1],
+                           self.pooled[0], self.pooled[1], float(self.scale0), float(self.lvl0),
+                           _ptr(ws), ctypes.c_size_t(wsb), _ptr(plan), ctypes.c_size_t(plan.size), None)
+                self._planned = True
+            elif not self.fp16:
+                self._planned = False
                 run(fn, ptrs, out_data[0])
             else:
                 try:
@@ -759,7 +769,7 @@ def _build_ops(mx):
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
             feats, rois = in_data[:-1], in_data[-1]
-            _wait(out_grad[0], rois, out_data[1], out_data[2])
+            _wait(out_grad[0], rois, *out_data[1:])
             rq = {_req(r) for r in req[:-1]}
             if len(rq) != 1:
                 raise RuntimeError("fpn_roi_align: all feature gradients must share one req")
@@ -778,7 +788,13 @@ def _build_ops(mx):
                 rq = {req_data}
             ptrs, Hs, Ws = self._levels(in_grad[:-1])
             out_grad = [og]
-            if self.packed:  # with the workspace the per-band RoI lists are built once, not per channel
+            if self.packed and not self.fp16 and getattr(self, "_planned", False):
+                plan = out_data[3]   # lists / tap tables left by this op's forward
+                lib().call("sd_fpn_roi_align_bwd_packed_plan", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                           _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B, C,
+                           rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
+                           float(self.lvl0), _ptr(plan), ctypes.c_size_t(plan.size), None)
+            elif self.packed:  # with the workspace the per-band RoI lists are built once, not per channel
                 lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
                 wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(Hs, Ws, len(feats), B, rois.shape[1])
                 ws = _scratch(rois, wsb)
@@ -813,7 +829,9 @@ def _build_ops(mx):
             return ["data_s{}".format(s) for s in self.rcnn_stride] + ["rois"]
 
         def list_outputs(self):
-            return ["output", "argmax", "coords"] if self.packed else ["output", "maxidx_x", "maxidx_y"]
+            # packed: output, then private forward -> backward state (arg-max codes, coordinate table,
+            # the backward's band lists / tap tables built by the forward's pre-pass)
+            return ["output", "argmax", "coords", "plan"] if self.packed else ["output", "maxidx_x", "maxidx_y"]
 
         num_visible_outputs = 1
 
@@ -824,22 +842,29 @@ def _build_ops(mx):
             o = (b[0], b[1], feats[0][1], self.pooled_size[0], self.pooled_size[1])
             if self.packed:
                 stride = int(lib().cdll.sd_fpn_roi_align_argmax_stride(*self.pooled_size))
+                lib().cdll.sd_fpn_roi_align_plan_bytes.restype = ctypes.c_size_t
+                pb = int(lib().cdll.sd_fpn_roi_align_plan_bytes(_iarr([f[2] for f in feats]),
+                                                                _iarr([f[3] for f in feats]), len(feats),
+                                                                int(b[0]), int(b[1])))
                 return in_shape, [o, (b[0], b[1], feats[0][1], stride),
-                                  (b[0], b[1], 9 * (self.pooled_size[0] + self.pooled_size[1]))]
+                                  (b[0], b[1], 9 * (self.pooled_size[0] + self.pooled_size[1])),
+                                  ((pb + 15) // 16 * 16,)]
             return in_shape, [o, o, o]
 
         def infer_type(self, in_type):
             import numpy as np
             f32 = np.float32
             if self.fp16:  # feature maps fp16, rois fp32 -> output fp16; the state keeps its types
-                return [np.float16] * (len(in_type) - 1) + [f32], [np.float16, np.uint8, f32], []
-            return in_type, [f32, np.uint8 if self.packed else f32, f32], []
+                return [np.float16] * (len(in_type) - 1) + [f32], [np.float16, np.uint8, f32, np.uint8], []
+            if self.packed:
+                return in_type, [f32, np.uint8, f32, np.uint8], []
+            return in_type, [f32, f32, f32], []
 
         def create_operator(self, ctx, shapes, dtypes):
             return FPNRoIAlign(self.rcnn_stride, self.pooled_size, self.scale0, self.lvl0, self.fp16)
 
         def declare_backward_dependency(self, out_grad, in_data, out_data):
-            return [out_grad[0], in_data[-1], out_data[1], out_data[2]]
+            return [out_grad[0], in_data[-1]] + list(out_data[1:])
 
     ops["fpn_roi_align"] = (FPNRoIAlignProp, None)
 

@@ -170,7 +170,7 @@ def argmax_codes(argmax, pooled_size):
 
 
 def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_canonical_scale=224,
-                                 roi_canonical_level=4):
+                                 roi_canonical_level=4, plan=False):
     """The fused extractor with a one-byte arg-max: -> out (B,R,C,ph,pw) fp32, argmax (B,R,C,S)
     uint8 (S = ph*pw rounded up to a multiple of 4; code = row sample * 3 + column sample, 255 =
     nothing pooled; unpack with argmax_codes()), coords (B,R,9*(ph+pw)) 4-byte
@@ -194,6 +194,17 @@ def fpn_roi_align_forward_packed(feats, rois, rcnn_stride, pooled_size, roi_cano
     coords = torch.empty((B, R, 9 * (ph + pw)), device=rois.device, dtype=torch.float32)
     wsb = lib().cdll.sd_fpn_roi_align_workspace_bytes(B, R)
     ws = torch.empty(wsb, device=rois.device, dtype=torch.uint8)
+    if plan:
+        # one rois-only pre-pass for the whole step: the backward's band lists / tap tables are built
+        # here too and travel to fpn_roi_align_backward_packed as the third element of the state
+        Hs, Ws = _iarr([f.shape[2] for f in feats]), _iarr([f.shape[3] for f in feats])
+        pb = lib().cdll.sd_fpn_roi_align_plan_bytes(Hs, Ws, len(feats), B, R)
+        plan_buf = torch.empty(pb, device=rois.device, dtype=torch.uint8)
+        lib().call("sd_fpn_roi_align_fwd_packed_plan", _parr(feats), Hs, Ws, _iarr(rcnn_stride), len(feats),
+                   _p(rois), _p(out), _p(amax), _p(coords), B, C, R, ph, pw, float(roi_canonical_scale),
+                   float(roi_canonical_level), _p(ws), ctypes.c_size_t(wsb), _p(plan_buf),
+                   ctypes.c_size_t(pb), _stream())
+        return out, (amax, coords, plan_buf)
     lib().call("sd_fpn_roi_align_fwd_packed", _parr(feats), _iarr([f.shape[2] for f in feats]),
                _iarr([f.shape[3] for f in feats]), _iarr(rcnn_stride), len(feats), _p(rois),
                _p(out), _p(amax), _p(coords), B, C, R, ph, pw, float(roi_canonical_scale),
@@ -245,7 +256,8 @@ def fpn_roi_align_backward_packed(out_grad, rois, argmax, feat_shapes, rcnn_stri
                                   d_feats=None):
     _chk(out_grad, "out_grad", ndim=5)
     _chk(rois, "rois", ndim=3)
-    argmax, coords = argmax
+    plan_buf = argmax[2] if len(argmax) > 2 else None   # forward(plan=True): lists / tap tables are built
+    argmax, coords = argmax[0], argmax[1]
     _chk(argmax, "argmax", dtype=torch.uint8, ndim=4)
     _chk(coords, "coords", ndim=3)
     B, R, C, ph, pw = out_grad.shape
@@ -260,6 +272,12 @@ def fpn_roi_align_backward_packed(out_grad, rois, argmax, feat_shapes, rcnn_stri
     for i, f in enumerate(d_feats):
         _chk(f, "d_feats[%d]" % i, ndim=4)
     hs, ws_ = _iarr([f.shape[2] for f in d_feats]), _iarr([f.shape[3] for f in d_feats])
+    if plan_buf is not None:
+        lib().call("sd_fpn_roi_align_bwd_packed_plan", _p(out_grad), _p(rois), _p(argmax), _p(coords),
+                   _parr(d_feats), hs, ws_, _iarr(rcnn_stride), len(d_feats), rd, B, C, R, ph, pw,
+                   float(roi_canonical_scale), float(roi_canonical_level), _p(plan_buf),
+                   ctypes.c_size_t(plan_buf.numel()), _stream())
+        return d_feats
     lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
     wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(hs, ws_, len(d_feats), B, R)
     work = torch.empty((max(int(wsb), 4) + 3) // 4, device=out_grad.device, dtype=torch.int32)

@@ -14,6 +14,10 @@ class _NDArray:
         return tuple(self.t.shape)
 
     @property
+    def size(self):
+        return int(self.t.numel())
+
+    @property
     def context(self):
         return str(self.t.device)
 

@@ -114,10 +114,15 @@ def test_fused_fpn_roi_align_prop(plugin):
     assert p.list_arguments() == ["data_s4", "data_s8", "data_s16", "data_s32", "rois"]
     assert p.num_visible_outputs == 1
     shapes = [(2, 256, 200, 334), (2, 256, 100, 167), (2, 256, 50, 84), (2, 256, 25, 42), (2, 512, 4)]
-    # 7x7: output + the op's private state (one-byte arg-max, per-RoI coordinate / tap table)
-    assert p.list_outputs() == ["output", "argmax", "coords"]
-    assert p.infer_shape(shapes)[1] == [(2, 512, 256, 7, 7), (2, 512, 256, 52), (2, 512, 126)]
-    assert [np.dtype(t) for t in p.infer_type([np.float32] * 5)[1]] == [np.float32, np.uint8, np.float32]
+    # 7x7: output + the op's private state (one-byte arg-max, per-RoI coordinate / tap table, and the
+    # backward's band lists / tap tables that the forward's single rois-only pre-pass builds)
+    assert p.list_outputs() == ["output", "argmax", "coords", "plan"]
+    out_shapes = p.infer_shape(shapes)[1]
+    assert out_shapes[:3] == [(2, 512, 256, 7, 7), (2, 512, 256, 52), (2, 512, 126)]
+    assert len(out_shapes[3]) == 1 and 1 << 20 < out_shapes[3][0] < 64 << 20 and out_shapes[3][0] % 16 == 0
+    assert [np.dtype(t) for t in p.infer_type([np.float32] * 5)[1]] == [np.float32, np.uint8, np.float32, np.uint8]
+    assert p.declare_backward_dependency(["dy"], ["a", "b", "c", "d", "rois"], ["o", "am", "co", "plan"]) == \
+        ["dy", "rois", "am", "co", "plan"]
     q = props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)", pooled_size="(5, 5)")
     assert q.list_outputs() == ["output", "maxidx_x", "maxidx_y"]
     assert q.infer_shape(shapes)[1] == [(2, 512, 256, 5, 5)] * 3
@@ -129,7 +134,8 @@ def test_fused_fpn_roi_align_prop_fp16(plugin):
     p = props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)", pooled_size="(14, 14)", fp16="True")
     tin, tout, _ = p.infer_type([np.float16] * 4 + [np.float32])
     assert [np.dtype(t) for t in tin] == [np.dtype(np.float16)] * 4 + [np.dtype(np.float32)]
-    assert [np.dtype(t) for t in tout] == [np.dtype(np.float16), np.dtype(np.uint8), np.dtype(np.float32)]
+    assert [np.dtype(t) for t in tout] == [np.dtype(np.float16), np.dtype(np.uint8), np.dtype(np.float32),
+                                           np.dtype(np.uint8)]
     with pytest.raises(ValueError):
         props["fpn_roi_align"](rcnn_stride="(4, 8, 16, 32)", pooled_size="(5, 5)", fp16="True")
 

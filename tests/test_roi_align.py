@@ -542,6 +542,49 @@ def test_packed_backward_is_bit_reproducible_and_within_1e4_at_full_size(ops, or
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pooled,num,channels", [((7, 7), 512, 256), ((14, 14), 128, 64), ((7, 7), 96, 16)])
+@pytest.mark.parametrize("knobs", [{}, {"roi_align_fwd_band": 0}, {"roi_align_bwd_lists": 2}])
+def test_planned_pair_one_prepass_equals_the_unplanned_pair(ops, pooled, num, channels, knobs):
+    """sd_fpn_roi_align_fwd_packed_plan / _bwd_packed_plan: both rois-only pre-passes in the forward's
+    single pre-pass launch (3 launches per step instead of 4).  Same bits as the _ws pair: output,
+    arg-max codes, coordinate table, gradients (the planned backward reads band lists / tap tables
+    whose sample coordinates were recomputed from rois instead of read from the forward's table).
+    knobs: the forward on its fallback kernels (the plan's list pre-pass then runs stand-alone), and a
+    setting under which the tap-table form does not apply (both calls fall back by the same decision)."""
+    import torch
+    from simpledet_amd._lib import lib
+    feats = [_t(f) for f in synth.feature_maps(41, batch=2, channels=channels)]
+    rois = _t(synth.random_rois(42, 2, num))
+    shapes = [f.shape for f in feats]
+    o0, st0 = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, pooled)
+    dy = torch.randn_like(o0)
+    g0 = ops.fpn_roi_align_backward_packed(dy, rois, st0, shapes, STRIDES)
+    for k, v in knobs.items():
+        lib().set_tuning(k, v)
+    try:
+        o1, st1 = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, pooled, plan=True)
+        assert len(st1) == 3
+        g1 = ops.fpn_roi_align_backward_packed(dy, rois, st1, shapes, STRIDES)
+        # the plan is op state: a second backward from the same plan (e.g. gradient accumulation)
+        acc = [torch.ones_like(g) for g in g1]
+        ops.fpn_roi_align_backward_packed(dy, rois, st1, shapes, STRIDES, req_data="add", d_feats=acc)
+    finally:
+        for k in knobs:
+            lib().set_tuning(k, 1)
+    assert torch.equal(o1, o0)
+    assert torch.equal(ops.argmax_codes(st1[0], pooled), ops.argmax_codes(st0[0], pooled))   # (rows are padded)
+    lvl = ops.fpn_roi_assign(rois, STRIDES)[1].reshape(-1) >= 0
+    assert torch.equal(st1[1].reshape(lvl.numel(), -1)[lvl], st0[1].reshape(lvl.numel(), -1)[lvl])
+    same_tables = "roi_align_bwd_lists" not in knobs     # (lists-only mode has other bands: other fixed-point scales)
+    for a, b, c in zip(g1, g0, acc):
+        if same_tables:
+            assert torch.equal(a, b)
+        else:
+            assert float((a - b).abs().max()) <= 1e-4
+        assert float((c - 1 - a).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pooled,num", [((7, 7), 512), ((14, 14), 128)])
 def test_packed_backward_workspace_modes(ops, oracle, pooled, num):
     """The packed backward with the workspace pre-pass (1: per-band RoI lists + tap tables, 27 KB
