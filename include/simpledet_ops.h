@@ -458,6 +458,19 @@ int sd_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, 
                    int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t sd_deform_conv_workspace_bytes(int N, int C, int H, int W, int kh, int kw, int pad,
                                       int stride, int dil);
+/* forward WITHOUT the col matrix: deformable sampling fused into the GEMM's B-operand staging (every
+ * sample taken once, all filters of a pixel tile in one workgroup).  3x3 kernels, C / dgroup % 16 == 0
+ * and H*W % 4 == 0 (every DCN layer of the reference's configs); other shapes run the unfused forward
+ * below through the same call (the workspace size says which: a few MB of pre-split weights against
+ * the N*C*9*Ho*Wo*4-byte col matrix).  Same arithmetic as the unfused path (sampled values bit-equal to
+ * sd_deform_im2col's, products by the scaled fp16 split), another summation order over k.
+ *   replaces DeformableConvolutionOp::Forward (upstream MXNet 1.6 deformable_convolution-inl.h;
+ *   call site models/dcn/builder.py:14-17) */
+size_t sd_deform_conv_fwd_nocol_workspace_bytes(int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                                int stride, int dil, int dgroup);
+int sd_deform_conv_fwd_nocol(const float* x, const float* offset, const float* weight, float* y, int N,
+                             int C, int H, int W, int F, int kh, int kw, int pad, int stride, int dil,
+                             int dgroup, void* workspace, size_t workspace_bytes, void* stream);
 /* forward = im2col + GEMM, num_group = 1, no bias (the reference's configuration) */
 int sd_deform_conv_fwd(const float* x, const float* offset, const float* weight, float* y, int N,
                        int C, int H, int W, int F, int kh, int kw, int pad, int stride, int dil,

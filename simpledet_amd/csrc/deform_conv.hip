@@ -20,6 +20,7 @@
 #include "common.h"
 #include "../../include/simpledet_ops.h"
 #include <math.h>
+#include <type_traits>
 
 namespace sd {
 
@@ -1362,6 +1363,468 @@ static void launch_absmax(const float* p, long rows, int cols, long ld, long bst
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, rows, cols, ld, bstride, batch, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused forward: y = W . col(x, offset) WITHOUT the col matrix (round 4).
+//   The unfused forward writes col (620 MB for the (16,256,50,84) layer) and reads it back: ~12x the
+//   bytes of x + offset + W + y.  Here a workgroup owns (image, tile of <= 96 output pixels) and ALL
+//   F <= 256 filters, so every deformable sample is taken exactly once:
+//     K order   k' = (half-slab of 8 channels, tap, channel): one k16 matrix-core step = two
+//               consecutive (half-slab, tap) units, i.e. 9 steps per 16 channels.  A half-slab lies
+//               inside one deformable group (C / dgroup % 16 == 0), so a unit's sampling state is ONE
+//               packed corner index + four bilinear weights per pixel, computed once per (tile, group)
+//               and kept in LDS (9 taps x 5 words per producer lane): the step loop is not unrolled
+//               by tap, and the per-step cost is five ds_read_b32
+//     x         the window of a half-slab's 8 channel planes that the tile's samples touch, in LDS;
+//               two half-slab buffers form a ring: a buffer is refilled as soon as its last unit has
+//               been sampled, four steps before its next use, by the FOURTH WAVE (which has no
+//               sampling work) through its registers -- loads at the top of a step, LDS stores at its
+//               end.  (global_load_lds fills would sit in front of every wave's A loads in the
+//               in-order vmcnt queue with a count the compiler cannot know: a full drain per step.)
+//     B tile    96 pixels x 16 k of one step: lanes 0..191 own (pixel, unit of the step), take the
+//               corners from LDS, interpolate in fp32 with the im2col expression (the sampled values
+//               are bit-equal to sd_deform_im2col's), scale + split into fp16 hi / lo and store two
+//               16-byte granules; double-buffered, ONE workgroup barrier per step; the sampling of
+//               step s + 1 is issued under the matrix-core ops of step s
+//     A tile    the weights, pre-split once per call by dcn_prep_weight_kernel into the per-lane
+//               fragment order of v_mfma_f32_32x32x16_f16; each wave loads its own 64 filter rows
+//               straight from L2 into registers (no LDS, no VALU), two steps ahead
+//     MFMA      4 waves x (64 filters x 96 pixels) = 2 x 3 accumulators of 32x32, three fp16 terms
+//               per product (the scaled hi / lo split of the GEMM above)
+//   Tiles per image are chosen so that the launch is a whole number of rounds of the 256 CUs
+//   (one 256-thread workgroup per CU: the x windows take most of the LDS); tile t of image n runs on
+//   XCD n % 8, so an image's planes are fetched into one L2.
+//   A tile whose windows do not fit (wild offsets: 8 planes x window > 70 KB) flags itself and is
+//   redone by the LDSX = false instance of the kernel, which takes its corners from global memory --
+//   slow, but exact, and launched over the flagged tiles only.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kFN = 96;            // pixel slots of a tile (3 x 32)
+constexpr int kFHalf = 8;          // channels per half-slab
+constexpr int kFThreads = 512;    // 4 matrix-core waves + 3 sampling waves + 1 loader wave
+constexpr int kFBBytes = 2 * 2 * kFN * 16 * 2;   // B tile: 2 buffers x (hi, lo) x 96 x 16 halves = 12 KB
+constexpr int kFStateBytes = 9 * 5 * 2 * kFN * 4;   // sampling state of 192 producer lanes x 9 taps x 5 words = 34.6 KB
+constexpr int kFXFloats = 28160;   // 110 KB of x windows: two half-slab buffers
+constexpr int kFStage = 16;        // 16-byte words per lane the loader wave moves per step (two channel windows)
+constexpr int kFSmemBytes = kFBBytes + kFStateBytes + kFXFloats * 4 + 64 + 64;
+
+struct DcnFusedArgs {
+  const float* x;
+  const float* offset;
+  const uint4* apre;     // pre-split weights, fragment order (dcn_prep_weight_kernel)
+  float* y;
+  DcnGeom g;
+  int F, mtiles, nslab, tiles_per_image, tile_w;
+  const unsigned* amax;  // {max|W|, max|x|}
+  int x_aligned;         // x is 16-byte aligned (16-byte window loads); else every tile takes the global path
+  int* flags;            // [tile] 1: left to the LDSX = false instance
+  int ablate;            // profiling build only: 1 no sampling, 2 no matrix-core ops, 4 no window loads, 8 no B reads
+};
+
+// weights (F, C, 9) -> apre[mt][slab16][j][wave][i][plane][lane] (16 bytes each): lane l of fragment
+// (wave, i) holds filter row mt*256 + wave*64 + i*32 + (l & 31) and the 8 k values of unit
+// u = 2 j + (l >> 5) of the slab: half-slab u / 9, tap u % 9, channels slab16*16 + (u / 9)*8 .. +7
+__global__ __launch_bounds__(256) void dcn_prep_weight_kernel(const float* __restrict__ w, uint4* __restrict__ apre,
+                                                              int F, int C, int mtiles, int nslab,
+                                                              const unsigned* amax) {
+  const long total = (long)mtiles * nslab * 9 * 4 * 2 * 64;   // (hi, lo) pairs
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  long r = e >> 6;
+  const int i = (int)(r & 1); r >>= 1;
+  const int wave = (int)(r & 3); r >>= 2;
+  const int j = (int)(r % 9); r /= 9;
+  const int slab = (int)(r % nslab);
+  const int mt = (int)(r / nslab);
+  const int f = mt * 256 + wave * 64 + i * 32 + (lane & 31);
+  const int u = 2 * j + (lane >> 5), tap = u % 9;
+  const int c0 = slab * 16 + (u / 9) * kFHalf;
+  float s, inv;
+  f16_split_scale(amax[0], s, inv);
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (f < F && c0 + k < C) ? w[((long)f * C + c0 + k) * 9 + tap] : 0.f;
+  uint4 h, l;
+  split2<true, kSplitF16>(v[0], v[1], s, h.x, l.x);
+  split2<true, kSplitF16>(v[2], v[3], s, h.y, l.y);
+  split2<true, kSplitF16>(v[4], v[5], s, h.z, l.z);
+  split2<true, kSplitF16>(v[6], v[7], s, h.w, l.w);
+  const long base = ((((long)(mt * nslab + slab) * 9 + j) * 4 + wave) * 2 + i) * 2 * 64;
+  apre[base + lane] = h;
+  apre[base + 64 + lane] = l;
+}
+
+// dense copy of n4 16-byte words into LDS (destination = wave-uniform base + lane * 16)
+__device__ __forceinline__ void dcn_fill16(const float* gsrc, int n4, float* dst, int wave, int lane) {
+  const float4* s4 = reinterpret_cast<const float4*>(gsrc);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int w4 = wave * 64; w4 < n4; w4 += (kFThreads / 64) * 64) {
+    const int i = w4 + lane;
+    if (i < n4) __builtin_amdgcn_global_load_lds(s4 + i, d4 + w4, 16, 0, 0);
+  }
+}
+
+// workgroup barrier for LDS hand-overs only: waits for this wave's LDS traffic, NOT for its global
+// loads (__syncthreads() carries a fence that drains vmcnt, i.e. every prefetch in flight)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool LDSX>
+__global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char fsm[];
+  char* Bs = fsm;
+  float* sst = reinterpret_cast<float*>(fsm + kFBBytes);                 // sampling state [tap][word][producer lane]
+  float* xs = reinterpret_cast<float*>(fsm + kFBBytes + kFStateBytes);   // two half-slab window buffers
+  int* rng = reinterpret_cast<int*>(fsm + kFBBytes + kFStateBytes + kFXFloats * 4);
+  float* dummy = reinterpret_cast<float*>(fsm + kFBBytes + kFStateBytes + kFXFloats * 4 + 64);   // 16 bytes
+  const DcnGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = g.Ho * g.Wo, plane = g.H * g.W;
+  // block -> (filter tile, image, pixel tile); the tiles of image n run on XCD n % 8
+  const int per_mt = (int)gridDim.x / a.mtiles;
+  const int mt = (int)blockIdx.x / per_mt, bb = (int)blockIdx.x % per_mt;
+  const int xcd = bb & 7, slot = bb >> 3;
+  const int n = (slot / a.tiles_per_image) * 8 + xcd, t = slot % a.tiles_per_image;
+  if (n >= g.N) return;
+  const int p0 = t * a.tile_w, p1 = iminr(p0 + a.tile_w, P);
+  if (p0 >= P) return;
+  int* flag = a.flags + ((long)mt * g.N + n) * a.tiles_per_image + t;
+  if (!LDSX && *flag == 0) return;   // (the LDS instance has done this tile)
+  const int cpg = g.C / g.dgroup;
+
+  // ---- roles: waves 0..3 matrix cores (64 filter rows each), waves 4..6 sampling (192 lanes =
+  // (pixel, unit of the step)), wave 7 the x windows.  One wave of the first kind and one of the
+  // others share a SIMD: its matrix pipe and its vector ALU / LDS ports work side by side ----
+  const int ptid = tid - 4 * 64;
+  const bool producer = ptid >= 0 && ptid < 2 * kFN;
+  const int pl = producer ? ptid % kFN : 0, half = producer ? ptid / kFN : 0;
+  const int p = p0 + pl;
+  const bool live = producer && p < p1;
+  const int h_col = live ? p / g.Wo : 0, w_col = live ? p % g.Wo : 0;
+  const int h_in = h_col * g.stride_h - g.pad_h, w_in = w_col * g.stride_w - g.pad_w;
+
+  float sa, sb, inva, invb;
+  f16_split_scale(a.amax[0], sa, inva);
+  f16_split_scale(a.amax[1], sb, invb);
+
+  const uint4* abase = a.apre + (long)mt * a.nslab * 9 * 1024 + (wave & 3) * 256 + lane;   // + step * 1024
+  const int nsteps = a.nslab * 9;
+  char* const bwr = Bs + half * (kFN * 16) + pl * 16;                          // this lane's B granule (hi)
+  const char* const brd = Bs + (lane >> 5) * (kFN * 16) + (lane & 31) * 16;    // this lane's fragment rows
+  const int nh = cpg / kFHalf, npair = nh / 2;   // half-slabs / 16-channel slabs of a group
+  const int S = npair * 9;                       // steps of a group
+  // Every workgroup walks the same k range, but starts somewhere else in it (group rot_g, then pair
+  // rot_p of every group, wrapping around): 256 CUs reading the SAME 16 KB of pre-split weights in
+  // the same step hammer a handful of L2 channels -- the A loads then take ~2000 clocks each
+  // (measured: staggering the walk per workgroup lets the tiles of an image touch all of its channel
+  // planes at once -- the image no longer fits its XCD's L2 and sigma = 2 offsets run 1.6x slower; off)
+  const int rot_g = 0, rot_p = 0;
+  auto grp_of = [&](int gi) { int v = gi + rot_g; return v >= g.dgroup ? v - g.dgroup : v; };
+  auto pair_of = [&](int k) { int v = k + rot_p; return v >= npair ? v - npair : v; };   // k-th pair of the walk
+
+  // ---- per group, every wave (same barriers in every role): the sampling state of the 9 taps into
+  // LDS, the window the samples touch, the first two half-slabs.  false: the windows do not fit ----
+  struct Grp { int wstart, wstride, n4; const float* xg; };
+  auto group_begin = [&](int grp, Grp& G) -> bool {
+    int wstart = 0, wcount = 0;
+    {
+      int info[kDcnMaxTaps];
+      float w1[kDcnMaxTaps], w2[kDcnMaxTaps], w3[kDcnMaxTaps], w4[kDcnMaxTaps];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        info[tap] = 0;
+        w1[tap] = w2[tap] = w3[tap] = w4[tap] = 0.f;
+      }
+      if (producer) {
+        const float* off = a.offset + ((long)n * g.dgroup + grp) * 18 * P + (live ? p : 0);
+        float oh[kDcnMaxTaps], ow[kDcnMaxTaps];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          oh[tap] = off[(long)(2 * tap) * P];
+          ow[tap] = off[(long)(2 * tap + 1) * P];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const Sample s = im2col_sample(g, h_in, w_in, tap / g.kw, tap % g.kw, oh[tap], ow[tap]);
+          info[tap] = dcn_pack(s.ok && live, s.h_low, s.w_low, s.h_high, s.w_high, g.W);
+          w1[tap] = s.w1; w2[tap] = s.w2; w3[tap] = s.w3; w4[tap] = s.w4;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();   // (the previous group's last step is done with the B buffers, windows, state)
+      {
+        // the contiguous float range [first corner, last corner] over all inside taps of all lanes
+        // (dcn_window's range, but reduced inside the wave first: a few hundred same-address LDS
+        // atomics serialise), rebased to a multiple of four floats
+        if (tid == 0) {
+          rng[0] = 0x7fffffff;
+          rng[1] = -1;
+        }
+        int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int in = info[tap];
+          if (in & kDcnInside) {
+            const int o1 = in & 0xfffffff;
+            lo = iminr(lo, o1);
+            hi = imaxr(hi, o1 + (((in >> 29) & 1) ? g.W : 0) + ((in >> 28) & 1));
+          }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          lo = iminr(lo, __shfl_xor(lo, o));
+          hi = imaxr(hi, __shfl_xor(hi, o));
+        }
+        __syncthreads();
+        if (lane == 0 && hi >= 0) {
+          atomicMin(&rng[0], lo);
+          atomicMax(&rng[1], hi);
+        }
+        __syncthreads();
+        lo = rng[0];
+        hi = rng[1];
+        if (hi >= 0) {
+          wstart = lo & ~3;
+          wcount = iminr((hi + 4) & ~3, plane) - wstart;
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+            if (info[tap] & kDcnInside) info[tap] -= wstart;
+        }
+      }
+      if (producer) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          float* d = sst + tap * 5 * (2 * kFN) + ptid;
+          d[0] = __int_as_float(info[tap]);
+          d[2 * kFN] = w1[tap]; d[2 * 2 * kFN] = w2[tap]; d[3 * 2 * kFN] = w3[tap]; d[4 * 2 * kFN] = w4[tap];
+        }
+      }
+    }
+    // floats between the channel windows in LDS: the second corner row of a sample may start W past
+    // the first whatever the clamping, + 1 for the pair: a window is followed by W + 4 floats of slack
+    G.wstart = wstart;
+    G.wstride = (wcount + g.W + 4 + 3) & ~3;
+    G.n4 = wcount >> 2;
+    G.xg = a.x + ((long)n * g.C + (long)grp * cpg) * plane;   // channel 0 of the group
+    if (LDSX) {
+      // windows that do not fit two half-slab buffers, more words than the loader wave moves per
+      // step, or a misaligned x: the tile is left to the global-gather instance
+      const bool fits = a.x_aligned && 2 * kFHalf * G.wstride <= kFXFloats && 2 * G.n4 <= 64 * kFStage;
+      if (!fits) {
+        if (tid == 0) *flag = 1;
+        return false;
+      }
+      if (grp == 0 && tid == 0) *flag = 0;
+      if (G.n4 > 0) {
+        // the first two half-slabs: dense global_load_lds by everybody, once per group
+        for (int c = 0; c < 2 * kFHalf; ++c)
+          dcn_fill16(G.xg + (long)(pair_of(0) * 2 * kFHalf + c) * plane + wstart, G.n4, xs + c * G.wstride, wave, lane);
+      }
+    }
+    // the windows and the state landed (every wave waits for its own fill loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    return true;
+  };
+
+  if (wave < 4) {
+    // ================= matrix-core waves: acc += A(step) . B(step) ====================================
+    floatx16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    uint4 acur[4], anxt[4];
+    auto load_a = [&](uint4 (&dst)[4], int grp, int k, int j) {   // A of step j of the k-th pair of the walk
+      if (j >= 9) { j -= 9; ++k; }
+      const int kk = k < npair ? k : npair - 1;   // (past the group's end: prefetched in vain, no branch)
+      const uint4* q = abase + (long)((grp * npair + pair_of(kk)) * 9 + j) * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = q[i * 64];
+    };
+    for (int gi = 0; gi < g.dgroup; ++gi) {
+      const int grp = grp_of(gi);
+      Grp G;
+      if (!group_begin(grp, G)) return;
+      load_a(anxt, grp, 0, 0);
+      lds_barrier();   // (the producers' B(0))
+      int k = 0, j = 0;
+      for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acur[i] = anxt[i];
+#ifdef SD_PROFILING
+        if (!(a.ablate & 8))
+#endif
+        load_a(anxt, grp, k, j + 1);
+        const char* bb_ = brd + (s & 1) * (kFBBytes / 2);
+        uint4 bh[3], bl[3];
+#ifdef SD_PROFILING
+        if (a.ablate & 16) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bh[q] = bl[q] = acur[q];
+        } else
+#endif
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          bh[q] = *reinterpret_cast<const uint4*>(bb_ + q * 512);
+          bl[q] = *reinterpret_cast<const uint4*>(bb_ + kFN * 32 + q * 512);
+        }
+#ifdef SD_PROFILING
+        if (!(a.ablate & 2))
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            acc[i][q] = mfma16<kSplitF16>(acur[2 * i + 1], bh[q], acc[i][q]);   // a_lo * b_hi
+            acc[i][q] = mfma16<kSplitF16>(acur[2 * i], bl[q], acc[i][q]);       // a_hi * b_lo
+            acc[i][q] = mfma16<kSplitF16>(acur[2 * i], bh[q], acc[i][q]);       // a_hi * b_hi
+          }
+        if (s + 1 < S) lds_barrier();
+        if (++j == 9) { j = 0; ++k; }
+      }
+    }
+    // ---- y[n, f, p] = acc / (s_w s_x): D layout of a 32x32 tile: element e of lane l -> row
+    // (e / 4) * 8 + (l / 32) * 4 + e % 4, column l % 32 ----
+    float* yn = a.y + (long)n * a.F * P;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int pp = p0 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int f = mt * 256 + wave * 64 + i * 32 + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3);
+          if (f < a.F && pp < p1) yn[(long)f * P + pp] = (acc[i][j][e] * inva) * invb;
+        }
+      }
+  } else if (wave < 7) {
+    // ================= sampling waves: B(s + 1) while the matrix cores work on B(s) ===================
+    for (int gi = 0; gi < g.dgroup; ++gi) {
+      const int grp = grp_of(gi);
+      Grp G;
+      if (!group_begin(grp, G)) return;
+      const int wstride = G.wstride, wstart = G.wstart;
+      const float* xg = G.xg;
+      // unit u = 2 j + half of the pair's step j: half-slab (= window buffer) u / 9, tap u % 9
+      auto produce = [&](int pair, int j, int step) {   // pair: the actual pair (global path only), step: B parity
+        const int u = 2 * j + half, hl = u >= 9 ? 1 : 0, tap = u - 9 * hl;
+        const float* sp = sst + tap * 5 * (2 * kFN) + ptid;
+        const int tin = __float_as_int(sp[0]);
+        const float a1 = sp[2 * kFN], a2 = sp[2 * 2 * kFN], a3 = sp[3 * 2 * kFN], a4 = sp[4 * 2 * kFN];
+        const bool inside = (tin & kDcnInside) != 0;
+        const int o1 = tin & 0xfffffff;
+        const bool dw = (tin >> 28) & 1;
+        const int o2 = o1 + (((tin >> 29) & 1) ? g.W : 0);   // second corner row (the first again when clamped)
+        float va[8], vb[8], vc[8], vd[8];
+        if (LDSX) {
+          const float* xw = xs + hl * kFHalf * wstride;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {   // all sixteen pair reads go out before the arithmetic
+            va[c] = xw[c * wstride + o1]; vb[c] = xw[c * wstride + o1 + 1];
+            vc[c] = xw[c * wstride + o2]; vd[c] = xw[c * wstride + o2 + 1];
+          }
+        } else {
+          // corners straight from global memory, every address inside the plane (window-relative
+          // index made absolute, no "+ 1" past a clamp)
+          const float* xc = xg + (long)((2 * pair + hl) * kFHalf) * plane;
+          const int g1 = inside ? o1 + wstart : 0, g2 = inside ? o2 + wstart : 0, d1 = dw ? 1 : 0;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            va[c] = xc[(long)c * plane + g1]; vb[c] = xc[(long)c * plane + g1 + d1];
+            vc[c] = xc[(long)c * plane + g2]; vd[c] = xc[(long)c * plane + g2 + d1];
+          }
+        }
+        uint4 h4, l4;
+        unsigned* hp = reinterpret_cast<unsigned*>(&h4);
+        unsigned* lp = reinterpret_cast<unsigned*>(&l4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int c = 2 * q + k;
+            const float x2 = dw ? vb[c] : va[c], x4 = dw ? vd[c] : vc[c];
+            const float r = (a1 * va[c] + a2 * x2 + a3 * vc[c] + a4 * x4);   // the im2col expression
+            v[k] = inside ? r : 0.f;
+          }
+          split2<true, kSplitF16>(v[0], v[1], sb, hp[q], lp[q]);
+        }
+        char* bd = bwr + (step & 1) * (kFBBytes / 2);
+        *reinterpret_cast<uint4*>(bd) = h4;
+        *reinterpret_cast<uint4*>(bd + kFN * 32) = l4;
+      };
+      produce(pair_of(0), 0, 0);
+      lds_barrier();
+      int k = 0, j = 0;
+      for (int s = 0; s + 1 < S; ++s) {
+        if (++j == 9) { j = 0; ++k; }
+#ifdef SD_PROFILING
+        if (!(a.ablate & 1))
+#endif
+        produce(pair_of(k), j, s + 1);
+        lds_barrier();
+      }
+    }
+  } else {
+    // ================= loader wave: the ring of half-slab windows =====================================
+    // One piece = two channel windows per step, loaded into registers in step s and stored to LDS
+    // at the top of step s + 1 (a whole step hides the load latency; the step barrier never waits
+    // for memory).  Buffer 0 is last sampled for step j = 4 of a pair (under step 3): half-slab
+    // 2 pair + 2 is loaded in steps 3..6 and stored in steps 4..7, in time for the sampling of the
+    // next pair's step 0 (under step 8).  Buffer 1 is last sampled under step 7: the pieces of the
+    // half-slab after next are loaded in steps 7, 8 and the next pair's 0, 1, stored one step later
+    // each, in time for the sampling of that pair's step 4 (under its step 3).
+    for (int gi = 0; gi < g.dgroup; ++gi) {
+      const int grp = grp_of(gi);
+      Grp G;
+      if (!group_begin(grp, G)) return;
+      const int wstride = G.wstride, n4 = G.n4, nw = 2 * G.n4;
+      lds_barrier();   // (the producers' B(0))
+      int pair = 0, j = 0;
+      u32x4 stg[kFStage];
+      float* pend = nullptr;   // where the piece in flight goes (null: none)
+      for (int s = 0; s < S; ++s) {
+        if (pend) {
+#pragma unroll
+          for (int k = 0; k < kFStage; ++k) {   // (lanes past the end rewrite the last word with the same data)
+            int i = lane + 64 * k;
+            i = i < nw ? i : nw - 1;
+            const int cc = i >= n4 ? 1 : 0, idx = i - cc * n4;
+            *reinterpret_cast<u32x4*>(pend + cc * wstride + 4 * idx) = stg[k];
+          }
+          pend = nullptr;
+        }
+        // (pair = position in the walk; lh = position of the half-slab in the walk, -1: nothing to load)
+        int lh = -1, piece = 0, lbuf = 0;
+        if (j >= 3 && j <= 6) { lh = 2 * pair + 2; piece = j - 3; lbuf = 0; }
+        else if (j >= 7) { lh = 2 * pair + 3; piece = j - 7; lbuf = 1; }
+        else if (j <= 1 && pair > 0) { lh = 2 * pair + 1; piece = j + 2; lbuf = 1; }
+#ifdef SD_PROFILING
+        if (a.ablate & 4) lh = -1;
+#endif
+        if (LDSX && lh >= 0 && lh < nh && n4 > 0) {
+          const float* src = G.xg + (long)((2 * pair_of(lh >> 1) + (lh & 1)) * kFHalf + 2 * piece) * plane + G.wstart;
+          pend = xs + (lbuf * kFHalf + 2 * piece) * wstride;
+#pragma unroll
+          for (int k = 0; k < kFStage; ++k) {
+            int i = lane + 64 * k;
+            i = i < nw ? i : nw - 1;
+            const int cc = i >= n4 ? 1 : 0, idx = i - cc * n4;
+            stg[k] = *reinterpret_cast<const u32x4*>(src + (long)cc * plane + 4 * idx);
+          }
+        }
+        if (s + 1 < S) lds_barrier();
+        if (++j == 9) { j = 0; ++pair; }
+      }
+    }
+  }
+}
+
 static int make_geom(DcnGeom& g, int N, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
                      int stride_h, int stride_w, int dil_h, int dil_w, int dgroup) {
   SD_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0, "bad input dimensions");
@@ -1599,6 +2062,87 @@ extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const flo
   // y[n] (F x P) = W (F x K) . col[n] (K x P)
   return gemm_f32_impl(0, 0, F, P, K, weight, K, 0, col, P, (long)K * P, y, P, (long)F * P, N, 0, amax,
                        stream);
+}
+
+// ---- forward without a col matrix (fused sampling + GEMM) ----------------------------------------
+static bool dcn_fused_shape_ok(int C, int H, int W, int kh, int kw, int dgroup) {
+  return kh * kw == 9 && dgroup > 0 && C % dgroup == 0 && (C / dgroup) % 16 == 0 && ((long)H * W) % 4 == 0 &&
+         (long)H * W < (1L << 28) && W + 16 < kFXFloats / 16 && tuning("dcn_fused", 1) == 1;
+}
+
+extern "C" size_t sd_deform_conv_fwd_nocol_workspace_bytes(int N, int C, int H, int W, int F, int kh, int kw,
+                                                           int pad, int stride, int dil, int dgroup) {
+  if (N <= 0 || C <= 0 || F <= 0) return 256;
+  if (!dcn_fused_shape_ok(C, H, W, kh, kw, dgroup))
+    return sd_deform_conv_workspace_bytes(N, C, H, W, kh, kw, pad, stride, dil);
+  const size_t mtiles = (F + 255) / 256, nslab = C / 16;
+  const size_t P = (size_t)((H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1) * ((W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1);
+  // the pre-split weights + the operand maxima + one flag per tile (at most one tile per pixel)
+  return mtiles * nslab * 9 * 1024 * sizeof(uint4) + 512 + mtiles * (size_t)N * P * sizeof(int);
+}
+
+extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, const float* weight, float* y,
+                                        int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                        int stride, int dil, int dgroup, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  DcnGeom g;
+  if (int e = make_geom(g, N, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dgroup)) return e;
+  SD_REQUIRE(F > 0, "num_filter must be positive");
+  if (N == 0) return SD_OK;
+  SD_REQUIRE(x && offset && weight && y, "null tensor pointer");
+  if (!dcn_fused_shape_ok(C, H, W, kh, kw, dgroup))
+    return sd_deform_conv_fwd(x, offset, weight, y, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup, workspace,
+                              workspace_bytes, stream);
+  const size_t need = sd_deform_conv_fwd_nocol_workspace_bytes(N, C, H, W, F, kh, kw, pad, stride, dil, dgroup);
+  if (!workspace || workspace_bytes < need)
+    return fail(SD_ERR_WORKSPACE, "DeformableConvolution (fused forward) workspace too small: %zu < %zu bytes",
+                workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const int mtiles = (F + 255) / 256, nslab = C / 16, P = g.Ho * g.Wo;
+  uint4* apre = reinterpret_cast<uint4*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const size_t apre_words = (size_t)mtiles * nslab * 9 * 1024;
+  unsigned* amax = reinterpret_cast<unsigned*>(apre + apre_words);   // {max|W|, max|x|}
+  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
+  launch_absmax(weight, 1, F * C * 9, F * C * 9, 0, 1, amax, st);
+  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 1, st);
+  {
+    const long total = (long)apre_words / 2;   // one thread per (hi, lo) pair
+    hipLaunchKernelGGL(dcn_prep_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight,
+                       apre, F, C, mtiles, nslab, amax);
+  }
+  DcnFusedArgs a{};
+  a.x = x; a.offset = offset; a.apre = apre; a.y = y; a.g = g; a.F = F; a.mtiles = mtiles; a.nslab = nslab;
+  a.amax = amax;
+  a.x_aligned = ((uintptr_t)x & 15) == 0;
+  // tiles per image: enough for <= 96 pixels each, then as many more as keeps the launch at the same
+  // whole number of rounds of the CUs (one workgroup per CU): equal tiles instead of a ragged last round
+  int T = cdiv(P, kFN);
+  const long total0 = (long)N * T * mtiles;
+  const long rounds = (total0 + kNumCU - 1) / kNumCU;
+  const long fit = rounds * kNumCU / ((long)N * mtiles);
+  if (fit > T) T = (int)(fit < P ? fit : P);
+  a.tile_w = cdiv(P, T);
+  const int tw = tuning("dcn_fused_tile", 0);
+  if (tw >= 1 && tw <= kFN) a.tile_w = tw;
+  a.tiles_per_image = cdiv(P, a.tile_w);
+  SD_REQUIRE((long)a.tiles_per_image * 8 * cdiv(N, 8) * mtiles < (1L << 31), "too many tiles");
+  a.flags = reinterpret_cast<int*>(amax + 64);   // (behind the maxima: 256 bytes into the 512 of slack)
+  a.ablate = SD_PROF_TUNING("dcn_fused_ablate", 0);
+  static bool attr = false;
+  if (!attr) {
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)dcn_fwd_fused_kernel<true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFSmemBytes));
+    SD_HIP_CHECK(hipFuncSetAttribute((const void*)dcn_fwd_fused_kernel<false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFSmemBytes));
+    attr = true;
+  }
+  const dim3 grid((unsigned)(a.tiles_per_image * 8 * cdiv(N, 8) * mtiles));
+  hipLaunchKernelGGL(dcn_fwd_fused_kernel<true>, grid, dim3(kFThreads), kFSmemBytes, st, a);
+  // tiles whose windows did not fit LDS (wild offsets) flagged themselves: the global-gather instance
+  // redoes exactly those (every other block returns at once)
+  hipLaunchKernelGGL(dcn_fwd_fused_kernel<false>, grid, dim3(kFThreads), kFSmemBytes, st, a);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
 }
 
 // `fwd_col`: the col matrix a forward of the same (x, offset) left in ITS workspace

@@ -65,7 +65,7 @@ Knob g_knobs[] = {
     {"proposal_topk", 0, false},         // 0 by level size (default), 1 single workgroup, 2 multi-workgroup
     {"top_proposal_select", 0, false},   // 1 radix select before the sort when top_n < N (default)
     {"soft_nms_threads", 0, false},      // threads per problem: 64, 128 or 256 (default)
-    {"deform_gemm_split", 0, false}, // 1 (default): fp32 products as three bf16 MFMA terms (hi/lo split); 0: fp32 MFMA
+    {"deform_gemm_split", 0, false}, // 2 (default): scaled fp16 hi/lo split (needs operand maxima); 1: bf16 hi/lo split; 0: fp32 MFMA
     {"deform_gemm_ksplit", 0, false},// 1 (default): tiles of a mostly empty last round are cut into k slices (atomic adds)
     {"deform_gemm_bk", 0, false},    // K extent of a GEMM tile: 16 (default) or 32
     {"deform_gemm_j", 0, false},     // GEMM tile width 64*J (1..3), 0 = by wave quantisation (default)
@@ -75,6 +75,9 @@ Knob g_knobs[] = {
     {"dcn_window", 0, false},        // 1 stage only the touched range of each plane (default)
     {"dcn_col2im", 0, false},        // 1 four channels per workgroup, shared sample geometry (default), 0 one channel
     {"dcn_coord", 0, false},         // 1 LDS-plane offset gradient (default), 0 per-lane gathers
+    {"dcn_fused", 0, false},         // 1 (default): the col-free entry points sample inside the GEMM; 0: im2col + GEMM
+    {"dcn_fused_ablate", 0, false},  // profiling build only: parts of the fused kernels switched off
+    {"dcn_fused_tile", 0, false},    // pixels per tile of the fused kernels (1..96), 0 = balanced over the CUs (default)
 };
 }  // namespace
 

@@ -627,13 +627,28 @@ def _build_ops(mx):
             _wait(x, off, w)
             g = self.g
             N, C, H, W = x.shape
+            if not (is_train and g["cache_col"]):
+                # no col matrix: deformable sampling fused into the GEMM (a few MB of workspace instead
+                # of N*C*9*Ho*Wo*4 bytes; shapes the fused kernel does not take run im2col + GEMM behind
+                # the same entry point)
+                lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes.restype = ctypes.c_size_t
+                n = int(lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes(
+                    N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"]))
+                ws = _scratch(x, n)
+                lib().call("sd_deform_conv_fwd_nocol", _ptr(x), _ptr(off), _ptr(w), _ptr(out_data[0]), N, C,
+                           H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"],
+                           _ptr(ws), ctypes.c_size_t(n), None)
+                self._fwd_ws = None
+                _sync()
+                return
             ws, n = self._ws(x)
             lib().call("sd_deform_conv_fwd", _ptr(x), _ptr(off), _ptr(w), _ptr(out_data[0]), N, C, H,
                        W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"],
                        _ptr(ws), ctypes.c_size_t(n), None)
-            # training: the col matrix stays alive until this node's backward, which then skips its
-            # own im2col (the reference recomputes it; 288 GB of HBM make keeping it the cheaper side)
-            self._fwd_ws = (ws, tuple(x.shape)) if (is_train and g["cache_col"]) else None
+            # training with cache_col: the col matrix stays alive until this node's backward, which then
+            # skips its own im2col (620 MB per layer at the baseline; cache_col="False" trades it for
+            # the fused col-free forward and a backward that recomputes col)
+            self._fwd_ws = (ws, tuple(x.shape))
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):

@@ -817,10 +817,20 @@ def deform_conv_forward(x, offset, weight, pad=1, stride=1, dilate=1, num_deform
         raise ValueError("offset shape %s != %s" % (tuple(offset.shape),
                                                      (N, num_deformable_group * 2 * kh * kw, Ho, Wo)))
     y = torch.empty((N, F, Ho, Wo), device=x.device, dtype=torch.float32)
+    if not keep_col:
+        # no col matrix: sampling fused into the GEMM (3x3, C / groups % 16 == 0, H*W % 4 == 0); other
+        # shapes run im2col + GEMM behind the same entry point, which its workspace size accounts for
+        lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes.restype = ctypes.c_size_t
+        n = int(lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes(N, C, H, W, F, kh, kw, pad, stride, dilate,
+                                                                    int(num_deformable_group)))
+        ws = torch.empty(n, device=x.device, dtype=torch.uint8)
+        lib().call("sd_deform_conv_fwd_nocol", _p(x), _p(offset), _p(weight), _p(y), N, C, H, W, F, kh, kw,
+                   pad, stride, dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
+        return y
     ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
     lib().call("sd_deform_conv_fwd", _p(x), _p(offset), _p(weight), _p(y), N, C, H, W, F, kh, kw,
                pad, stride, dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
-    return (y, ws) if keep_col else y
+    return y, ws
 
 
 def deform_conv_backward(out_grad, x, offset, weight, pad=1, stride=1, dilate=1,

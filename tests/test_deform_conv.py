@@ -370,6 +370,55 @@ def test_deform_conv_layer_holds_the_absolute_bar_on_every_image(ops, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, C=64, H=12, W=16, F=24, dg=4),                      # 16 channels per group: one slab each
+    dict(N=3, C=64, H=20, W=24, F=70, dg=2, off_scale=3.0),       # 2 slabs per group, F not a multiple of 32
+    dict(N=9, C=32, H=12, W=16, F=8, dg=2),                       # more images than XCDs, N % 8 != 0
+    dict(N=1, C=64, H=25, W=44, F=300, dg=4, off_scale=2.0),      # two filter tiles (F > 256)
+    dict(N=2, C=64, H=20, W=24, F=32, dg=4, off_scale=40.0),      # wild offsets: most samples outside
+    dict(N=2, C=64, H=20, W=24, F=32, dg=4, off_scale=0.0),       # zero offsets: an ordinary convolution
+    dict(N=2, C=32, H=16, W=20, F=16, dg=2, stride=2),
+    dict(N=2, C=32, H=12, W=16, F=16, dg=2, pad=2, dil=2),
+    dict(N=1, C=64, H=100, W=168, F=16, dg=4, off_scale=30.0),    # windows too large for LDS: corners from global
+    dict(N=2, C=256, H=50, W=84, F=256, dg=4, off_scale=2.0),     # the layer of models/dcn/builder.py:14-17
+])
+def test_fused_forward_without_col_matrix(ops, oracle, cfg):
+    """sd_deform_conv_fwd_nocol (sampling fused into the GEMM, no col matrix) against the unfused
+    forward and the oracle: every image, absolute bar.  Also with tiles of a forced width (partial
+    last tiles, one-pixel tiles) and with the fusion switched off behind the same entry point."""
+    import torch
+    from simpledet_amd._lib import lib
+    x, off, w, kw = _case(51, **cfg)
+    if cfg.get("C", 8) >= 256:
+        w *= 0.25
+    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
+    tx, to, tw = _t(x), _t(off), _t(w)
+    y = ops.deform_conv_forward(tx, to, tw, **a)                       # fused
+    y_unf, _ = ops.deform_conv_forward(tx, to, tw, keep_col=True, **a)   # im2col + GEMM
+    F, K = w.shape[0], w[0].size
+    wm = w.reshape(F, K).astype(np.float64)
+    yn = y.cpu().numpy()
+    for n in range(x.shape[0]):
+        col = oracle.deform_im2col(x[n], off[n], **kw).astype(np.float64)
+        want = (wm @ col).reshape(yn[n].shape)
+        assert float(np.abs(yn[n] - want).max()) <= _bar(want), (n, float(np.abs(yn[n] - want).max()))
+    assert float((y - y_unf).abs().max()) <= _bar(y_unf.cpu().numpy())
+    for tile in (96, 37, 1) if x.shape[2] * x.shape[3] <= 600 else (64,):
+        lib().set_tuning("dcn_fused_tile", tile)
+        try:
+            yt = ops.deform_conv_forward(tx, to, tw, **a)
+        finally:
+            lib().set_tuning("dcn_fused_tile", 0)
+        assert float((yt - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())), tile
+    lib().set_tuning("dcn_fused", 0)
+    try:
+        y0 = ops.deform_conv_forward(tx, to, tw, **a)
+    finally:
+        lib().set_tuning("dcn_fused", 1)
+    assert torch.equal(y0, y_unf)
+
+
+@pytest.mark.gpu
 def test_backward_with_the_forward_col_matrix(ops):
     """sd_deform_conv_bwd_cached: the col matrix left in the forward's workspace replaces the
     backward's own im2col -- same bits for d_offset (a per-lane reduction), d_data and d_weight up
