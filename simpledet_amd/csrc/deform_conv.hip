@@ -1336,7 +1336,19 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
   if (dense) {
     const long n4 = n >> 2;
     const uint4* p4 = reinterpret_cast<const uint4*>(p);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // four independent 16-byte loads in flight per lane (one dependent chain per lane runs at a
+    // quarter of the HBM rate: 55 us for the 69 MB of x)
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      const uint4 v0 = p4[i], v1 = p4[i + stride], v2 = p4[i + 2 * stride], v3 = p4[i + 3 * stride];
+      const unsigned a = max(max(v0.x & 0x7fffffffu, v0.y & 0x7fffffffu), max(v0.z & 0x7fffffffu, v0.w & 0x7fffffffu));
+      const unsigned b = max(max(v1.x & 0x7fffffffu, v1.y & 0x7fffffffu), max(v1.z & 0x7fffffffu, v1.w & 0x7fffffffu));
+      const unsigned c = max(max(v2.x & 0x7fffffffu, v2.y & 0x7fffffffu), max(v2.z & 0x7fffffffu, v2.w & 0x7fffffffu));
+      const unsigned d = max(max(v3.x & 0x7fffffffu, v3.y & 0x7fffffffu), max(v3.z & 0x7fffffffu, v3.w & 0x7fffffffu));
+      m = max(m, max(max(a, b), max(c, d)));
+    }
+    for (; i < n4; i += stride) {
       const uint4 v = p4[i];
       m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
     }
@@ -1351,14 +1363,22 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  // one atomic per workgroup: thousands of same-address atomics cost more than the reads (measured:
+  // 8192 of them 100 us, against 15 us for streaming the 69 MB)
+  __shared__ unsigned wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (m) atomicMax(out, m);
+  }
 }
 
 static void launch_absmax(const float* p, long rows, int cols, long ld, long bstride, int batch, unsigned* out,
                           hipStream_t st) {
   const long n = rows * cols * batch;
   if (n <= 0) return;
-  long blocks = (n + 256 * 16 - 1) / (256 * 16);   // ~16 floats per lane
+  long blocks = (n + 256 * 16 - 1) / (256 * 16);   // >= 16 floats per lane
   if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, rows, cols, ld, bstride, batch, out);
 }

@@ -14,6 +14,6 @@ def t(fn, it=10):
     return e0.elapsed_time(e1) / it
 N, C, H, W, F = 16, 256, 50, 84, 256
 x = torch.randn(N, C, H, W, device="cuda"); off = torch.randn(N, 72, H, W, device="cuda") * 2; wt = torch.randn(F, C, 3, 3, device="cuda") * 0.05
-for ab in (0, 31, 7, 1, 2):
+for ab in (0, 31, 1, 2, 4, 8, 16):
     lib().set_tuning("dcn_fused_ablate", ab)
     print("ablate", ab, "(1 no sampling, 2 no MFMA, 4 no window loads, 8 no A loads, 16 no B reads): %.3f ms" % t(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)))
