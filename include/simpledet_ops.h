@@ -192,6 +192,18 @@ int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float* rois, con
                                    int C, int R, int pooled_h, int pooled_w, float roi_canonical_scale,
                                    float roi_canonical_level, void* workspace, size_t workspace_bytes,
                                    void* stream);
+/* fp16 gradient in, fp16 feature gradients out (the backward of sd_fpn_roi_align_fwd_packed_f16): the
+ * sums are formed exactly as in the fp32 call -- fp32 tap values, fixed-point / fp32 accumulation --
+ * only the two conversions of the graph's to_fp32 / to_fp16 casts (models/FPN/builder.py:581-586,
+ * 607-608) happen inside the kernel: bit-equal to cast -> sd_fpn_roi_align_bwd_packed_ws -> cast with
+ * req (write / add, the sum formed in fp32).  d_feats 8-byte aligned.  SD_ERR_UNSUPPORTED where the
+ * default wide kernel does not apply (callers then use the casts). */
+int sd_fpn_roi_align_bwd_packed_f16(const void* out_grad, const float* rois, const uint8_t* argmax,
+                                    const float* coords, void* const* d_feats_host, const int* Hs_host,
+                                    const int* Ws_host, const int* strides_host, int nlvl, int req_data,
+                                    int B, int C, int R, int pooled_h, int pooled_w,
+                                    float roi_canonical_scale, float roi_canonical_level, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 /* ONE rois-only pre-pass per training step.  Both pre-passes of the fused extractor -- the forward's
  * item lists / tap entries / coordinate table and the backward's band lists / tap tables -- are pure
  * functions of `rois` and the level geometry.  With a `plan` buffer of sd_fpn_roi_align_plan_bytes()

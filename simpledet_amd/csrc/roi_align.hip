@@ -1816,6 +1816,7 @@ struct BwdFusedArgs {
   float* ws_taps;                    // [unit][R][2 * 3 * (PH + PW)] band-relative tap entries, list order
   int unit_base[SD_MAX_FPN_LEVELS];  // first unit of launch-order level li
   int lists_units;                   // (level, image, band) units the list pre-pass covers
+  int half_io;                       // dy and dx are fp16 (packed arg-max, wide kernel only)
 };
 
 template <int PP, int THREADS, bool PK>
@@ -2168,9 +2169,18 @@ __global__ __launch_bounds__(kBandThreads) void roi_prep_merged_kernel(BandArgs 
   else bwd_lists_block<POOL, POOL, kBandThreads, kMergedListSplit>(b, (int)blockIdx.x - nfwd, smem);
 }
 
-template <int PH, int PW, int THREADS, int TCH, int MODE>
+// HALF: the gradient comes in and the feature gradients go out as fp16 (the sums are formed exactly as
+// in the fp32 kernel: fp32 tap values, fixed-point or fp32 accumulation in LDS; only the two I/O
+// conversions move into the kernel) -- what an fp16 graph computes with the reference's casts around
+// the op (models/FPN/builder.py:581-586, 607-608), without the two cast passes over 26 + 182 MB.
+struct __attribute__((packed, aligned(2))) H4u {
+  __half x, y, z, w;
+};
+template <int PH, int PW, int THREADS, int TCH, int MODE, bool HALF = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: four 512-thread workgroups per CU
 void roi_align_bwd_packed4(BwdFusedArgs a) {
+  using TIO = typename std::conditional<HALF, __half, float>::type;
+  static_assert(!HALF || MODE != 2, "fp16 I/O goes with the packed arg-max");
   // MODE 0: one-byte arg-max codes + the forward's coordinate table (4 bytes per sample coordinate);
   // MODE 1 (TAPS): the workspace pre-pass has left band-relative tap entries (8 bytes each) for the
   // listed RoIs; MODE 2 (FLT): the reference's float arg-max planes (the drop-in ROIAlign_v2 op and
@@ -2247,7 +2257,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
 
   // wave-uniform bases + 32-bit lane offsets (the launcher checks R*C*PP < 2^31)
   const int roi_stride = a.C * PP;
-  const float* dyb = a.dy + (long)img * a.R * roi_stride + (long)c * PP;
+  const TIO* dyb = reinterpret_cast<const TIO*>(a.dy) + (long)img * a.R * roi_stride + (long)c * PP;
   const float* axb = FLT ? a.ax + (long)img * a.R * roi_stride + (long)c * PP : nullptr;
   const float* ayb = FLT ? a.ay + (long)img * a.R * roi_stride + (long)c * PP : nullptr;
   const unsigned char* amb = FLT ? nullptr : a.amax8 + ((long)img * a.R * a.C + c) * PPS;
@@ -2276,6 +2286,17 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
       unsigned code = FLT ? 0u : *reinterpret_cast<const unsigned*>(amb + r * am_stride + 4 * g);
       // bins PP-4 .. PP-1 are fetched by the last lane of a RoI, only the last PP % 4 belong to it
       constexpr int KEEP = TAIL ? PP % 4 : 1;
+      // four gradients at element offset o (fp16: 8 bytes, converted)
+      auto load_g = [&](int o) {
+        if constexpr (HALF) {
+          const H4u h = *reinterpret_cast<const H4u*>(dyb + o);
+          F4u v;
+          v.x = __half2float(h.x); v.y = __half2float(h.y); v.z = __half2float(h.z); v.w = __half2float(h.w);
+          return v;
+        } else {
+          return *reinterpret_cast<const F4u*>(dyb + o);
+        }
+      };
       auto tail4 = [](const F4u& v, float fill) {
         const float gg[4] = {v.x, v.y, v.z, v.w};
         return make_float4(gg[4 - KEEP], KEEP > 1 ? gg[KEEP > 1 ? 5 - KEEP : 0] : fill,
@@ -2283,7 +2304,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
       };
       if (TAIL && g == GP - 1) {
         const int o = r * roi_stride + (PP - 4);
-        it.g = tail4(*reinterpret_cast<const F4u*>(dyb + o), 0.f);
+        it.g = tail4(load_g(o), 0.f);
         if (FLT) {
           it.x = tail4(*reinterpret_cast<const F4u*>(axb + o), -1.f);
           it.y = tail4(*reinterpret_cast<const F4u*>(ayb + o), -1.f);
@@ -2291,7 +2312,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
         code |= FLT ? 0u : 0xffffffffu << (8 * KEEP);  // the padding bytes of the row are not codes
       } else {
         const int o = r * roi_stride + 4 * g;
-        const F4u v = *reinterpret_cast<const F4u*>(dyb + o);
+        const F4u v = load_g(o);
         it.g = make_float4(v.x, v.y, v.z, v.w);
         if (FLT) {
           const F4u vx = *reinterpret_cast<const F4u*>(axb + o), vy = *reinterpret_cast<const F4u*>(ayb + o);
@@ -2501,25 +2522,43 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   if (!synced) __syncthreads();
   if (SD_ABLATE(a, 2)) return;  // (profiling build, 2: no write-out)
   const long off = (((long)img * a.C + c) * H + row0) * W;
-  float* dst = a.dx[lvl] + off;
+  TIO* dst = reinterpret_cast<TIO*>(a.dx[lvl]) + off;
   if (((off | band_elems) & 3) == 0) {
-    float4* d4 = reinterpret_cast<float4*>(dst);
     for (int i = tid; i < band_elems / 4; i += THREADS) {
       float4 v = reinterpret_cast<const float4*>(plane)[i];
       if (use_fx) {
         const int4 q = reinterpret_cast<const int4*>(plane_i)[i];
         v = make_float4((float)q.x * fx_inv, (float)q.y * fx_inv, (float)q.z * fx_inv, (float)q.w * fx_inv);
       }
-      if (a.req == SD_REQ_ADD) {
-        const float4 o = d4[i];
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      if constexpr (HALF) {
+        __half2* d2 = reinterpret_cast<__half2*>(dst) + 2 * i;   // (8-byte aligned: off and band_elems % 4 == 0)
+        if (a.req == SD_REQ_ADD) {   // the sum is formed in fp32, rounded once
+          const float2 o0 = __half22float2(d2[0]), o1 = __half22float2(d2[1]);
+          v.x += o0.x; v.y += o0.y; v.z += o1.x; v.w += o1.y;
+        }
+        uint2 pk;
+        const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+        pk.x = *reinterpret_cast<const unsigned*>(&h0);
+        pk.y = *reinterpret_cast<const unsigned*>(&h1);
+        *reinterpret_cast<uint2*>(d2) = pk;
+      } else {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        if (a.req == SD_REQ_ADD) {
+          const float4 o = d4[i];
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        d4[i] = v;
       }
-      d4[i] = v;
     }
   } else {
     for (int i = tid; i < band_elems; i += THREADS) {
-      const float v = use_fx ? (float)plane_i[i] * fx_inv : plane[i];
-      dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + v : v;
+      float v = use_fx ? (float)plane_i[i] * fx_inv : plane[i];
+      if constexpr (HALF) {
+        if (a.req == SD_REQ_ADD) v += __half2float(dst[i]);
+        dst[i] = __float2half(v);
+      } else {
+        dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + v : v;
+      }
     }
   }
 }
@@ -2713,6 +2752,22 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   int threads = tuning("roi_align_bwd_threads", 0);
   if (threads != 256 && threads != 512) threads = 512;
   if (wide) {
+    if (a.half_io) {   // fp16 I/O: the default configuration of the wide kernel (512 threads, default chunk)
+      if (flt || threads != 512 || tch != (a.PP == 49 ? 32 : 16)) return SD_ERR_UNSUPPORTED;
+#define SD_BWDH(PHv, TCHv)                                                                       \
+  do {                                                                                           \
+    auto k = a.ws_taps ? roi_align_bwd_packed4<PHv, PHv, 512, TCHv, 1, true>                     \
+                       : roi_align_bwd_packed4<PHv, PHv, 512, TCHv, 0, true>;                    \
+    if (lds_max > 64 * 1024)                                                                     \
+      SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds_max));                                           \
+    hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(512), lds_max, st, a);                     \
+  } while (0)
+      if (a.PP == 49) SD_BWDH(7, 32); else SD_BWDH(14, 16);
+#undef SD_BWDH
+      SD_LAUNCH_CHECK();
+      return SD_OK;
+    }
 #define SD_BWDW(PHv, T, TCHv)                                                                    \
   do {                                                                                           \
     auto k = flt ? roi_align_bwd_packed4<PHv, PHv, T, TCHv, 2>                                   \
@@ -2737,6 +2792,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
     SD_LAUNCH_CHECK();
     return SD_OK;
   }
+  if (a.half_io) return SD_ERR_UNSUPPORTED;   // (the per-item fallback kernel has no fp16 form)
 #define SD_BWDF2(PPv, T, PKv)                                                                    \
   do {                                                                                           \
     auto k = roi_align_bwd_fused<PPv, T, PKv>;                                                   \
@@ -3422,7 +3478,8 @@ extern "C" int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* r
                                         roi_canonical_scale, roi_canonical_level, nullptr, 0, stream);
 }
 
-static int fpn_bwd_packed_impl(int planned, const float* out_grad, const float* rois,
+// mode: bit 0 the forward left the lists / tap tables in `workspace` (planned), bit 1 fp16 gradient in and out
+static int fpn_bwd_packed_impl(int mode, const float* out_grad, const float* rois,
                                               const uint8_t* argmax, const float* coords,
                                               float* const* d_feats_host,
                                               const int* Hs_host, const int* Ws_host,
@@ -3449,12 +3506,14 @@ static int fpn_bwd_packed_impl(int planned, const float* out_grad, const float* 
     SD_REQUIRE(d_feats_host[l] || (long)B * C == 0, "d_feats[%d] null", l);
     f.dx[l] = d_feats_host[l];
   }
+  const int planned = mode & 1;
+  f.half_io = (mode >> 1) & 1;
   f.B = B; f.C = C; f.R = R; f.PP = PPv; f.filter = 1; f.req = req_data;
   if ((long)B * R * C == 0) {
     for (int l = 0; l < nlvl; ++l)
       if (req_data == SD_REQ_WRITE && d_feats_host[l])
         SD_HIP_CHECK(hipMemsetAsync(d_feats_host[l], 0,
-                                    sizeof(float) * (size_t)B * C * Hs_host[l] * Ws_host[l],
+                                    (f.half_io ? 2 : sizeof(float)) * (size_t)B * C * Hs_host[l] * Ws_host[l],
                                     (hipStream_t)stream));
     return SD_OK;
   }
@@ -3467,7 +3526,10 @@ static int fpn_bwd_packed_impl(int planned, const float* out_grad, const float* 
   // `workspace`; where its plan did not apply (same deterministic decision here) the normal path runs
   if (planned) e = launch_bwd_fused(f, nlvl, (hipStream_t)stream, workspace, workspace_bytes, 2);
   if (e == SD_ERR_UNSUPPORTED) e = launch_bwd_fused(f, nlvl, (hipStream_t)stream, workspace, workspace_bytes, 0);
-  if (e == SD_ERR_UNSUPPORTED) return fail(e, "packed arg-max backward: a level does not fit LDS");
+  if (e == SD_ERR_UNSUPPORTED)
+    return fail(e, f.half_io ? "fp16 packed arg-max backward runs on the default wide kernel only (a level does not "
+                               "fit LDS, or roi_align_bwd_packed / _threads / _tch were changed)"
+                             : "packed arg-max backward: a level does not fit LDS");
   return e;
 }
 
@@ -3480,6 +3542,24 @@ extern "C" int sd_fpn_roi_align_bwd_packed_ws(const float* out_grad, const float
                                               float roi_canonical_scale, float roi_canonical_level,
                                               void* workspace, size_t workspace_bytes, void* stream) {
   return fpn_bwd_packed_impl(0, out_grad, rois, argmax, coords, d_feats_host, Hs_host, Ws_host, strides_host,
+                             nlvl, req_data, B, C, R, pooled_h, pooled_w, roi_canonical_scale,
+                             roi_canonical_level, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sd_fpn_roi_align_bwd_packed_f16(const void* out_grad, const float* rois,
+                                               const uint8_t* argmax, const float* coords,
+                                               void* const* d_feats_host, const int* Hs_host,
+                                               const int* Ws_host, const int* strides_host, int nlvl,
+                                               int req_data, int B, int C, int R, int pooled_h,
+                                               int pooled_w, float roi_canonical_scale,
+                                               float roi_canonical_level, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  SD_REQUIRE(((uintptr_t)out_grad & 1) == 0, "out_grad must be 2-byte aligned");
+  if (d_feats_host)
+    for (int l = 0; l < nlvl; ++l)
+      SD_REQUIRE(((uintptr_t)d_feats_host[l] & 7) == 0, "d_feats[%d] must be 8-byte aligned", l);
+  return fpn_bwd_packed_impl(2, reinterpret_cast<const float*>(out_grad), rois, argmax, coords,
+                             reinterpret_cast<float* const*>(d_feats_host), Hs_host, Ws_host, strides_host,
                              nlvl, req_data, B, C, R, pooled_h, pooled_w, roi_canonical_scale,
                              roi_canonical_level, workspace, workspace_bytes, stream);
 }

@@ -791,6 +791,24 @@ def _build_ops(mx):
             B, C = feats[0].shape[:2]
             req_data = rq.pop()
             og, grads16 = out_grad[0], None
+            if self.fp16 and self.packed:
+                # the backward kernel's fp16-I/O instance: the graph's to_fp32 / to_fp16 casts
+                # (models/FPN/builder.py:581-586, 607-608) happen inside the kernel
+                ptrs16, Hs16, Ws16 = self._levels(in_grad[:-1])
+                lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
+                wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(Hs16, Ws16, len(feats), B, rois.shape[1])
+                ws = _scratch(rois, wsb)
+                try:
+                    lib().call("sd_fpn_roi_align_bwd_packed_f16", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                               _ptr(out_data[2]), ptrs16, Hs16, Ws16, _iarr(self.strides), len(feats), req_data,
+                               B, C, rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
+                               float(self.lvl0), _ptr(ws), ctypes.c_size_t(wsb), None)
+                    _sync()
+                    self.assign(in_grad[-1], req[-1], 0)
+                    return
+                except SimpleDetOpsError as e:
+                    if e.code != SD_ERR_UNSUPPORTED:
+                        raise
             if self.fp16:
                 # the sums are formed by the fp32 kernel: the graph's to_fp32 / to_fp16 casts
                 # (models/FPN/builder.py:581-586, 607-608) happen here, at the op boundary

@@ -305,21 +305,39 @@ def cast_f32_to_f16(src, out=None, req="write"):
 
 def fpn_roi_align_backward_packed_f16(out_grad, rois, argmax, feat_shapes, rcnn_stride,
                                       roi_canonical_scale=224, roi_canonical_level=4, req_data="write",
-                                      d_feats=None):
-    """Backward of fpn_roi_align_forward_packed_f16: out_grad fp16 -> gradients fp16.  The sums are
-    formed by the fp32 backward kernel; the fp16 interface is the two op-boundary casts of the
-    reference's fp16 graphs (to_fp32 on the way in, to_fp16 on the way out) around it -- a backward
-    kernel with fp16 I/O of its own is not built."""
+                                      d_feats=None, native=True):
+    """Backward of fpn_roi_align_forward_packed_f16: out_grad fp16 -> gradients fp16, by the backward
+    kernel's fp16-I/O instance (sd_fpn_roi_align_bwd_packed_f16: fp32 tap values, fixed-point sums,
+    fp16 only at the two ends).  native=False, or a shape the wide kernel does not take: the two
+    op-boundary casts of the reference's fp16 graphs around the fp32 kernel (same bits)."""
     _chk(out_grad, "out_grad", dtype=torch.float16, ndim=5)
+    _chk(rois, "rois", ndim=3)
     rd = REQ[req_data] if isinstance(req_data, str) else int(req_data)
-    g32 = fpn_roi_align_backward_packed(cast_f16_to_f32(out_grad), rois, argmax, feat_shapes, rcnn_stride,
-                                        roi_canonical_scale, roi_canonical_level)
     if d_feats is None:
         if rd == REQ["add"]:
             raise ValueError("req_data='add' needs d_feats")
         d_feats = [torch.empty(tuple(s), device=out_grad.device, dtype=torch.float16) for s in feat_shapes]
-    for g, d in zip(g32, d_feats):
+    for d in d_feats:
         _chk(d, "d_feats", dtype=torch.float16, ndim=4)
+    if native:
+        am, coords = argmax[0], argmax[1]
+        B, R, C, ph, pw = out_grad.shape
+        hs, ws_ = _iarr([f.shape[2] for f in d_feats]), _iarr([f.shape[3] for f in d_feats])
+        lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
+        wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(hs, ws_, len(d_feats), B, R)
+        work = torch.empty((max(int(wsb), 4) + 3) // 4, device=out_grad.device, dtype=torch.int32)
+        try:
+            lib().call("sd_fpn_roi_align_bwd_packed_f16", _p(out_grad), _p(rois), _p(am), _p(coords),
+                       _parr(d_feats), hs, ws_, _iarr(rcnn_stride), len(d_feats), rd, B, C, R, ph, pw,
+                       float(roi_canonical_scale), float(roi_canonical_level), _p(work),
+                       ctypes.c_size_t(work.numel() * 4), _stream())
+            return d_feats
+        except SimpleDetOpsError as e:
+            if e.code != SD_ERR_UNSUPPORTED:
+                raise
+    g32 = fpn_roi_align_backward_packed(cast_f16_to_f32(out_grad), rois, argmax, feat_shapes, rcnn_stride,
+                                        roi_canonical_scale, roi_canonical_level)
+    for g, d in zip(g32, d_feats):
         cast_f32_to_f16(g, d, rd)
     return d_feats
 

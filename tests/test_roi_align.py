@@ -557,6 +557,7 @@ def test_planned_pair_one_prepass_equals_the_unplanned_pair(ops, pooled, num, ch
     rois = _t(synth.random_rois(42, 2, num))
     shapes = [f.shape for f in feats]
     o0, st0 = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, pooled)
+    torch.manual_seed(43)
     dy = torch.randn_like(o0)
     g0 = ops.fpn_roi_align_backward_packed(dy, rois, st0, shapes, STRIDES)
     for k, v in knobs.items():
@@ -579,8 +580,8 @@ def test_planned_pair_one_prepass_equals_the_unplanned_pair(ops, pooled, num, ch
     for a, b, c in zip(g1, g0, acc):
         if same_tables:
             assert torch.equal(a, b)
-        else:
-            assert float((a - b).abs().max()) <= 1e-4
+        else:   # two fixed-point scales, each within ~5e-5 of the exact sum
+            assert float((a - b).abs().max()) <= 2e-4
         assert float((c - 1 - a).abs().max()) <= 1e-4
 
 
@@ -701,23 +702,35 @@ def test_fpn_packed_forward_fp16_io(ops, oracle, pooled, num, channels):
 
 
 @pytest.mark.gpu
-def test_fpn_packed_backward_fp16_io(ops, oracle):
+@pytest.mark.parametrize("pooled,num,channels", [((7, 7), 128, 16), ((14, 14), 40, 8)])
+def test_fpn_packed_backward_fp16_io(ops, oracle, pooled, num, channels):
     """fp16 gradient in, fp16 gradients out: the fp32 sums (within 1e-4 of the oracle's) rounded to
     fp16 -- at most one fp16 step from the rounded exact sum wherever 1e-4 crosses a rounding boundary."""
     import torch
-    feats16 = [f.astype(np.float16) for f in synth.feature_maps(6, batch=2, channels=16)]
-    rois = synth.random_rois(6, 2, 128)
-    out, am = ops.fpn_roi_align_forward_packed_f16([_t(f) for f in feats16], _t(rois), STRIDES, (7, 7))
+    feats16 = [f.astype(np.float16) for f in synth.feature_maps(6, batch=2, channels=channels)]
+    rois = synth.random_rois(6, 2, num)
+    out, am = ops.fpn_roi_align_forward_packed_f16([_t(f) for f in feats16], _t(rois), STRIDES, pooled)
     dy16 = np.random.RandomState(7).standard_normal(tuple(out.shape)).astype(np.float16)
     shapes = [f.shape for f in feats16]
     g16 = ops.fpn_roi_align_backward_packed_f16(_t(dy16), _t(rois), am, shapes, STRIDES)
-    fw = oracle.fpn_roi_align_fwd([f.astype(np.float32) for f in feats16], rois, STRIDES, (7, 7), nthreads=8)
+    fw = oracle.fpn_roi_align_fwd([f.astype(np.float32) for f in feats16], rois, STRIDES, pooled, nthreads=8)
     want = oracle.fpn_roi_align_bwd(dy16.astype(np.float32), rois, fw[1], fw[2], shapes, STRIDES, nthreads=8)
     for g, w in zip(g16, want):
         assert g.dtype == torch.float16
         got = g.cpu().numpy().astype(np.float32)
         step = np.maximum(np.abs(w) * 2.0 ** -10, 2.0 ** -24)   # one fp16 step at the value's magnitude
         assert np.all(np.abs(got - w) <= 1e-4 + step)
+    # the kernel's fp16-I/O instance == the casts around the fp32 kernel, bit for bit (write and add)
+    gc = ops.fpn_roi_align_backward_packed_f16(_t(dy16), _t(rois), am, shapes, STRIDES, native=False)
+    for a_, b_ in zip(g16, gc):
+        assert torch.equal(a_, b_)
+    acc_n = [torch.full(tuple(s), 0.5, device="cuda", dtype=torch.float16) for s in shapes]
+    acc_c = [a_.clone() for a_ in acc_n]
+    ops.fpn_roi_align_backward_packed_f16(_t(dy16), _t(rois), am, shapes, STRIDES, req_data="add", d_feats=acc_n)
+    ops.fpn_roi_align_backward_packed_f16(_t(dy16), _t(rois), am, shapes, STRIDES, req_data="add", d_feats=acc_c,
+                                          native=False)
+    for a_, b_ in zip(acc_n, acc_c):
+        assert torch.equal(a_, b_)
     # req = add accumulates into fp16 gradients
     acc = [torch.ones(tuple(s), device="cuda", dtype=torch.float16) for s in shapes]
     ops.fpn_roi_align_backward_packed_f16(_t(dy16), _t(rois), am, shapes, STRIDES, req_data="add", d_feats=acc)
