@@ -80,6 +80,15 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_source_sha():
+    """sha256 over the sources of the kernels the roofline is about: a PMC profile is only quoted for them"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("roi_align.hip", "common.h", "runtime.hip"):
+        h.update(open(os.path.join(ROOT, "simpledet_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def algorithmic_bytes(n_img, n_roi, channels, shapes, pooled=49):
     s_f = 4 * channels * sum(h * w for h, w in shapes)      # every level read (fwd) / written (bwd)
     s_o = 4 * n_roi * channels * pooled                      # one (R,C,7,7) fp32 tensor per image
@@ -214,6 +223,7 @@ def main():
             out, am = ops.fpn_roi_align_forward_packed(feats, rois, strides, (7, 7), plan=not args.no_plan)
         if ev:
             ev[1].record()
+            state["fwd_dispatch"] = (lib().cdll.sd_last_dispatch() or b"").decode()
         if reducer is not None:
             # the gradients of the layers behind the RoI head exist by now: their all-reduce runs
             # under the RoIAlign backward, as in a data-parallel training step
@@ -224,6 +234,7 @@ def main():
             ops.fpn_roi_align_backward_packed(dy, rois, am, None, strides, d_feats=d_feats)
         if ev:
             ev[2].record()
+            state["bwd_dispatch"] = (lib().cdll.sd_last_dispatch() or b"").decode()
         if reducer is not None:
             reducer.finish()  # the optimizer needs the reduced gradients: the step ends here
         state["out"] = out
@@ -344,9 +355,17 @@ def main():
     # stale_* are superseded ones
     cands = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
              if re.match(r"^r\d+[a-z]?_pmc_summary\.json$", os.path.basename(f))]
+    src_sha = kernel_source_sha()
+    stale = []
     for pmc_path in sorted(cands)[::-1]:
         try:
-            ks = json.load(open(pmc_path))["kernels"]
+            prof = json.load(open(pmc_path))
+            # a profile is quoted only if it was taken with THESE kernel sources (tools/summarize_profile.py
+            # records the hash of simpledet_amd/csrc/{roi_align.hip,common.h,runtime.hip} next to the counters)
+            if prof.get("kernel_source_sha256") != src_sha:
+                stale.append(os.path.basename(pmc_path))
+                continue
+            ks = prof["kernels"]
             # the step's kernel is the most-dispatched forward / backward kernel of the profile
             # (the per-level kernels of the --extra leg run a handful of times)
             for pat in ("roi_align_fwd", "roi_align_bwd"):
@@ -355,31 +374,25 @@ def main():
                 if cand:
                     d = max(cand, key=lambda t: t[0])[1]
                     tot = d["fetch_bytes_x2_gfx950"] + d.get("write_bytes", 0.0)
-                    if pat == "roi_align_bwd":  # + the list / tap-table pre-pass of the same step
-                        tot += sum(x["fetch_bytes_x2_gfx950"] + x.get("write_bytes", 0.0)
-                                   for name, x in ks.items()
-                                   if "bwd_lists" in name and "fetch_bytes_x2_gfx950" in x)
-                    else:                       # + the forward's pre-pass
-                        tot += sum(x["fetch_bytes_x2_gfx950"] + x.get("write_bytes", 0.0)
-                                   for name, x in ks.items()
-                                   if "roi_fwd_prep" in name and "fetch_bytes_x2_gfx950" in x)
+                    pre = ("bwd_lists",) if pat == "roi_align_bwd" else ("roi_fwd_prep", "roi_prep_merged")
+                    tot += sum(x["fetch_bytes_x2_gfx950"] + x.get("write_bytes", 0.0)
+                               for name, x in ks.items()
+                               if any(q in name for q in pre) and "fetch_bytes_x2_gfx950" in x)
                     if pat == "roi_align_fwd":
                         traffic = tot
                     else:
                         bwd_traffic = tot
             if traffic is not None:
-                traffic_source = ("%s (rocprofv3 --pmc passes of this command at commit time; "
-                                  "not re-measured in this run)" % os.path.relpath(pmc_path, ROOT))
+                traffic_source = ("%s (rocprofv3 --pmc passes of this command with these kernel sources, sha256 %s; "
+                                  "not re-measured in this run)" % (os.path.relpath(pmc_path, ROOT), src_sha[:12]))
                 break
         except Exception:
             traffic = None
-    band = lib().get_tuning("roi_align_fwd_band")
-    if band != 0:  # (-1: not set = the default)
-        fwd_kernel = ("sd::roi_align_fwd_band<7,%s> (fused FPN forward, planes streamed through LDS) + "
-                      "sd::roi_fwd_prep_kernel<7> (item lists / tap entries, ~6.5 us, inside avg_launch_ms)"
-                      % ("false" if args.float_argmax else "true"))
-    else:
-        fwd_kernel = "sd::roi_align_fwd_tiled_lean<2,true> (fused FPN forward, per-RoI gathers, 1 launch/step)"
+    if traffic is None:
+        traffic_source = ("none: no committed PMC profile was taken with the current kernel sources (sha256 %s)%s"
+                          % (src_sha[:12], "; stale: " + ", ".join(stale[:4]) if stale else ""))
+    fwd_kernel = state.get("fwd_dispatch") or "unknown"
+    bwd_kernel = state.get("bwd_dispatch") or "unknown"
     roofline = {
         "kernel": fwd_kernel,
         "bound": "hbm",
@@ -391,8 +404,10 @@ def main():
         "traffic_source": traffic_source,
         "algorithmic_bytes": alg,
         "avg_launch_ms": fwd_ms,
+        "kernel_note": "names reported by the library for the dispatch it took (sd_last_dispatch); avg_launch_ms "
+                       "spans every launch of the forward op incl. its rois-only pre-pass",
         "backward": {
-            "kernel": "sd::roi_align_bwd_packed4<7,7,512,32,true> (all FPN levels, 1 launch/step) + sd::roi_align_bwd_lists (list / tap-table pre-pass, ~6.7 us, inside avg_ms)",
+            "kernel": bwd_kernel,
             "achieved": alg / (bwd_ms * 1e-3) / 1e9,
             "frac": alg / (bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "avg_ms": bwd_ms,

@@ -349,7 +349,10 @@ def run(seed=0, cpu=True, only=None):
         off = torch.randn((N, 72, H, W), device="cuda") * 2
         wt = torch.randn((F, C, 3, 3), device="cuda") * 0.05
         ms_i = _time_gpu(lambda: ops.deform_im2col(x, off, (3, 3), 1, 1, 1, 4), iters=20, warm=2)
+        # the layer's forward = the col-free fused kernel (sd_deform_conv_fwd_nocol); the im2col + GEMM
+        # forward (sd_deform_conv_fwd, what a training step that keeps col for its backward runs) beside it
         ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=10, warm=2)
+        ms_fu = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4, keep_col=True), iters=10, warm=2)
         y = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)
         dyc = torch.randn_like(y)
         grads = (torch.empty_like(x), torch.empty_like(off), torch.empty_like(wt))
@@ -366,8 +369,17 @@ def run(seed=0, cpu=True, only=None):
         P_ = H * W
         im2col_bytes = N * (4 * (C + 72) * P_ + 4 * 9 * C * P_)
         flops = 2.0 * N * F * 9 * C * P_
-        gemm_ms = max(ms_f - ms_i, 1e-6)
+        gemm_ms = max(ms_fu - ms_i, 1e-6)
+        from simpledet_amd._lib import lib as _lib
+        import ctypes as _ct
+        _lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes.restype = _ct.c_size_t
+        ws_fused = int(_lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes(N, C, H, W, F, 3, 3, 1, 1, 1, 4))
+        ws_unfused = int(_lib().cdll.sd_deform_conv_workspace_bytes(N, C, H, W, 3, 3, 1, 1, 1))
+        io_bytes = 4 * (x.numel() + off.numel() + wt.numel() + y.numel())
         res["deform_conv"] = {
+            "fwd_kernel": "sd::dcn_fwd_fused_kernel (sampling fused into the GEMM, no col matrix)",
+            "fwd_unfused_ms": ms_fu, "fwd_workspace_bytes": ws_fused, "fwd_unfused_workspace_bytes": ws_unfused,
+            "fwd_io_bytes": io_bytes, "fwd_frac_of_f16_mfma_peak": 3.0 * flops / ms_f / 1e9 / PEAK_BF16_MFMA_TFLOPS,
             "im2col_ms": ms_i, "im2col_GBs": im2col_bytes / ms_i / 1e6,
             "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
             "col2im_ms": ms_c2i, "col2im_coord_ms": ms_crd,

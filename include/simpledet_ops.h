@@ -44,6 +44,10 @@ extern "C" {
 #define SD_MAX_FPN_LEVELS 8
 
 const char* sd_last_error(void);
+/* the kernels the calling thread's last fused-RoIAlign entry point launched, e.g.
+ * "sd::roi_prep_merged_kernel<7> + sd::roi_align_fwd_band<7,true,false>" (measurement tools label
+ * their numbers with the dispatch actually taken instead of assuming one) */
+const char* sd_last_dispatch(void);
 /* ABI version of this header: bumped on any signature change AND on any change of a buffer layout
  * or size contract (a caller built against an older header must not pass it buffers of the old
  * size).  History: 1 round 1; 2 packed arg-max rows padded to whole dwords (7x7: 49 -> 52 bytes)

@@ -17,6 +17,8 @@ namespace sd {
 // thread-local last-error message, read through sd_last_error()
 char* err_buf();
 int fail(int code, const char* fmt, ...);
+// names of the kernels an entry point launches (sd_last_dispatch(): bench.py labels its roofline with them)
+void note_dispatch(const char* fmt, ...);
 
 #define SD_REQUIRE(cond, ...)                                    \
   do {                                                           \

@@ -2765,6 +2765,8 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   } while (0)
       if (a.PP == 49) SD_BWDH(7, 32); else SD_BWDH(14, 16);
 #undef SD_BWDH
+      note_dispatch("%ssd::roi_align_bwd_packed4<%d,%d,512,%d,%d,true>", prepass == 0 && a.ws_list ? "sd::roi_align_bwd_lists + " : "",
+                    a.PP == 49 ? 7 : 14, a.PP == 49 ? 7 : 14, tch, a.ws_taps ? 1 : 0);
       SD_LAUNCH_CHECK();
       return SD_OK;
     }
@@ -2789,6 +2791,8 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
     }
 #undef SD_BWDW_T
 #undef SD_BWDW
+    note_dispatch("%ssd::roi_align_bwd_packed4<%d,%d,%d,%d,%d>", prepass == 0 && a.ws_list ? "sd::roi_align_bwd_lists + " : "",
+                  a.PP == 49 ? 7 : 14, a.PP == 49 ? 7 : 14, threads, tch, flt ? 2 : (a.ws_taps ? 1 : 0));
     SD_LAUNCH_CHECK();
     return SD_OK;
   }
@@ -2813,6 +2817,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   }
 #undef SD_BWDF
 #undef SD_BWDF2
+  note_dispatch("sd::roi_align_bwd_fused<%d> (per-item fallback)", a.PP);
   SD_LAUNCH_CHECK();
   return SD_OK;
 }
@@ -3113,6 +3118,8 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       }
 #undef SD_FWD_BAND
 #undef SD_FWD_PREP
+      note_dispatch("sd::%s<%d> + sd::roi_align_fwd_band<%d,%s,%s>", merged ? "roi_prep_merged_kernel" : "roi_fwd_prep_kernel",
+                    POOL, POOL, a.amax8 ? "true" : "false", a.half_io ? "true" : "false");
       SD_LAUNCH_CHECK();
       return SD_OK;
     }
@@ -3120,6 +3127,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   if (a.half_io)
     return fail(SD_ERR_UNSUPPORTED, "fp16 RoIAlign runs on the band-resident kernel only: it needs the workspace, "
                 "7x7 or 14x14 pooling, W in [2, 4095] and roi_align_fwd = 1, roi_align_fwd_band = 1");
+  note_dispatch("sd::roi_align_fwd (tiled / naive fallback kernels: no workspace or a shape the band kernel does not take)");
   if (variant == 1 && a.amax8 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
     // packed arg-max (the fused op): the 64-VGPR build, four workgroups per CU
     hipLaunchKernelGGL((roi_align_fwd_tiled_lean<2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);

@@ -1,5 +1,6 @@
 // Error reporting, ABI version and tuning knobs of libsimpledet_ops_hip.so.
 #include "common.h"
+#include <stdarg.h>
 #include "../../include/simpledet_ops.h"
 #include <atomic>
 #include <string.h>
@@ -167,7 +168,19 @@ extern "C" int sd_stream_synchronize(void* stream) {
   return SD_OK;
 }
 
+namespace sd {
+// the kernels the last RoIAlign entry point of this thread launched, for measurement tools
+static thread_local char g_dispatch[256] = {0};
+void note_dispatch(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_dispatch, sizeof(g_dispatch), fmt, ap);
+  va_end(ap);
+}
+}  // namespace sd
+
 extern "C" const char* sd_last_error(void) { return sd::err_buf(); }
+extern "C" const char* sd_last_dispatch(void) { return sd::g_dispatch; }
 extern "C" int sd_abi_version(void) { return SD_ABI_VERSION; }
 
 extern "C" int sd_set_tuning(const char* key, int value) {

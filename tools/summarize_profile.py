@@ -55,6 +55,13 @@ def main(out):
         res["kernels"][k] = d
         print("==", k[:100])
         print("   ", {c: ("%.5g" % v if isinstance(v, float) else v) for c, v in d.items()})
+    # which kernel sources these counters belong to (bench.py quotes a profile only for the same hash)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("roi_align.hip", "common.h", "runtime.hip"):
+        h.update(open(os.path.join(root, "simpledet_amd", "csrc", f), "rb").read())
+    res["kernel_source_sha256"] = h.hexdigest()
     json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
 
