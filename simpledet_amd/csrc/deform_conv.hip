@@ -1422,8 +1422,8 @@ constexpr int kFN = 96;            // pixel slots of a tile (3 x 32)
 constexpr int kFHalf = 8;          // channels per half-slab
 constexpr int kFThreads = 512;    // 4 matrix-core waves + 3 sampling waves + 1 loader wave
 constexpr int kFBBytes = 2 * 2 * kFN * 16 * 2;   // B tile: 2 buffers x (hi, lo) x 96 x 16 halves = 12 KB
-constexpr int kFStateBytes = 9 * 5 * 2 * kFN * 4;   // sampling state of 192 producer lanes x 9 taps x 5 words = 34.6 KB
-constexpr int kFXFloats = 28160;   // 110 KB of x windows: two half-slab buffers
+constexpr int kFStateBytes = 9 * 5 * kFN * 4;   // sampling state of 96 pixels x 9 taps x 5 words = 17.3 KB
+constexpr int kFXFloats = 33280;   // 130 KB of x windows: two half-slab buffers
 constexpr int kFStage = 16;        // 16-byte words per lane the loader wave moves per step (two channel windows)
 constexpr int kFSmemBytes = kFBBytes + kFStateBytes + kFXFloats * 4 + 64 + 64;
 
@@ -1438,6 +1438,7 @@ struct DcnFusedArgs {
   int x_aligned;         // x is 16-byte aligned (16-byte window loads); else every tile takes the global path
   int* flags;            // [tile] 1: left to the LDSX = false instance
   int ablate;            // profiling build only: 1 no sampling, 2 no matrix-core ops, 4 no window loads, 8 no B reads
+  long long* dbg;        // profiling build only: per (workgroup, wave) {total, barrier wait, set-up} clocks
 };
 
 // weights (F, C, 9) -> apre[mt][slab16][j][wave][i][plane][lane] (16 bytes each): lane l of fragment
@@ -1490,14 +1491,29 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifdef SD_PROFILING
+#define SD_FBAR()                                                   \
+  do {                                                              \
+    const long long t0_ = __builtin_readcyclecounter();             \
+    lds_barrier();                                                  \
+    p_wait += __builtin_readcyclecounter() - t0_;                   \
+  } while (0)
+#else
+#define SD_FBAR() lds_barrier()
+#endif
+
 template <bool LDSX>
 __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a) {
+#ifdef SD_PROFILING
+  long long p_wait = 0, p_setup = 0;
+  const long long p_begin = __builtin_readcyclecounter();
+#endif
   extern __shared__ __attribute__((aligned(16))) char fsm[];
-  char* Bs = fsm;
-  float* sst = reinterpret_cast<float*>(fsm + kFBBytes);                 // sampling state [tap][word][producer lane]
-  float* xs = reinterpret_cast<float*>(fsm + kFBBytes + kFStateBytes);   // two half-slab window buffers
-  int* rng = reinterpret_cast<int*>(fsm + kFBBytes + kFStateBytes + kFXFloats * 4);
-  float* dummy = reinterpret_cast<float*>(fsm + kFBBytes + kFStateBytes + kFXFloats * 4 + 64);   // 16 bytes
+  float* xs = reinterpret_cast<float*>(fsm);                              // two half-slab window buffers (at LDS
+                                                                          // address 0: no base to add per read)
+  char* Bs = fsm + kFXFloats * 4;
+  float* sst = reinterpret_cast<float*>(fsm + kFXFloats * 4 + kFBBytes);  // sampling state [tap][word][pixel]
+  int* rng = reinterpret_cast<int*>(fsm + kFXFloats * 4 + kFBBytes + kFStateBytes);
   const DcnGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1550,26 +1566,38 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
   auto group_begin = [&](int grp, Grp& G) -> bool {
     int wstart = 0, wcount = 0;
     {
-      int info[kDcnMaxTaps];
-      float w1[kDcnMaxTaps], w2[kDcnMaxTaps], w3[kDcnMaxTaps], w4[kDcnMaxTaps];
+      // the state of pixel pl is shared by its two lanes: lane (pl, 0) sets up taps 0..4, lane (pl, 1) taps 5..8
+      constexpr int kT = 5;
+      int info[kT];
+      float w1[kT], w2[kT], w3[kT], w4[kT];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        info[tap] = 0;
-        w1[tap] = w2[tap] = w3[tap] = w4[tap] = 0.f;
+      for (int i = 0; i < kT; ++i) {
+        info[i] = 0;
+        w1[i] = w2[i] = w3[i] = w4[i] = 0.f;
       }
+      const int tap0 = half * kT, ntap = half ? 9 - kT : kT;
       if (producer) {
         const float* off = a.offset + ((long)n * g.dgroup + grp) * 18 * P + (live ? p : 0);
-        float oh[kDcnMaxTaps], ow[kDcnMaxTaps];
+        float oh[kT], ow[kT];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          oh[tap] = off[(long)(2 * tap) * P];
-          ow[tap] = off[(long)(2 * tap + 1) * P];
+        for (int i = 0; i < kT; ++i) {
+          const int tap = tap0 + (i < ntap ? i : 0);   // (lane (pl, 1)'s fifth slot: tap 5 again, not stored)
+          oh[i] = off[(long)(2 * tap) * P];
+          ow[i] = off[(long)(2 * tap + 1) * P];
         }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const Sample s = im2col_sample(g, h_in, w_in, tap / g.kw, tap % g.kw, oh[tap], ow[tap]);
-          info[tap] = dcn_pack(s.ok && live, s.h_low, s.w_low, s.h_high, s.w_high, g.W);
-          w1[tap] = s.w1; w2[tap] = s.w2; w3[tap] = s.w3; w4[tap] = s.w4;
+        for (int i = 0; i < kT; ++i) {
+          const int tap = tap0 + (i < ntap ? i : 0);
+          const int ti = (tap * 11) >> 5;   // tap / 3 for tap < 9
+          const Sample s = im2col_sample(g, h_in, w_in, ti, tap - 3 * ti, oh[i], ow[i]);
+          const bool in_ = s.ok && live && i < ntap;
+          info[i] = dcn_pack(in_, s.h_low, s.w_low, s.h_high, s.w_high, g.W);
+          // a sample outside the image (or a lane past the tile) has weights 0 and reads corner 0: the
+          // sampling loop needs no "inside" select (0 x finite = 0; non-finite x gives NaN, as in the
+          // split GEMM).  Likewise a column clamped at the border has lw == 0 exactly, so the weights of
+          // the "right" corners are 0 and what is read there (the next row's first pixel, or the zeroed
+          // slack behind the window) does not matter.
+          w1[i] = in_ ? s.w1 : 0.f; w2[i] = in_ ? s.w2 : 0.f; w3[i] = in_ ? s.w3 : 0.f; w4[i] = in_ ? s.w4 : 0.f;
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1584,8 +1612,8 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
         }
         int lo = 0x7fffffff, hi = -1;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int in = info[tap];
+        for (int i = 0; i < kT; ++i) {
+          const int in = info[i];
           if (in & kDcnInside) {
             const int o1 = in & 0xfffffff;
             lo = iminr(lo, o1);
@@ -1609,17 +1637,18 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
           wstart = lo & ~3;
           wcount = iminr((hi + 4) & ~3, plane) - wstart;
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap)
-            if (info[tap] & kDcnInside) info[tap] -= wstart;
+          for (int i = 0; i < kT; ++i)
+            if (info[i] & kDcnInside) info[i] -= wstart;
         }
       }
       if (producer) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          float* d = sst + tap * 5 * (2 * kFN) + ptid;
-          d[0] = __int_as_float(info[tap]);
-          d[2 * kFN] = w1[tap]; d[2 * 2 * kFN] = w2[tap]; d[3 * 2 * kFN] = w3[tap]; d[4 * 2 * kFN] = w4[tap];
-        }
+        for (int i = 0; i < kT; ++i)
+          if (i < ntap) {
+            float* d = sst + (tap0 + i) * 5 * kFN + pl;
+            d[0] = __int_as_float(info[i]);
+            d[kFN] = w1[i]; d[2 * kFN] = w2[i]; d[3 * kFN] = w3[i]; d[4 * kFN] = w4[i];
+          }
       }
     }
     // floats between the channel windows in LDS: the second corner row of a sample may start W past
@@ -1637,6 +1666,13 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
         return false;
       }
       if (grp == 0 && tid == 0) *flag = 0;
+      // the W + 4 .. W + 7 floats of slack behind each of the 16 channel windows are read (with weight 0)
+      // by samples clamped at the border: keep them finite
+      {
+        const int sl_ = G.wstride - (G.n4 << 2);
+        for (int i = tid; i < 2 * kFHalf * sl_; i += kFThreads)
+          xs[(i / sl_) * G.wstride + (G.n4 << 2) + i % sl_] = 0.f;
+      }
       if (G.n4 > 0) {
         // the first two half-slabs: dense global_load_lds by everybody, once per group
         for (int c = 0; c < 2 * kFHalf; ++c)
@@ -1669,9 +1705,15 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
     for (int gi = 0; gi < g.dgroup; ++gi) {
       const int grp = grp_of(gi);
       Grp G;
+#ifdef SD_PROFILING
+      const long long ts_ = __builtin_readcyclecounter();
+#endif
       if (!group_begin(grp, G)) return;
+#ifdef SD_PROFILING
+      p_setup += __builtin_readcyclecounter() - ts_;
+#endif
       load_a(anxt, grp, 0, 0);
-      lds_barrier();   // (the producers' B(0))
+      SD_FBAR();   // (the producers' B(0))
       int k = 0, j = 0;
       for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -1704,7 +1746,7 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
             acc[i][q] = mfma16<kSplitF16>(acur[2 * i], bl[q], acc[i][q]);       // a_hi * b_lo
             acc[i][q] = mfma16<kSplitF16>(acur[2 * i], bh[q], acc[i][q]);       // a_hi * b_hi
           }
-        if (s + 1 < S) lds_barrier();
+        if (s + 1 < S) SD_FBAR();
         if (++j == 9) { j = 0; ++k; }
       }
     }
@@ -1727,38 +1769,53 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
     for (int gi = 0; gi < g.dgroup; ++gi) {
       const int grp = grp_of(gi);
       Grp G;
+#ifdef SD_PROFILING
+      const long long ts_ = __builtin_readcyclecounter();
+#endif
       if (!group_begin(grp, G)) return;
+#ifdef SD_PROFILING
+      p_setup += __builtin_readcyclecounter() - ts_;
+#endif
       const int wstride = G.wstride, wstart = G.wstart;
       const float* xg = G.xg;
       // unit u = 2 j + half of the pair's step j: half-slab (= window buffer) u / 9, tap u % 9
-      auto produce = [&](int pair, int j, int step) {   // pair: the actual pair (global path only), step: B parity
+      struct St { int tin; float a1, a2, a3, a4; };            // one unit's sampling state
+      struct Rd { float va[8], vb[8], vc[8], vd[8]; St st; };  // its sixteen corner pairs
+      auto read_state = [&](int j, St& st) {
         const int u = 2 * j + half, hl = u >= 9 ? 1 : 0, tap = u - 9 * hl;
-        const float* sp = sst + tap * 5 * (2 * kFN) + ptid;
-        const int tin = __float_as_int(sp[0]);
-        const float a1 = sp[2 * kFN], a2 = sp[2 * 2 * kFN], a3 = sp[3 * 2 * kFN], a4 = sp[4 * 2 * kFN];
-        const bool inside = (tin & kDcnInside) != 0;
+        const float* sp = sst + tap * 5 * kFN + pl;
+        st.tin = __float_as_int(sp[0]) | (hl << 31);   // (bit 31: the window buffer)
+        st.a1 = sp[kFN]; st.a2 = sp[2 * kFN]; st.a3 = sp[3 * kFN]; st.a4 = sp[4 * kFN];
+      };
+      // the sixteen pair reads of one unit go out ...
+      auto issue = [&](int pair, const St& st, Rd& r) {
+        r.st = st;
+        const int tin = st.tin, hl = (unsigned)tin >> 31;
         const int o1 = tin & 0xfffffff;
-        const bool dw = (tin >> 28) & 1;
         const int o2 = o1 + (((tin >> 29) & 1) ? g.W : 0);   // second corner row (the first again when clamped)
-        float va[8], vb[8], vc[8], vd[8];
         if (LDSX) {
           const float* xw = xs + hl * kFHalf * wstride;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {   // all sixteen pair reads go out before the arithmetic
-            va[c] = xw[c * wstride + o1]; vb[c] = xw[c * wstride + o1 + 1];
-            vc[c] = xw[c * wstride + o2]; vd[c] = xw[c * wstride + o2 + 1];
+          for (int c = 0; c < 8; ++c) {
+            r.va[c] = xw[c * wstride + o1]; r.vb[c] = xw[c * wstride + o1 + 1];
+            r.vc[c] = xw[c * wstride + o2]; r.vd[c] = xw[c * wstride + o2 + 1];
           }
         } else {
           // corners straight from global memory, every address inside the plane (window-relative
           // index made absolute, no "+ 1" past a clamp)
+          const bool inside = (tin & kDcnInside) != 0;
           const float* xc = xg + (long)((2 * pair + hl) * kFHalf) * plane;
-          const int g1 = inside ? o1 + wstart : 0, g2 = inside ? o2 + wstart : 0, d1 = dw ? 1 : 0;
+          const int g1 = inside ? o1 + wstart : 0, g2 = inside ? o2 + wstart : 0, d1 = (tin >> 28) & 1;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            va[c] = xc[(long)c * plane + g1]; vb[c] = xc[(long)c * plane + g1 + d1];
-            vc[c] = xc[(long)c * plane + g2]; vd[c] = xc[(long)c * plane + g2 + d1];
+            r.va[c] = xc[(long)c * plane + g1]; r.vb[c] = xc[(long)c * plane + g1 + d1];
+            r.vc[c] = xc[(long)c * plane + g2]; r.vd[c] = xc[(long)c * plane + g2 + d1];
           }
         }
+      };
+      // ... and are consumed one step later: interpolate (fused multiply-adds: within an ulp of
+      // sd_deform_im2col's value), scale + split into fp16 hi / lo, store the two granules of B(step)
+      auto finish = [&](const Rd& r, int step) {
         uint4 h4, l4;
         unsigned* hp = reinterpret_cast<unsigned*>(&h4);
         unsigned* lp = reinterpret_cast<unsigned*>(&l4);
@@ -1768,9 +1825,8 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int c = 2 * q + k;
-            const float x2 = dw ? vb[c] : va[c], x4 = dw ? vd[c] : vc[c];
-            const float r = (a1 * va[c] + a2 * x2 + a3 * vc[c] + a4 * x4);   // the im2col expression
-            v[k] = inside ? r : 0.f;
+            v[k] = __builtin_fmaf(r.st.a4, r.vd[c], __builtin_fmaf(r.st.a3, r.vc[c],
+                                  __builtin_fmaf(r.st.a2, r.vb[c], r.st.a1 * r.va[c])));
           }
           split2<true, kSplitF16>(v[0], v[1], sb, hp[q], lp[q]);
         }
@@ -1778,33 +1834,68 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
         *reinterpret_cast<uint4*>(bd) = h4;
         *reinterpret_cast<uint4*>(bd + kFN * 32) = l4;
       };
-      produce(pair_of(0), 0, 0);
-      lds_barrier();
-      int k = 0, j = 0;
-      for (int s = 0; s + 1 < S; ++s) {
-        if (++j == 9) { j = 0; ++k; }
+      // Pipeline: in iteration s the reads of step s + 2 are issued first, then step s + 1 (read in
+      // iteration s - 1) is finished under their latency; the state of step s + 3 is fetched behind them.
+      //   (pj, pk): (step in pair, pair) of the step whose STATE is fetched next
+      Rd ra, rb;
+      St st;
+      int pj = 0, pk = 0;
+      auto next_state = [&]() {   // the state of the next step of the walk (past the end: the last step again)
+        read_state(pj, st);
+        if (pk * 9 + pj + 1 < S) { if (++pj == 9) { pj = 0; ++pk; } }
+      };
+      auto pair_now = [&](int step) { const int k_ = step / 9; return pair_of(k_ < npair ? k_ : npair - 1); };
+      next_state();                        // state(0)
+      issue(pair_now(0), st, ra);          // reads(0)
+      next_state();                        // state(1)
+      finish(ra, 0);                       // B(0)
+      issue(pair_now(1), st, rb);          // reads(1)   (S >= 9: step 1 exists)
+      next_state();                        // state(2)
+      SD_FBAR();
+      for (int s = 0;;) {   // S - 1 iterations (= barriers), two per trip: the read buffers alternate
+        if (s + 1 >= S) break;
+        issue(pair_now(s + 2), st, ra);   // reads(s + 2)   (past the end: the last step again, unused)
+        next_state();
+        __builtin_amdgcn_sched_barrier(0);   // (all reads out before the arithmetic on the other buffer starts)
 #ifdef SD_PROFILING
         if (!(a.ablate & 1))
 #endif
-        produce(pair_of(k), j, s + 1);
-        lds_barrier();
+        finish(rb, s + 1);                // B(s + 1)
+        SD_FBAR();
+        ++s;
+        if (s + 1 >= S) break;
+        issue(pair_now(s + 2), st, rb);
+        next_state();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef SD_PROFILING
+        if (!(a.ablate & 1))
+#endif
+        finish(ra, s + 1);
+        SD_FBAR();
+        ++s;
       }
     }
   } else {
     // ================= loader wave: the ring of half-slab windows =====================================
     // One piece = two channel windows per step, loaded into registers in step s and stored to LDS
     // at the top of step s + 1 (a whole step hides the load latency; the step barrier never waits
-    // for memory).  Buffer 0 is last sampled for step j = 4 of a pair (under step 3): half-slab
-    // 2 pair + 2 is loaded in steps 3..6 and stored in steps 4..7, in time for the sampling of the
-    // next pair's step 0 (under step 8).  Buffer 1 is last sampled under step 7: the pieces of the
-    // half-slab after next are loaded in steps 7, 8 and the next pair's 0, 1, stored one step later
-    // each, in time for the sampling of that pair's step 4 (under its step 3).
+    // for memory).  The schedule follows from when the sampling waves read a buffer last (see the
+    // step loop below).
+    // (measured alternatives: global memory straight to LDS -- a half-slab at once, or three channel
+    // windows per step -- is slower, 0.48 against 0.45 ms: a single wave issues those at ~100 clocks
+    // each; as 4-byte pieces, 0.70 ms)
     for (int gi = 0; gi < g.dgroup; ++gi) {
       const int grp = grp_of(gi);
       Grp G;
+#ifdef SD_PROFILING
+      const long long ts_ = __builtin_readcyclecounter();
+#endif
       if (!group_begin(grp, G)) return;
+#ifdef SD_PROFILING
+      p_setup += __builtin_readcyclecounter() - ts_;
+#endif
       const int wstride = G.wstride, n4 = G.n4, nw = 2 * G.n4;
-      lds_barrier();   // (the producers' B(0))
+      SD_FBAR();   // (the producers' B(0))
       int pair = 0, j = 0;
       u32x4 stg[kFStage];
       float* pend = nullptr;   // where the piece in flight goes (null: none)
@@ -1820,10 +1911,15 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
           pend = nullptr;
         }
         // (pair = position in the walk; lh = position of the half-slab in the walk, -1: nothing to load)
+        // (the sampling waves issue the reads of step X in iteration X - 2 and have them back by that
+        // iteration's barrier: buffer 0, last read for step 4, may be overwritten from iteration 3 on
+        // and must be complete by the end of iteration 6; buffer 1, last read for step 8, from
+        // iteration 7 on, complete by the end of the next pair's iteration 1.  A piece loaded in
+        // iteration j is stored at the top of iteration j + 1.)
         int lh = -1, piece = 0, lbuf = 0;
-        if (j >= 3 && j <= 6) { lh = 2 * pair + 2; piece = j - 3; lbuf = 0; }
-        else if (j >= 7) { lh = 2 * pair + 3; piece = j - 7; lbuf = 1; }
-        else if (j <= 1 && pair > 0) { lh = 2 * pair + 1; piece = j + 2; lbuf = 1; }
+        if (j >= 2 && j <= 5) { lh = 2 * pair + 2; piece = j - 2; lbuf = 0; }
+        else if (j >= 6) { lh = 2 * pair + 3; piece = j - 6; lbuf = 1; }
+        else if (j == 0 && pair > 0) { lh = 2 * pair + 1; piece = 3; lbuf = 1; }
 #ifdef SD_PROFILING
         if (a.ablate & 4) lh = -1;
 #endif
@@ -1838,11 +1934,17 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
             stg[k] = *reinterpret_cast<const u32x4*>(src + (long)cc * plane + 4 * idx);
           }
         }
-        if (s + 1 < S) lds_barrier();
+        if (s + 1 < S) SD_FBAR();
         if (++j == 9) { j = 0; ++pair; }
       }
     }
   }
+#ifdef SD_PROFILING
+  if (a.dbg && lane == 0) {
+    long long* d = a.dbg + ((long)blockIdx.x * 8 + wave) * 4;
+    d[0] = __builtin_readcyclecounter() - p_begin; d[1] = p_wait; d[2] = p_setup; d[3] = wave;
+  }
+#endif
 }
 
 static int make_geom(DcnGeom& g, int N, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
@@ -2148,6 +2250,11 @@ extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, con
   SD_REQUIRE((long)a.tiles_per_image * 8 * cdiv(N, 8) * mtiles < (1L << 31), "too many tiles");
   a.flags = reinterpret_cast<int*>(amax + 64);   // (behind the maxima: 256 bytes into the 512 of slack)
   a.ablate = SD_PROF_TUNING("dcn_fused_ablate", 0);
+  a.dbg = nullptr;
+#ifdef SD_PROFILING
+  a.dbg = reinterpret_cast<long long*>(((uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_hi", 0) << 32) |
+                                       (uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_lo", 0));
+#endif
   static bool attr = false;
   if (!attr) {
     SD_HIP_CHECK(hipFuncSetAttribute((const void*)dcn_fwd_fused_kernel<true>,

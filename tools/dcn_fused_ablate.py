@@ -12,6 +12,7 @@ def t(fn, it=10):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
+torch.manual_seed(0)
 N, C, H, W, F = 16, 256, 50, 84, 256
 x = torch.randn(N, C, H, W, device="cuda"); off = torch.randn(N, 72, H, W, device="cuda") * 2; wt = torch.randn(F, C, 3, 3, device="cuda") * 0.05
 for ab in (0, 31, 1, 2, 4, 8, 16):
