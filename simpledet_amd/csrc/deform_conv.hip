@@ -1418,13 +1418,17 @@ static void launch_absmax(const float* p, long rows, int cols, long ld, long bst
 //   slow, but exact, and launched over the flagged tiles only.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// LDS slot of window position p: positions are permuted inside groups of four by the group's number,
+// so that the loader's transposed stores (four consecutive groups at a time) land on 32 different banks
+__device__ __forceinline__ int fslot(int p) { return p ^ ((p >> 2) & 3); }
 constexpr int kFN = 96;            // pixel slots of a tile (3 x 32)
 constexpr int kFHalf = 8;          // channels per half-slab
 constexpr int kFThreads = 512;    // 4 matrix-core waves + 3 sampling waves + 1 loader wave
 constexpr int kFBBytes = 2 * 2 * kFN * 16 * 2;   // B tile: 2 buffers x (hi, lo) x 96 x 16 halves = 12 KB
-constexpr int kFStateBytes = 9 * 5 * kFN * 4;   // sampling state of 96 pixels x 9 taps x 5 words = 17.3 KB
-constexpr int kFXFloats = 33280;   // 130 KB of x windows: two half-slab buffers
-constexpr int kFStage = 16;        // 16-byte words per lane the loader wave moves per step (two channel windows)
+constexpr int kFStateBytes = 9 * 6 * kFN * 4;   // sampling state of 96 pixels x 9 taps x 6 words = 20.7 KB
+constexpr int kFXFloats = 32512;   // 127 KB of x windows: two half-slab buffers
+constexpr int kFStage = 16;        // 16-byte words per lane the loader wave moves per step (a quarter of a half-slab)
 constexpr int kFSmemBytes = kFBBytes + kFStateBytes + kFXFloats * 4 + 64 + 64;
 
 struct DcnFusedArgs {
@@ -1642,17 +1646,27 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
         }
       }
       if (producer) {
+        // state of (tap, pixel): three 8-byte words [tap][word][pixel].  Word 0 of the LDS instance: the
+        // window slots of the four corners, 16 bits each (the window fits the LDS, or the tile is
+        // flagged and this is never read); of the global-gather instance: the packed corner index
 #pragma unroll
         for (int i = 0; i < kT; ++i)
           if (i < ntap) {
-            float* d = sst + (tap0 + i) * 5 * kFN + pl;
-            d[0] = __int_as_float(info[i]);
-            d[kFN] = w1[i]; d[2 * kFN] = w2[i]; d[3 * kFN] = w3[i]; d[4 * kFN] = w4[i];
+            int wa = info[i], wb = 0;
+            if (LDSX) {
+              const int o1 = info[i] & 0xfffffff, o2 = o1 + (((info[i] >> 29) & 1) ? g.W : 0);
+              wa = fslot(o1) | (fslot(o1 + 1) << 16);
+              wb = fslot(o2) | (fslot(o2 + 1) << 16);
+            }
+            float2* d = reinterpret_cast<float2*>(sst) + (tap0 + i) * 3 * kFN + pl;
+            d[0] = make_float2(__int_as_float(wa), __int_as_float(wb));
+            d[kFN] = make_float2(w1[i], w2[i]);
+            d[2 * kFN] = make_float2(w3[i], w4[i]);
           }
       }
     }
-    // floats between the channel windows in LDS: the second corner row of a sample may start W past
-    // the first whatever the clamping, + 1 for the pair: a window is followed by W + 4 floats of slack
+    // positions behind a window in LDS: the second corner row of a sample may start W past the first
+    // whatever the clamping, + 1 for the pair: a window is followed by W + 4 positions of slack
     G.wstart = wstart;
     G.wstride = (wcount + g.W + 4 + 3) & ~3;
     G.n4 = wcount >> 2;
@@ -1666,17 +1680,34 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
         return false;
       }
       if (grp == 0 && tid == 0) *flag = 0;
-      // the W + 4 .. W + 7 floats of slack behind each of the 16 channel windows are read (with weight 0)
-      // by samples clamped at the border: keep them finite
+      // the W + 4 .. W + 7 positions of slack behind the two windows are read (with weight 0) by samples
+      // clamped at the border: keep them finite (whole groups of four positions: closed under fslot())
       {
-        const int sl_ = G.wstride - (G.n4 << 2);
-        for (int i = tid; i < 2 * kFHalf * sl_; i += kFThreads)
-          xs[(i / sl_) * G.wstride + (G.n4 << 2) + i % sl_] = 0.f;
+        const int sl_ = kFHalf * (G.wstride - (G.n4 << 2));
+        for (int i = tid; i < 2 * sl_; i += kFThreads)
+          xs[(i / sl_) * kFHalf * G.wstride + kFHalf * (G.n4 << 2) + i % sl_] = 0.f;
       }
-      if (G.n4 > 0) {
-        // the first two half-slabs: dense global_load_lds by everybody, once per group
-        for (int c = 0; c < 2 * kFHalf; ++c)
-          dcn_fill16(G.xg + (long)(pair_of(0) * 2 * kFHalf + c) * plane + wstart, G.n4, xs + c * G.wstride, wave, lane);
+      // the first two half-slabs, by everybody, once per group
+      {
+        // lane = (channel quad l & 1, position group l >> 1), as in the loader wave below; the 16 waves'
+        // worth of (half-slab, group) items are dealt round-robin
+        const int cq = lane & 1;
+        for (int it = wave; it < 2 * ((G.n4 + 31) >> 5); it += kFThreads / 64) {
+          const int hs = it & 1, i = (it >> 1) * 32 + (lane >> 1);
+          if (i < G.n4) {
+            const float* src = G.xg + (long)(pair_of(0) * 2 * kFHalf + hs * kFHalf + cq * 4) * plane + wstart + 4 * i;
+            f32x4 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const f32x4*>(src + (long)c * plane);
+            float* d = xs + hs * kFHalf * G.wstride + (4 * i) * kFHalf + cq * 4;
+            const int x_ = i & 3;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              f32x4 o; o[0] = v[0][jj]; o[1] = v[1][jj]; o[2] = v[2][jj]; o[3] = v[3][jj];
+              *reinterpret_cast<f32x4*>(d + (jj ^ x_) * kFHalf) = o;
+            }
+          }
+        }
       }
     }
     // the windows and the state landed (every wave waits for its own fill loads)
@@ -1714,29 +1745,29 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
 #endif
       load_a(anxt, grp, 0, 0);
       SD_FBAR();   // (the producers' B(0))
-      int k = 0, j = 0;
-      for (int s = 0; s < S; ++s) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acur[i] = anxt[i];
-#ifdef SD_PROFILING
-        if (!(a.ablate & 8))
-#endif
-        load_a(anxt, grp, k, j + 1);
-        const char* bb_ = brd + (s & 1) * (kFBBytes / 2);
-        uint4 bh[3], bl[3];
+      // One step behind the B tiles: in interval s the fragments of B(s) are read (their LDS latency,
+      // behind the sampling waves' reads in the same queue, is hidden) while the matrix cores work on
+      // step s - 1 from registers.  B(s) is in registers by the interval's barrier, so its LDS buffer is
+      // free for B(s + 2) exactly as before.
+      uint4 bh[3], bl[3], nh_[3], nl_[3];
+      auto read_b = [&](int st, uint4 (&h)[3], uint4 (&l)[3]) {
+        const char* bb_ = brd + (st & 1) * (kFBBytes / 2);
 #ifdef SD_PROFILING
         if (a.ablate & 16) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) bh[q] = bl[q] = acur[q];
-        } else
+          for (int q = 0; q < 3; ++q) h[q] = l[q] = acur[q];
+          return;
+        }
 #endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          bh[q] = *reinterpret_cast<const uint4*>(bb_ + q * 512);
-          bl[q] = *reinterpret_cast<const uint4*>(bb_ + kFN * 32 + q * 512);
+          h[q] = *reinterpret_cast<const uint4*>(bb_ + q * 512);
+          l[q] = *reinterpret_cast<const uint4*>(bb_ + kFN * 32 + q * 512);
         }
+      };
+      auto mma = [&]() {
 #ifdef SD_PROFILING
-        if (!(a.ablate & 2))
+        if (a.ablate & 2) return;
 #endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1746,9 +1777,32 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
             acc[i][q] = mfma16<kSplitF16>(acur[2 * i], bl[q], acc[i][q]);       // a_hi * b_lo
             acc[i][q] = mfma16<kSplitF16>(acur[2 * i], bh[q], acc[i][q]);       // a_hi * b_hi
           }
+      };
+      auto next_a = [&](int k, int j) {   // acur = A(step), then the load of A(step + 1) goes out
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acur[i] = anxt[i];
+#ifdef SD_PROFILING
+        if (!(a.ablate & 8))
+#endif
+        load_a(anxt, grp, k, j + 1);
+      };
+      int k = 0, j = 0;
+      read_b(0, nh_, nl_);
+      next_a(k, j);
+      if (++j == 9) { j = 0; ++k; }
+      if (S > 1) SD_FBAR();
+      for (int s = 1; s < S; ++s) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { bh[q] = nh_[q]; bl[q] = nl_[q]; }
+        read_b(s, nh_, nl_);
+        mma();             // step s - 1
+        next_a(k, j);      // A(s)
         if (s + 1 < S) SD_FBAR();
         if (++j == 9) { j = 0; ++k; }
       }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { bh[q] = nh_[q]; bl[q] = nl_[q]; }
+      mma();               // step S - 1
     }
     // ---- y[n, f, p] = acc / (s_w s_x): D layout of a 32x32 tile: element e of lane l -> row
     // (e / 4) * 8 + (l / 32) * 4 + e % 4, column l % 32 ----
@@ -1779,37 +1833,39 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
       const int wstride = G.wstride, wstart = G.wstart;
       const float* xg = G.xg;
       // unit u = 2 j + half of the pair's step j: half-slab (= window buffer) u / 9, tap u % 9
-      struct St { int tin; float a1, a2, a3, a4; };            // one unit's sampling state
-      struct Rd { float va[8], vb[8], vc[8], vd[8]; St st; };  // its sixteen corner pairs
+      struct St { int wa, wb, hl; float a1, a2, a3, a4; };     // one unit's sampling state (hl: the window buffer)
+      struct Rd { f32x4 va[2], vb[2], vc[2], vd[2]; St st; };  // its four corners x eight channels
       auto read_state = [&](int j, St& st) {
         const int u = 2 * j + half, hl = u >= 9 ? 1 : 0, tap = u - 9 * hl;
-        const float* sp = sst + tap * 5 * kFN + pl;
-        st.tin = __float_as_int(sp[0]) | (hl << 31);   // (bit 31: the window buffer)
-        st.a1 = sp[kFN]; st.a2 = sp[2 * kFN]; st.a3 = sp[3 * kFN]; st.a4 = sp[4 * kFN];
+        const float2* sp = reinterpret_cast<const float2*>(sst) + tap * 3 * kFN + pl;
+        const float2 q0 = sp[0], q1 = sp[kFN], q2 = sp[2 * kFN];
+        st.wa = __float_as_int(q0.x); st.wb = __float_as_int(q0.y); st.hl = hl;
+        st.a1 = q1.x; st.a2 = q1.y; st.a3 = q2.x; st.a4 = q2.y;
       };
-      // the sixteen pair reads of one unit go out ...
+      // the eight 16-byte reads of one unit (a corner's eight channels lie side by side) go out ...
       auto issue = [&](int pair, const St& st, Rd& r) {
         r.st = st;
-        const int tin = st.tin, hl = (unsigned)tin >> 31;
-        const int o1 = tin & 0xfffffff;
-        const int o2 = o1 + (((tin >> 29) & 1) ? g.W : 0);   // second corner row (the first again when clamped)
         if (LDSX) {
-          const float* xw = xs + hl * kFHalf * wstride;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            r.va[c] = xw[c * wstride + o1]; r.vb[c] = xw[c * wstride + o1 + 1];
-            r.vc[c] = xw[c * wstride + o2]; r.vd[c] = xw[c * wstride + o2 + 1];
-          }
+          const char* xb = reinterpret_cast<const char*>(xs) + st.hl * (kFHalf * 4 * wstride);
+          const f32x4* c1 = reinterpret_cast<const f32x4*>(xb + (st.wa & 0xffff) * (kFHalf * 4));
+          const f32x4* c2 = reinterpret_cast<const f32x4*>(xb + ((unsigned)st.wa >> 16) * (kFHalf * 4));
+          const f32x4* c3 = reinterpret_cast<const f32x4*>(xb + (st.wb & 0xffff) * (kFHalf * 4));
+          const f32x4* c4 = reinterpret_cast<const f32x4*>(xb + ((unsigned)st.wb >> 16) * (kFHalf * 4));
+          r.va[0] = c1[0]; r.va[1] = c1[1]; r.vb[0] = c2[0]; r.vb[1] = c2[1];
+          r.vc[0] = c3[0]; r.vc[1] = c3[1]; r.vd[0] = c4[0]; r.vd[1] = c4[1];
         } else {
           // corners straight from global memory, every address inside the plane (window-relative
           // index made absolute, no "+ 1" past a clamp)
+          const int tin = st.wa;
+          const int o1 = tin & 0xfffffff;
+          const int o2 = o1 + (((tin >> 29) & 1) ? g.W : 0);   // second corner row (the first again when clamped)
           const bool inside = (tin & kDcnInside) != 0;
-          const float* xc = xg + (long)((2 * pair + hl) * kFHalf) * plane;
+          const float* xc = xg + (long)((2 * pair + st.hl) * kFHalf) * plane;
           const int g1 = inside ? o1 + wstart : 0, g2 = inside ? o2 + wstart : 0, d1 = (tin >> 28) & 1;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            r.va[c] = xc[(long)c * plane + g1]; r.vb[c] = xc[(long)c * plane + g1 + d1];
-            r.vc[c] = xc[(long)c * plane + g2]; r.vd[c] = xc[(long)c * plane + g2 + d1];
+            r.va[c >> 2][c & 3] = xc[(long)c * plane + g1]; r.vb[c >> 2][c & 3] = xc[(long)c * plane + g1 + d1];
+            r.vc[c >> 2][c & 3] = xc[(long)c * plane + g2]; r.vd[c >> 2][c & 3] = xc[(long)c * plane + g2 + d1];
           }
         }
       };
@@ -1825,8 +1881,8 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int c = 2 * q + k;
-            v[k] = __builtin_fmaf(r.st.a4, r.vd[c], __builtin_fmaf(r.st.a3, r.vc[c],
-                                  __builtin_fmaf(r.st.a2, r.vb[c], r.st.a1 * r.va[c])));
+            v[k] = __builtin_fmaf(r.st.a4, r.vd[c >> 2][c & 3], __builtin_fmaf(r.st.a3, r.vc[c >> 2][c & 3],
+                                  __builtin_fmaf(r.st.a2, r.vb[c >> 2][c & 3], r.st.a1 * r.va[c >> 2][c & 3])));
           }
           split2<true, kSplitF16>(v[0], v[1], sb, hp[q], lp[q]);
         }
@@ -1877,13 +1933,17 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
     }
   } else {
     // ================= loader wave: the ring of half-slab windows =====================================
-    // One piece = two channel windows per step, loaded into registers in step s and stored to LDS
-    // at the top of step s + 1 (a whole step hides the load latency; the step barrier never waits
-    // for memory).  The schedule follows from when the sampling waves read a buffer last (see the
-    // step loop below).
-    // (measured alternatives: global memory straight to LDS -- a half-slab at once, or three channel
-    // windows per step -- is slower, 0.48 against 0.45 ms: a single wave issues those at ~100 clocks
-    // each; as 4-byte pieces, 0.70 ms)
+    // One piece = a quarter of a half-slab's positions (all eight channels) per step, loaded into
+    // registers in step s and stored to LDS at the top of step s + 1 (a whole step hides the load
+    // latency; the step barrier never waits for memory).  Lane = (channel quad l & 1, position group
+    // l >> 1): four wave-wide loads take 512 contiguous bytes of each of the quad's four channel
+    // planes, and a lane's 4 x 4 block goes to LDS transposed, as four 16-byte stores of one position's
+    // four channels into [slot][channel] (fslot() spreads the 8 lanes of a store phase over the 32
+    // banks).  The schedule follows from when the sampling waves read a buffer last (see the step
+    // loop below).
+    // (measured alternatives on the channel-planar layout: global memory straight to LDS -- a half-slab
+    // at once, or three channel windows per step -- is slower, 0.48 against 0.45 ms: a single wave
+    // issues those at ~100 clocks each; as 4-byte pieces, 0.70 ms)
     for (int gi = 0; gi < g.dgroup; ++gi) {
       const int grp = grp_of(gi);
       Grp G;
@@ -1894,48 +1954,70 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
 #ifdef SD_PROFILING
       p_setup += __builtin_readcyclecounter() - ts_;
 #endif
-      const int wstride = G.wstride, n4 = G.n4, nw = 2 * G.n4;
+      const int wstride = G.wstride, n4 = G.n4, Q = (n4 + 3) >> 2;   // Q: four-position groups of a piece
+      const int cq = lane & 1, lg = lane >> 1;
       SD_FBAR();   // (the producers' B(0))
-      int pair = 0, j = 0;
-      u32x4 stg[kFStage];
-      float* pend = nullptr;   // where the piece in flight goes (null: none)
-      for (int s = 0; s < S; ++s) {
-        if (pend) {
+      // Two pieces in flight: the piece loaded in iteration s is stored at the top of iteration s + 2
+      // from the register set of s's parity (two named sets and a loop unrolled by two: a
+      // run-time-indexed set would live in scratch memory).
+      //   (the sampling waves issue the reads of step X in iteration X - 2 and have them back by that
+      //   iteration's barrier: buffer 0, last read for step 4, may be overwritten from iteration 3 on
+      //   and must be complete by the end of iteration 6; buffer 1, last read for step 8, from
+      //   iteration 7 on, complete by the end of the next pair's iteration 1.  Stores at the tops of
+      //   iterations 3..6 and 7, 8, 0', 1': loads in iterations 1..4 and 5..8.)
+      struct Pc { u32x4 stg[kFStage]; float* pend; int pend_i; };   // stg: [unit of 32 groups][channel of the quad]
+      Pc pa, pb;
+      pa.pend = pb.pend = nullptr;   // where the piece goes: slot 4 * (first group), this lane's channel quad
+      pa.pend_i = pb.pend_i = 0;     // its first group + lg
+      auto lstep = [&](Pc& pc, int pair, int j) {
+        if (pc.pend) {
+          const int x_ = pc.pend_i & 3;
+          float* d = pc.pend + lg * (4 * kFHalf);
 #pragma unroll
-          for (int k = 0; k < kFStage; ++k) {   // (lanes past the end rewrite the last word with the same data)
-            int i = lane + 64 * k;
-            i = i < nw ? i : nw - 1;
-            const int cc = i >= n4 ? 1 : 0, idx = i - cc * n4;
-            *reinterpret_cast<u32x4*>(pend + cc * wstride + 4 * idx) = stg[k];
+          for (int u = 0; u < kFStage / 4; ++u) {
+            if (32 * u >= Q) break;   // (wave-uniform: a piece of a small window has fewer units)
+            if (32 * u + lg < Q && pc.pend_i + 32 * u < n4) {
+              float* du = d + u * (32 * 4 * kFHalf);
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                u32x4 o; o[0] = pc.stg[4 * u][jj]; o[1] = pc.stg[4 * u + 1][jj]; o[2] = pc.stg[4 * u + 2][jj]; o[3] = pc.stg[4 * u + 3][jj];
+                *reinterpret_cast<u32x4*>(du + (jj ^ x_) * kFHalf) = o;
+              }
+            }
           }
-          pend = nullptr;
+          pc.pend = nullptr;
         }
         // (pair = position in the walk; lh = position of the half-slab in the walk, -1: nothing to load)
-        // (the sampling waves issue the reads of step X in iteration X - 2 and have them back by that
-        // iteration's barrier: buffer 0, last read for step 4, may be overwritten from iteration 3 on
-        // and must be complete by the end of iteration 6; buffer 1, last read for step 8, from
-        // iteration 7 on, complete by the end of the next pair's iteration 1.  A piece loaded in
-        // iteration j is stored at the top of iteration j + 1.)
         int lh = -1, piece = 0, lbuf = 0;
-        if (j >= 2 && j <= 5) { lh = 2 * pair + 2; piece = j - 2; lbuf = 0; }
-        else if (j >= 6) { lh = 2 * pair + 3; piece = j - 6; lbuf = 1; }
-        else if (j == 0 && pair > 0) { lh = 2 * pair + 1; piece = 3; lbuf = 1; }
+        if (j >= 1 && j <= 4) { lh = 2 * pair + 2; piece = j - 1; lbuf = 0; }
+        else if (j >= 5) { lh = 2 * pair + 3; piece = j - 5; lbuf = 1; }
 #ifdef SD_PROFILING
         if (a.ablate & 4) lh = -1;
 #endif
         if (LDSX && lh >= 0 && lh < nh && n4 > 0) {
-          const float* src = G.xg + (long)((2 * pair_of(lh >> 1) + (lh & 1)) * kFHalf + 2 * piece) * plane + G.wstart;
-          pend = xs + (lbuf * kFHalf + 2 * piece) * wstride;
+          const float* src = G.xg + (long)((2 * pair_of(lh >> 1) + (lh & 1)) * kFHalf + cq * 4) * plane + G.wstart;
+          pc.pend_i = piece * Q + lg;
+          pc.pend = xs + lbuf * kFHalf * wstride + (4 * piece * Q) * kFHalf + cq * 4;
 #pragma unroll
-          for (int k = 0; k < kFStage; ++k) {
-            int i = lane + 64 * k;
-            i = i < nw ? i : nw - 1;
-            const int cc = i >= n4 ? 1 : 0, idx = i - cc * n4;
-            stg[k] = *reinterpret_cast<const u32x4*>(src + (long)cc * plane + 4 * idx);
+          for (int u = 0; u < kFStage / 4; ++u) {
+            if (32 * u >= Q) break;
+            int i = pc.pend_i + 32 * u;
+            i = i < n4 ? i : n4 - 1;   // (past the end: loaded in vain, not stored)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pc.stg[4 * u + c] = *reinterpret_cast<const u32x4*>(src + (long)c * plane + 4 * i);
           }
         }
+      };
+      int pair = 0, j = 0;
+      for (int s = 0; s < S;) {
+        lstep(pa, pair, j);
         if (s + 1 < S) SD_FBAR();
         if (++j == 9) { j = 0; ++pair; }
+        if (++s >= S) break;
+        lstep(pb, pair, j);
+        if (s + 1 < S) SD_FBAR();
+        if (++j == 9) { j = 0; ++pair; }
+        ++s;
       }
     }
   }

@@ -2,7 +2,7 @@ import torch, sys
 sys.path.insert(0,".")
 from simpledet_amd import ops
 from simpledet_amd._lib import lib
-def t(fn,it=10):
+def t(fn,it=40):
     fn(); torch.cuda.synchronize()
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
     e0.record()
