@@ -353,6 +353,11 @@ def run(seed=0, cpu=True, only=None):
         # forward (sd_deform_conv_fwd, what a training step that keeps col for its backward runs) beside it
         ms_f = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4), iters=10, warm=2)
         ms_fu = _time_gpu(lambda: ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4, keep_col=True), iters=10, warm=2)
+        # the same layer with offsets of half a pixel (what a trained offset branch emits; sigma = 2 above is
+        # the stress case: 15-row windows per tile, LDS bank conflicts of random taps)
+        off_s = off * 0.25
+        ms_fs = _time_gpu(lambda: ops.deform_conv_forward(x, off_s, wt, 1, 1, 1, 4), iters=10, warm=2)
+        del off_s
         y = ops.deform_conv_forward(x, off, wt, 1, 1, 1, 4)
         dyc = torch.randn_like(y)
         grads = (torch.empty_like(x), torch.empty_like(off), torch.empty_like(wt))
@@ -383,12 +388,12 @@ def run(seed=0, cpu=True, only=None):
             "im2col_ms": ms_i, "im2col_GBs": im2col_bytes / ms_i / 1e6,
             "im2col_frac": im2col_bytes / ms_i / 1e6 / PEAK_HBM_GBS,
             "col2im_ms": ms_c2i, "col2im_coord_ms": ms_crd,
-            "fwd_ms": ms_f, "bwd_ms": ms_b, "bwd_with_forward_col_ms": ms_bc, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
+            "fwd_ms": ms_f, "fwd_ms_offsets_sigma_0p5": ms_fs, "bwd_ms": ms_b, "bwd_with_forward_col_ms": ms_bc, "gemm_ms": gemm_ms, "gemm_TFLOPs": flops / gemm_ms / 1e9,
             # fp32 products as three fp16 MFMA terms (scaled hi/lo split): 3 x the flops on the f16 pipe
             "gemm_arith": "fp32 in/out, 3 f16 MFMA terms per product of a scaled hi/lo split (deform_gemm_split=2)",
             "gemm_frac_of_bf16_mfma_peak": 3.0 * flops / gemm_ms / 1e9 / PEAK_BF16_MFMA_TFLOPS,
             "gemm_vs_f32_mfma_peak": flops / gemm_ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
-            "config": "x (16,256,50,84), 3x3 pad 1, 4 deformable groups, 256 filters, fp32"}
+            "config": "x (16,256,50,84), 3x3 pad 1, 4 deformable groups, 256 filters, fp32, offsets ~ N(0, 2^2)"}
         if orc:
             # every image of the batch against the oracle, north_star's ABSOLUTE bar: 1e-4 wherever the
             # values stay within |y| <= 32, scaled with the magnitude above that (tests/test_deform_conv.py)

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_deform_conv.py tests/test_redzone.py tests/test_mxnet_plugin.py -q -m gpu 2>&1 | tail -4
+for ab in 0 60 63; do echo "== ablate $ab"; bash tools/kt_ops.sh ktdcn$ab deform_conv dcn_fused_ablate=$ab 2>&1 | grep "gemm_pre\|gemm_prep"; done
