@@ -185,7 +185,11 @@ int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const 
  *     sd_set_tuning("roi_align_bwd_packed", 0)   (packed arg-max)
  *     sd_set_tuning("roi_align_bwd", 1) + sd_set_tuning("roi_align_bwd_accum", 0)   (float arg-max planes)
  * at ~1.3-2.5 x the time; those paths sum in the order the hardware serves the adds, like the
- * reference. */
+ * reference.
+ *   EXCEPTION: sd_roi_align_v2_bwd on a single map with C % 4 == 0 whose four planes fit 72 KB of LDS
+ * (the C4 family) runs roi_align_bwd_flt4_kernel by default, which already sums with fp32
+ * compare-and-swap adds in hardware order: fp32-relative accuracy, NOT bit-reproducible run to run.
+ * sd_set_tuning("roi_align_bwd_flt4", 0) selects the banded fixed-point kernel there too. */
 /* The same with a device workspace of sd_fpn_roi_align_bwd_workspace_bytes(): the per-band RoI
  * lists are then built by one small pre-pass instead of by every channel's workgroup (same
  * results bit for bit).  workspace may be NULL (= the call above). */

@@ -6,6 +6,8 @@ Each function mirrors the symbol constructor of the same name in the reference g
 `X.roi_align`): same argument names and meaning, same visible outputs.  Forward and backward both
 go through the HIP C ABI (simpledet_amd.ops); there is no CPU path.
 """
+import os
+
 import torch
 
 from . import ops
@@ -102,8 +104,13 @@ class _DeformConv(torch.autograd.Function):
     def forward(ctx, data, offset, weight, pad, stride, dilate, dg):
         ctx.save_for_backward(data, offset, weight)
         ctx.cfg = (pad, stride, dilate, dg)
-        # the col matrix stays alive for the backward (which then skips its own im2col)
-        y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg, keep_col=True)
+        # the col matrix stays alive for the backward (which then skips its own im2col): 620 MB per
+        # layer at (16,256,50,84).  SIMPLEDET_AMD_DCN_CACHE_COL=0 turns that off process-wide: the forward
+        # then is the col-free fused kernel and the backward recomputes col.
+        if os.environ.get("SIMPLEDET_AMD_DCN_CACHE_COL", "1") != "0":
+            y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg, keep_col=True)
+        else:
+            y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg), None
         return y
 
     @staticmethod

@@ -21,6 +21,7 @@ NULL stream -> sd_stream_synchronize before forward()/backward() return, because
 CustomOp's outputs as written when the callback returns (threading).
 """
 import ctypes
+import os
 from ast import literal_eval
 
 from ._lib import SD_ERR_UNSUPPORTED, SimpleDetOpsError, lib
@@ -689,7 +690,10 @@ def _build_ops(mx):
             if s[0] != s[1] or d[0] != d[1] or p[0] != p[1]:
                 raise ValueError("DeformableConvolution: square stride/dilate/pad only")
             self.g = dict(kh=k[0], kw=k[1], stride=s[0], dil=d[0], pad=p[0], F=int(num_filter),
-                          dg=int(num_deformable_group), cache_col=_bool(cache_col))
+                          dg=int(num_deformable_group),
+                          # SIMPLEDET_AMD_DCN_CACHE_COL=0: process-wide off switch (no node keeps 620 MB
+                          # between its forward and backward, whatever its attribute says)
+                          cache_col=_bool(cache_col) and os.environ.get("SIMPLEDET_AMD_DCN_CACHE_COL", "1") != "0")
 
         def list_arguments(self):
             return ["data", "offset", "weight"]
