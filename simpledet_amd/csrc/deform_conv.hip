@@ -224,20 +224,123 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
 // channel planes in LDS, works the four (LDS index, weight) pairs out once per (tap, pixel) and
 // applies them to the CC col values -- read as 16-byte loads, four pixels per lane.
 //   grid: x = channel chunk, y = band, z = image; LDS = CC * band floats
-template <int CC, int T>
+//
+// FX (round 4): the sums in 32-bit fixed point with plain integer LDS adds (fire and forget) instead of
+// fp32 compare-and-swap loops -- 16 chained loops per sample were the kernel.  The unit needs a bound
+// on what a pixel can collect: |dcol| <= cmax (the maximum the producing GEMM's epilogue recorded) times
+// the largest sum of bilinear weights landing on one pixel, which depends on (image, group) only and
+// is bounded per tap by deform_col2im_wsum_kernel (sum over the taps of each tap's largest pile-up).
+// scale = the power of two that puts that bound below 2^29; one unit is then <= 2^-28 of the largest
+// possible sum, and the result does not depend on the order of the adds.  A non-finite bound (inf /
+// nan in dcol) keeps the compare-and-swap adds, which send inf / nan where the reference sends them.
+
+// where a sample lands: LDS index of the (floor, floor) corner relative to the band and the factors of
+// the two rows / two columns (0 for a corner that does not exist, lies outside the band or has weight 0)
+__device__ __forceinline__ void col2im_geom(const DcnGeom& g, float inv_h, float inv_w, int row0, int row1,
+                                            int& base, float (&fhv)[2], float (&fwv)[2]) {
+  // same arithmetic as deform_col2im_kernel above, as (index, weight) pairs
+  float ah = inv_h, aw = inv_w;
+  const bool inside = !(ah < 0 || ah > g.H || aw < 0 || aw > g.W);
+  int hl = (int)ah, wl = (int)aw, hh_, wh_;
+  if (hl >= g.H - 1) {
+    hh_ = hl = g.H - 1;
+    ah = (float)hl;
+  } else {
+    hh_ = hl + 1;
+  }
+  if (wl >= g.W - 1) {
+    wh_ = wl = g.W - 1;
+    aw = (float)wl;
+  } else {
+    wh_ = wl + 1;
+  }
+  const int fh = (int)floorf(inv_h), fw = (int)floorf(inv_w);
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int hh = fh + d;
+    const bool ok = inside && hh >= 0 && hh < g.H && fabsf(inv_h - hh) < 1 && hh >= row0 && hh < row1;
+    fhv[d] = !ok ? 0.f : hh == hl ? (hh + 1 - ah) : hh == hh_ ? (ah + 1 - hh) : 0.f;
+    const int ww = fw + d;
+    const bool okw = ww >= 0 && ww < g.W && fabsf(inv_w - ww) < 1;
+    fwv[d] = !okw ? 0.f : ww == wl ? (ww + 1 - aw) : ww == wh_ ? (aw + 1 - ww) : 0.f;
+  }
+  base = (fh - row0) * g.W + fw;
+}
+
+// per (tap, group, image): the largest sum of weights one pixel collects from this tap's samples, added
+// into wsum[image * dgroup + group] (zeroed by the caller).  LDS = H * W floats
+__global__ __launch_bounds__(512) void deform_col2im_wsum_kernel(const float* __restrict__ offset,
+                                                                 float* __restrict__ wsum, DcnGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];
+  __shared__ float s_max[8];
+  const int P = g.Ho * g.Wo, K2 = g.kh * g.kw, HW = g.H * g.W;
+  const int tap = blockIdx.x, grp = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+  for (int i = tid; i < HW; i += 512) plane[i] = 0.f;
+  __syncthreads();
+  const float* oh = offset + (((long)n * g.dgroup + grp) * 2 * K2 + 2 * tap) * P;
+  const float* ow = oh + P;
+  const int ti = tap / g.kw, tj = tap % g.kw;
+  for (int p = tid; p < P; p += 512) {
+    const int h_out = p / g.Wo, w_out = p - h_out * g.Wo;
+    const float inv_h = h_out * g.stride_h - g.pad_h + ti * g.dil_h + oh[p];
+    const float inv_w = w_out * g.stride_w - g.pad_w + tj * g.dil_w + ow[p];
+    int base;
+    float fhv[2], fwv[2];
+    col2im_geom(g, inv_h, inv_w, 0, g.H, base, fhv, fwv);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float w = fhv[d >> 1] * fwv[d & 1];
+      if (w != 0.f) lds_add_cas(plane + base + (d >> 1) * g.W + (d & 1), w);
+    }
+  }
+  __syncthreads();
+  float m = 0.f;
+  for (int i = tid; i < HW; i += 512) m = fmaxr(m, plane[i]);
+  m = wave_max_f32(m);
+  if ((tid & 63) == 0) s_max[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t = fmaxr(t, s_max[k]);
+    atomicAdd(wsum + (long)n * g.dgroup + grp, t);
+  }
+}
+
+template <int CC, int T, bool FX>
 __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __restrict__ col,
                                                                 const float* __restrict__ offset,
                                                                 float* __restrict__ dx, DcnGeom g,
-                                                                int band_rows, int req_add) {
+                                                                int band_rows, int req_add,
+                                                                const unsigned* __restrict__ cmax,
+                                                                const float* __restrict__ wsum) {
   extern __shared__ __attribute__((aligned(16))) float plane[];
   const int P = g.Ho * g.Wo, K2 = g.kh * g.kw;
   const int c0 = blockIdx.x * CC, n = blockIdx.z;
   const int row0 = blockIdx.y * band_rows, row1 = iminr(row0 + band_rows, g.H);
   const int band_elems = (row1 - row0) * g.W;
   const int tid = threadIdx.x;
-  for (int i = tid; i < CC * band_elems; i += T) plane[i] = 0.f;
+  for (int i = tid; i < CC * band_elems; i += T) plane[i] = 0.f;   // (0.f and 0 are the same bits)
   __syncthreads();
   const int cpg = g.C / g.dgroup, grp = c0 / cpg;
+  // fixed point: scale * (largest possible sum) < 2^29 (rounding of the individual adds and the slack of
+  // the fp32 weight sums stay far inside the remaining two bits)
+  bool fx = false;
+  float scale = 1.f;
+  if (FX) {
+    const float bound = __uint_as_float(cmax[0]) * wsum[(long)n * g.dgroup + grp];
+    const unsigned bb = __float_as_uint(bound);
+    const int e = (int)((bb >> 23) & 255);
+    if (bound == 0.f) {
+      fx = true;   // nothing but zeros can arrive
+    } else if (e != 255 && e != 0) {
+      int es = 127 + 28 - (e - 127);   // scale = 2^(28 - floor(log2 bound))
+      es = es > 254 ? 254 : es;
+      if (es >= 1) {
+        scale = __uint_as_float((unsigned)es << 23);
+        fx = true;
+      }
+    }
+  }
   const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P;
   const float* cp = col + ((long)n * g.C + c0) * K2 * P;
   const long cstride = (long)K2 * P;  // col elements per channel
@@ -264,34 +367,9 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
         }
         const float inv_h = h_in + i * g.dil_h + offset_h;
         const float inv_w = w_in + j * g.dil_w + offset_w;
-        // same arithmetic as deform_col2im_kernel above, as (index, weight) pairs
-        float ah = inv_h, aw = inv_w;
-        const bool inside = !(ah < 0 || ah > g.H || aw < 0 || aw > g.W);
-        int hl = (int)ah, wl = (int)aw, hh_, wh_;
-        if (hl >= g.H - 1) {
-          hh_ = hl = g.H - 1;
-          ah = (float)hl;
-        } else {
-          hh_ = hl + 1;
-        }
-        if (wl >= g.W - 1) {
-          wh_ = wl = g.W - 1;
-          aw = (float)wl;
-        } else {
-          wh_ = wl + 1;
-        }
-        const int fh = (int)floorf(inv_h), fw = (int)floorf(inv_w);
+        int base;
         float fhv[2], fwv[2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const int hh = fh + d;
-          const bool ok = inside && hh >= 0 && hh < g.H && fabsf(inv_h - hh) < 1 && hh >= row0 && hh < row1;
-          fhv[d] = !ok ? 0.f : hh == hl ? (hh + 1 - ah) : hh == hh_ ? (ah + 1 - hh) : 0.f;
-          const int ww = fw + d;
-          const bool okw = ww >= 0 && ww < g.W && fabsf(inv_w - ww) < 1;
-          fwv[d] = !okw ? 0.f : ww == wl ? (ww + 1 - aw) : ww == wh_ ? (aw + 1 - ww) : 0.f;
-        }
-        const int base = (fh - row0) * g.W + fw;
+        col2im_geom(g, inv_h, inv_w, row0, row1, base, fhv, fwv);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const float w = fhv[d >> 1] * fwv[d & 1];
@@ -300,7 +378,11 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc) {
               const float gv = e == 0 ? cv[cc].x : e == 1 ? cv[cc].y : e == 2 ? cv[cc].z : cv[cc].w;
-              lds_add_cas(q + cc * band_elems, w * gv);
+              if (FX && fx)
+                __hip_atomic_fetch_add(reinterpret_cast<int*>(q + cc * band_elems), __float2int_rn((w * gv) * scale),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              else
+                lds_add_cas(q + cc * band_elems, w * gv);
             }
           }
         }
@@ -308,10 +390,14 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
     }
   }
   __syncthreads();
+  const float unscale = 1.0f / scale;   // exact
   for (int cc = 0; cc < CC; ++cc) {
     float* d = dx + (((long)n * g.C + c0 + cc) * g.H + row0) * g.W;
     const float* pl = plane + cc * band_elems;
-    for (int i = tid; i < band_elems; i += T) d[i] = req_add ? d[i] + pl[i] : pl[i];
+    for (int i = tid; i < band_elems; i += T) {
+      const float v = (FX && fx) ? (float)__float_as_int(pl[i]) * unscale : pl[i];
+      d[i] = req_add ? d[i] + v : v;
+    }
   }
 }
 
@@ -698,6 +784,8 @@ struct GemmArgs {
   int whole, whole_blocks, ksplit;  // split kernel: tiles run whole, their blocks (padded), k slices of the rest
   int ablate;  // profiling build only: bit 0 skip the A prefetch, bit 1 skip the B prefetch
   const unsigned* amax;  // f16 split: bit patterns of max|A|, max|B| (upper bounds), device memory
+  unsigned* cmax;        // split kernel, optional: atomic max of the bit patterns of |C| as stored (an upper bound
+                         // of max|C| when tiles are cut into k slices: slice maximum x slices)
 };
 
 constexpr int BM = 128;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
@@ -1174,6 +1262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
     mfma_step();
   }
   // D layout of the 32x32 tile: element e of lane l -> row (e/4)*8 + (l/32)*4 + e%4, col l%32
+  float vmax = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1189,9 +1278,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
           if (piece || a.mode == 2) atomicAdd(c, v);
           else if (a.mode == 0) *c = v;
           else *c += v;
+          // (NaN: fmaxf would drop it -- keep it as +inf so that consumers of the maximum see "not finite")
+          const float av = fabsf(v);
+          vmax = av == av ? fmaxr(vmax, av) : __uint_as_float(0x7f800000u);
         }
       }
     }
+  if (a.cmax) {
+    if (piece) vmax *= (float)a.ksplit;
+    vmax = wave_max_f32(vmax);
+    if (lane == 0) atomicMax(a.cmax, __float_as_uint(vmax));
+  }
 }
 
 // zero the tiles that k slices add into (C = A.B with the last tiles cut along k)
@@ -2084,10 +2181,11 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
   return SD_OK;
 }
 
-extern "C" int sd_deform_col2im(const float* col, const float* offset, float* dx, int req, int N,
-                                int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
-                                int stride_h, int stride_w, int dil_h, int dil_w, int dgroup,
-                                void* stream) {
+// cmax / wsum (device; both or neither): bound of |col| and room for N * dgroup floats -- with them the
+// four-channel kernel sums in fixed point (deform_col2im_chunk_kernel<.., true>)
+static int col2im_impl(const float* col, const float* offset, float* dx, int req, int N, int C, int H, int W,
+                       int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
+                       int dgroup, void* stream, const unsigned* cmax, float* wsum) {
   DcnGeom g;
   if (int e = make_geom(g, N, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dgroup))
     return e;
@@ -2108,11 +2206,27 @@ extern "C" int sd_deform_col2im(const float* col, const float* offset, float* dx
         (((uintptr_t)col | (uintptr_t)offset) & 15) == 0 && (long)CC * rows4 * W * 4 <= 150 * 1024 &&
         nb4 <= 65535) {
       const size_t lds4 = (size_t)CC * rows4 * W * sizeof(float);
+      const size_t ldsw = (size_t)H * W * sizeof(float);
+      const bool fx = cmax && wsum && ldsw <= 150 * 1024 && kh * kw <= 65535 && tuning("dcn_col2im_fx", 1) == 1;
+      if (fx) {
+        SD_HIP_CHECK(hipMemsetAsync(wsum, 0, sizeof(float) * (size_t)N * dgroup, st));
+        if (ldsw > 64 * 1024)
+          SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_wsum_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+        hipLaunchKernelGGL(deform_col2im_wsum_kernel, dim3(kh * kw, dgroup, N), dim3(512), ldsw, st, offset, wsum, g);
+        if (lds4 > 64 * 1024)
+          SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T, true>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
+                           col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, cmax, wsum);
+        SD_LAUNCH_CHECK();
+        return SD_OK;
+      }
       if (lds4 > 64 * 1024)
-        SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T>,
+        SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T, false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-      hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
-                         col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0);
+      hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T, false>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
+                         col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, nullptr, nullptr);
       SD_LAUNCH_CHECK();
       return SD_OK;
     }
@@ -2133,6 +2247,14 @@ extern "C" int sd_deform_col2im(const float* col, const float* offset, float* dx
                      rows, req == SD_REQ_ADD ? 1 : 0);
   SD_LAUNCH_CHECK();
   return SD_OK;
+}
+
+extern "C" int sd_deform_col2im(const float* col, const float* offset, float* dx, int req, int N,
+                                int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                                int stride_h, int stride_w, int dil_h, int dil_w, int dgroup,
+                                void* stream) {
+  return col2im_impl(col, offset, dx, req, N, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
+                     dgroup, stream, nullptr, nullptr);
 }
 
 extern "C" int sd_deform_col2im_coord(const float* col, const float* x, const float* offset,
@@ -2170,7 +2292,8 @@ extern "C" int sd_deform_col2im_coord(const float* col, const float* x, const fl
 
 static int gemm_f32_impl(int transA, int transB, int M, int N, int K, const float* A, int lda,
                          long strideA, const float* B, int ldb, long strideB, float* C, int ldc,
-                         long strideC, int batch, int accumulate, const unsigned* amax, void* stream) {
+                         long strideC, int batch, int accumulate, const unsigned* amax, void* stream,
+                         unsigned* cmax = nullptr) {
   SD_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative dimension");
   SD_REQUIRE(accumulate >= 0 && accumulate <= 2, "accumulate must be 0, 1 or 2");
   if (M == 0 || N == 0 || batch == 0) return SD_OK;
@@ -2183,6 +2306,7 @@ static int gemm_f32_impl(int transA, int transB, int M, int N, int K, const floa
   g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
   g.mode = accumulate;
   g.amax = amax;
+  g.cmax = cmax;
   if (K == 0) {
     if (accumulate == 0)
       for (int b = 0; b < batch; ++b)
@@ -2379,20 +2503,28 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
   hipStream_t st = (hipStream_t)stream;
   // operand maxima for the scaled fp16 split: {max|W|, max|dY|, max|x| >= max|col|}
   unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
-  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
+  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 32, st));
   launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
   launch_absmax(out_grad, (long)N * F, P, P, 0, 1, amax + 1, st);
   launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 2, st);
+  // fixed-point col2im: max|dcol| out of the GEMM's epilogue (amax[4]) and N * dgroup weight-sum bounds
+  // (amax[8..]), all inside the 512 bytes of slack behind the col matrix
+  unsigned* cmax = nullptr;
+  float* wsum = nullptr;
+  if (8 + (long)N * dgroup <= 120 && tuning("deform_gemm_split", 2) >= 1) {
+    cmax = amax + 4;
+    wsum = reinterpret_cast<float*>(amax + 8);
+  }
   if (req_x != SD_REQ_NULL || req_offset != SD_REQ_NULL) {
     // dcol[n] (K x P) = W^T (K x F) . dY[n] (F x P)
     if (int e = gemm_f32_impl(1, 0, K, P, F, weight, K, 0, out_grad, P, (long)F * P, col, P,
-                              (long)K * P, N, 0, amax, stream))
+                              (long)K * P, N, 0, amax, stream, cmax))
       return e;
     if (int e = sd_deform_col2im_coord(col, x, offset, d_offset, req_offset, N, C, H, W, kh, kw, pad,
                                        pad, stride, stride, dil, dil, dgroup, stream))
       return e;
-    if (int e = sd_deform_col2im(col, offset, d_x, req_x, N, C, H, W, kh, kw, pad, pad, stride,
-                                 stride, dil, dil, dgroup, stream))
+    if (int e = col2im_impl(col, offset, d_x, req_x, N, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil,
+                            dgroup, stream, cmax, wsum))
       return e;
   }
   if (req_weight != SD_REQ_NULL) {

@@ -75,6 +75,7 @@ Knob g_knobs[] = {
     {"dcn_im2col_nt", 0, false},     // bit 0: non-temporal col stores (default 1); bits 1-2 exist in the profiling build only
     {"dcn_window", 0, false},        // 1 stage only the touched range of each plane (default)
     {"dcn_col2im", 0, false},        // 1 four channels per workgroup, shared sample geometry (default), 0 one channel
+    {"dcn_col2im_fx", 0, false},     // 1 (default): the layer's backward sums dX in fixed point (integer LDS adds), 0 fp32 compare-and-swap
     {"dcn_coord", 0, false},         // 1 LDS-plane offset gradient (default), 0 per-lane gathers
     {"dcn_fused", 0, false},         // 1 (default): the col-free entry points sample inside the GEMM; 0: im2col + GEMM
     {"dcn_fused_ablate", 0, false},  // profiling build only: parts of the fused kernels switched off

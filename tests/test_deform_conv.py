@@ -419,6 +419,63 @@ def test_fused_forward_without_col_matrix(ops, oracle, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "pile_up", "tiny_gradients", "inf"])
+def test_backward_fixed_point_col2im(ops, oracle, case):
+    """Round 4: the layer's backward sums dX with integer LDS adds in fixed point (dcn_col2im_fx = 1,
+    default), the unit derived from max|dcol| (GEMM epilogue) x a bound on the bilinear weights one
+    pixel can collect (deform_col2im_wsum_kernel).  Against the fp32 compare-and-swap path (= 0) and
+    the oracle; bit-reproducible; every sample of an image piled onto ONE pixel (the bound's worst
+    case); gradients of 1e-20 (the scale is a power of two from the data, not a constant); inf in dY
+    takes the float path and reaches the pixels the reference sends it to."""
+    import torch
+    from simpledet_amd._lib import lib
+    x, off, w, kw = _case(31, N=2, C=32, H=12, W=10, F=16, dg=2)
+    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
+    rs = np.random.RandomState(32)
+    N, C, H, W = x.shape
+    F, K = w.shape[0], w[0].size
+    dy = rs.standard_normal((N, F, H, W)).astype(np.float32)
+    if case == "pile_up":
+        # every tap of every pixel samples the point (3.0, 4.0): offset = target - (h_in + i, w_in + j)
+        hh, ww = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        for t in range(9):
+            off[:, 2 * t::18] = 3.0 - (hh - 1 + t // 3)
+            off[:, 2 * t + 1::18] = 4.0 - (ww - 1 + t % 3)
+    if case == "tiny_gradients":
+        dy *= 1e-20
+    if case == "inf":
+        dy[1, 3, 5, 6] = np.inf
+    outs = {}
+    try:
+        for fx in (1, 1, 0):
+            lib().set_tuning("dcn_col2im_fx", fx)
+            outs.setdefault(fx, []).append(
+                ops.deform_conv_backward(_t(dy), _t(x), _t(off), _t(w), **a)[0].cpu().numpy())
+    finally:
+        lib().set_tuning("dcn_col2im_fx", 1)
+    np.testing.assert_array_equal(outs[1][0], outs[1][1])          # order independent
+    wdx = np.zeros_like(x)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for n in range(N):
+            dcol = (w.reshape(F, K).T.astype(np.float64) @ dy[n].reshape(F, -1).astype(np.float64)).astype(np.float32)
+            wdx[n] = oracle.deform_col2im(dcol, off[n], x[n].shape, **kw)
+    if case == "inf":
+        # image 0 is finite and unaffected; in image 1 the non-finite pattern is the float path's
+        assert np.isfinite(outs[1][0][0]).all() and np.abs(outs[1][0][0] - wdx[0]).max() <= _bar(wdx[0])
+        np.testing.assert_array_equal(np.isfinite(outs[1][0][1]), np.isfinite(outs[0][0][1]))
+        assert not np.isfinite(outs[1][0][1]).all()
+        return
+    scale = float(np.abs(wdx).max())
+    assert scale > 0
+    for got in (outs[1][0], outs[0][0]):
+        assert np.abs(got - wdx).max() <= 2e-5 * scale, (case, np.abs(got - wdx).max(), scale)
+    if case == "pile_up":
+        # one pixel per (image, channel) holds the whole gradient: 9 * H * W samples with weight 1
+        nz = np.abs(wdx) > 0
+        assert nz.reshape(N, C, -1).sum(-1).max() == 1 and nz[:, :, 3, 4].all()
+
+
+@pytest.mark.gpu
 def test_backward_with_the_forward_col_matrix(ops):
     """sd_deform_conv_bwd_cached: the col matrix left in the forward's workspace replaces the
     backward's own im2col -- same bits for d_offset (a per-lane reduction), d_data and d_weight up
