@@ -2394,7 +2394,7 @@ extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const flo
 
 // ---- forward without a col matrix (fused sampling + GEMM) ----------------------------------------
 static bool dcn_fused_shape_ok(int C, int H, int W, int kh, int kw, int dgroup) {
-  return kh * kw == 9 && dgroup > 0 && C % dgroup == 0 && (C / dgroup) % 16 == 0 && ((long)H * W) % 4 == 0 &&
+  return kh == 3 && kw == 3 && dgroup > 0 && C % dgroup == 0 && (C / dgroup) % 16 == 0 && ((long)H * W) % 4 == 0 &&
          (long)H * W < (1L << 28) && W + 16 < kFXFloats / 16 && tuning("dcn_fused", 1) == 1;
 }
 
