@@ -419,6 +419,25 @@ def test_fused_forward_without_col_matrix(ops, oracle, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kshape", [(1, 9), (9, 1), (3, 3), (1, 1)])
+def test_nocol_entry_takes_any_kernel_shape(ops, oracle, kshape):
+    """The fused kernel is for 3x3 taps; nine taps in a row (or any other shape) must take the im2col + GEMM
+    path behind sd_deform_conv_fwd_nocol, not the fused one with a wrong (i, j) per tap."""
+    kh, kw = kshape
+    rs = np.random.RandomState(61)
+    N, C, H, W, F, dg = 2, 32, 12, 20, 8, 2
+    Ho, Wo = H - (kh - 1), W - (kw - 1)
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    off = (rs.standard_normal((N, dg * 2 * kh * kw, Ho, Wo)) * 1.5).astype(np.float32)
+    w = (rs.standard_normal((F, C, kh, kw)) * 0.2).astype(np.float32)
+    y = ops.deform_conv_forward(_t(x), _t(off), _t(w), pad=0, stride=1, dilate=1,
+                                num_deformable_group=dg).cpu().numpy()
+    want = oracle.deform_conv_fwd(x, off, w, pad=0, stride=1, dil=1, dgroup=dg)
+    assert y.shape == want.shape
+    assert np.abs(y - want).max() <= _bar(want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["random", "pile_up", "tiny_gradients", "inf"])
 def test_backward_fixed_point_col2im(ops, oracle, case):
     """Round 4: the layer's backward sums dX with integer LDS adds in fixed point (dcn_col2im_fx = 1,
