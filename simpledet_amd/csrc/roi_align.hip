@@ -1052,19 +1052,36 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     }
     return v;
   };
-  if (wave == 0) {
-    int vbase = 0;
-    for (int u0 = 0; u0 < P.nunits; u0 += kWave) {
-      const int u = u0 + lane;
-      int cnt = 0, rounds = 0, lv = 0;
+  // (round 4: wave b builds the entries of units 64 b .. 64 b + 63 -- one global round trip and two wave
+  // scans per WAVE instead of per 64 units of one wave's serial walk, ~10 % of a workgroup's life at the
+  // baseline's 257 units; the cross-wave offsets go through LDS)
+  static_assert(kBandMaxUnits % kWave == 0 && kBandMaxUnits / kWave <= kBandWaves, "unit table: one wave per 64 units");
+  constexpr int NB = kBandMaxUnits / kWave;
+  __shared__ int s_tot[NB], s_ctot[NB];
+  {
+    // phase A: rounds per unit, scanned inside the wave
+    const int u = wave * kWave + lane;
+    int cnt = 0, rounds = 0, lv = 0, incl = 0;
+    if (wave < NB) {
       if (u < P.nunits) {
         lv = level_of(u);
 #pragma unroll
         for (int j = 0; j < kBandSub; ++j) cnt += P.seg[u * kBandSub + j].y;
         rounds = (cnt + CAP - 1) / CAP;
       }
-      const int incl = wave_incl_scan(rounds);
-      const int vb = vbase + incl - rounds;
+      incl = wave_incl_scan(rounds);
+      if (lane == kWave - 1) s_tot[wave] = incl;
+    }
+    __syncthreads();
+    // phase B: the virtual units of this wave's units, behind those of the waves before it
+    int total = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) total += s_tot[b];
+    const int n = total < kBandMaxUnits ? total : kBandMaxUnits;  // (the launcher keeps a level's rounds few)
+    if (wave < NB) {
+      int vb = incl - rounds;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) vb += b < wave ? s_tot[b] : 0;
       for (int r = 0; r < rounds && vb + r < kBandMaxUnits; ++r) {
         const int it = cnt - r * CAP < CAP ? cnt - r * CAP : CAP;
         v_unit[vb + r] = u;
@@ -1077,30 +1094,36 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
         const int cst = kBandFillCost / P.g[lv] + kBandPlaneCost + it;
         v_cost[vb + r] = P.g[lv] > 1 ? cst + cst * P.gbias / 100 : cst;
       }
-      vbase += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
-    const int n = vbase < kBandMaxUnits ? vbase : kBandMaxUnits;  // (the launcher keeps a level's rounds few)
-    wave_lds_sync();
-    int run = 0;
-    for (int v0 = 0; v0 < n; v0 += kWave) {
-      const int v = v0 + lane;
-      const int mine = v < n ? kBandSetupCost + v_cost[v] * a.C : 0;
-      const int incl = wave_incl_scan(mine);
-      if (v < n) v_start[v] = run + incl - mine;
-      run += __builtin_amdgcn_readlane(incl, kWave - 1);
+    __syncthreads();
+    // phase C: exclusive prefix of the virtual units' cost, wave w for virtual units 64 w .. 64 w + 63
+    const int v = wave * kWave + lane;
+    int mine = 0, cincl = 0;
+    if (wave < NB) {
+      mine = v < n ? kBandSetupCost + v_cost[v] * a.C : 0;
+      cincl = wave_incl_scan(mine);
+      if (lane == kWave - 1) s_ctot[wave] = cincl;
     }
-    if (lane == 0) {
-      v_start[n] = run;
-      s_nvu = n;
+    __syncthreads();
+    if (wave < NB) {
+      int run = cincl - mine;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) run += b < wave ? s_ctot[b] : 0;
+      if (v < n) v_start[v] = run;
+      if (v == n - 1 || (n == 0 && v == 0)) v_start[n] = n == 0 ? 0 : run + mine;
     }
+    if (tid == 0) s_nvu = n;
   }
   __syncthreads();
   const int nvu = s_nvu;
   int vu = 0;
   {
+    // the last virtual unit whose start is <= this workgroup's share of the cost (v_start ascends)
     const long pos = (long)v_start[nvu] * (2 * wg + 1) / (2 * nwg);
-    for (int k = 0; k < nvu; ++k)
-      if (v_start[k] <= pos) vu = k;
+    int below = 0;
+    for (int k = lane; k < nvu; k += kWave) below += v_start[k] <= pos ? 1 : 0;
+    below = wave_sum_i32(below);
+    vu = below > 0 ? below - 1 : 0;
   }
   float* buf0 = band_smem;
   float* buf1 = band_smem + kBandBufFloats;
