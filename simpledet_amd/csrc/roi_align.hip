@@ -139,6 +139,7 @@ struct FwdArgs {
   unsigned char* amax8;  // packed arg-max output (fused op); when set, ax / ay are not written
   float* coords;         // with amax8: (B*R, 2, 3*P) sample-coordinate table the backward decodes with
   int nslice;  // channel slices per RoI (one workgroup each)
+  int fbslice; // band kernel: channel slices of a RoI on its exact per-element path (one workgroup each)
   const int* order;  // optional locality order of the RoIs (a permutation of [0, B*R)), or null
   int ablate;  // profiling only: 1 stop after the tables
   long long* dbg;                     // profiling build only: per-wave phase clocks (or null)
@@ -1506,7 +1507,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     // of the RoIs that pool nothing), after the band work: workgroup = (RoI slot, channel slice).
     // (As blocks of their own in front of the launch they delayed every band workgroup's start.) ----
     const int nroi = a.B * a.R;
-    const int nsl = nwg >= a.nslice ? a.nslice : 1, csl = a.C / nsl, slice = wg % nsl;
+    const int nsl = nwg >= a.fbslice ? a.fbslice : 1, csl = a.C / nsl, slice = wg % nsl;
     const int nslots = nwg / nsl;
     // the flags of this workgroup's RoIs are fetched 64 at a time by every wave (one load each,
     // not a chain of dependent loads), then only the flagged ones are visited
@@ -2993,6 +2994,13 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   a.nslice = 1;
   for (int d = 1; d <= a.C && d <= want; ++d)
     if (a.C % d == 0) a.nslice = d;
+  // the band kernel's exact path (a handful of RoIs per launch, after the band work): 32 slices -- with 8
+  // the few workgroups that own a flagged RoI finish 1.5-2 us after everybody else (same-box A/B, 4 pairs)
+  int wantfb = tuning("roi_align_fwd_fb_slices", 32);
+  if (wantfb < 1) wantfb = 1;
+  a.fbslice = 1;
+  for (int d = 1; d <= a.C && d <= wantfb; ++d)
+    if (a.C % d == 0) a.fbslice = d;
   // the tiled kernels fetch (left,right) column pairs with one 8-byte load: needs W >= 2
   bool wide = true;
   for (int l = 0; l < a.L.nlvl; ++l)

@@ -49,6 +49,7 @@ Knob g_knobs[] = {
     {"roi_align_fwd_tail_planes", 0, false},  // planes of a tail piece (default 8 = a whole fill)
     {"roi_align_fwd_tail", 0, false},    // last per cent of a unit's channels reserved one fill at a time (default 0)
     {"roi_align_fwd_grab", 0, false},    // channels a band workgroup reserves at a time (default 4)
+    {"roi_align_fwd_fb_slices", 0, false},  // band kernel: workgroups that share a flagged RoI's channels on the exact path (default 32)
     {"roi_align_fwd_wgs", 0, false},     // persistent band workgroups (default 256 = one per CU)
     {"roi_align_fwd_split", 0, false},   // 1 more bands than LDS needs when a unit's expected items exceed a round (default)
     {"roi_align_fwd_g", 0, false},       // most planes per fill of the band-resident forward (1, 2, 4 or 8; default 8)

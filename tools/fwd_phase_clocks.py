@@ -41,6 +41,12 @@ print("partition before the first visit (ticks): mean %.0f max %d;  outside the 
     b[:, 0, 5].mean(), b[:, 0, 5].max(), (b[:, :, 4].max(1) - (b[:, 0, 0] + b[:, 0, 1] + b[:, 0, 2])).mean()))
 print("units per workgroup: mean %.2f max %d; items visited per workgroup mean %.0f" % (b[:, 0, 6].mean(), b[:, 0, 6].max(), b[:, 0, 3].mean()))
 tot = b[:, :, 4].max(1)
+inv = b[:, 0, 0] + b[:, 0, 1] + b[:, 0, 2]
+outv = b[:, :, 4].max(1) - inv
+print("inside the visits (wave 0): p10 %d p50 %d p90 %d max %d;  outside: p10 %d p50 %d p90 %d max %d" % (
+    tuple(np.percentile(inv, [10, 50, 90, 100]).astype(int)) + tuple(np.percentile(outv, [10, 50, 90, 100]).astype(int))))
+print("start tick spread (t_begin - min): p50 %d p90 %d max %d" % tuple(np.percentile(b[:, 0, 7] - b[:, 0, 7].min(), [50, 90, 100]).astype(int)))
+print("visits per workgroup histogram:", np.bincount(b[:, 0, 6].astype(int)).tolist())
 print("workgroup total ticks: p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(tot, [10, 50, 90, 100]).astype(int)))
 
 v = raw[nblk * 16 * 8:].reshape(nblk, 4, 8)
