@@ -2996,7 +2996,9 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     if (a.C % d == 0) a.nslice = d;
   // the band kernel's exact path (a handful of RoIs per launch, after the band work): 32 slices -- with 8
   // the few workgroups that own a flagged RoI finish 1.5-2 us after everybody else (same-box A/B, 4 pairs)
-  int wantfb = tuning("roi_align_fwd_fb_slices", 32);
+  // (single-level calls keep 8: a per-level op of the unfused FPN graph sees three quarters of its RoIs as
+  // "void" rows of the exact path, which then wants fuller workgroups: 63.6 -> 81.8 us with 32)
+  int wantfb = tuning("roi_align_fwd_fb_slices", a.L.nlvl > 1 ? 32 : 8);
   if (wantfb < 1) wantfb = 1;
   a.fbslice = 1;
   for (int d = 1; d <= a.C && d <= wantfb; ++d)
