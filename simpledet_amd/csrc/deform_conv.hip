@@ -268,18 +268,22 @@ __device__ __forceinline__ void col2im_geom(const DcnGeom& g, float inv_h, float
 }
 
 // per (tap, group, image): the largest sum of weights one pixel collects from this tap's samples, added
-// into wsum[image * dgroup + group] (zeroed by the caller).  LDS = H * W floats
+// into wsum[image * dgroup + group] (zeroed by the caller).  In integers -- every weight rounded UP to a
+// multiple of 2^-wshift, integer LDS adds, integer maximum, integer sum over the taps -- so that the
+// bound, and with it the fixed-point unit of the scatter, is the same in every run.  wshift is chosen
+// by the host so that P weights of 1 cannot overflow 32 bits.  LDS = H * W words
 __global__ __launch_bounds__(512) void deform_col2im_wsum_kernel(const float* __restrict__ offset,
-                                                                 float* __restrict__ wsum, DcnGeom g) {
-  extern __shared__ __attribute__((aligned(16))) float plane[];
-  __shared__ float s_max[8];
+                                                                 unsigned* __restrict__ wsum, DcnGeom g, int wshift) {
+  extern __shared__ __attribute__((aligned(16))) unsigned wplane[];
+  __shared__ unsigned s_max[8];
   const int P = g.Ho * g.Wo, K2 = g.kh * g.kw, HW = g.H * g.W;
   const int tap = blockIdx.x, grp = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
-  for (int i = tid; i < HW; i += 512) plane[i] = 0.f;
+  for (int i = tid; i < HW; i += 512) wplane[i] = 0u;
   __syncthreads();
   const float* oh = offset + (((long)n * g.dgroup + grp) * 2 * K2 + 2 * tap) * P;
   const float* ow = oh + P;
   const int ti = tap / g.kw, tj = tap % g.kw;
+  const float wscale = (float)(1u << wshift);
   for (int p = tid; p < P; p += 512) {
     const int h_out = p / g.Wo, w_out = p - h_out * g.Wo;
     const float inv_h = h_out * g.stride_h - g.pad_h + ti * g.dil_h + oh[p];
@@ -290,19 +294,25 @@ __global__ __launch_bounds__(512) void deform_col2im_wsum_kernel(const float* __
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const float w = fhv[d >> 1] * fwv[d & 1];
-      if (w != 0.f) lds_add_cas(plane + base + (d >> 1) * g.W + (d & 1), w);
+      if (w != 0.f)   // (w <= 1; NaN offsets give w == 0 through the comparisons of col2im_geom)
+        __hip_atomic_fetch_add(wplane + base + (d >> 1) * g.W + (d & 1), (unsigned)ceilf(fminr(w, 1.f) * wscale),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   __syncthreads();
-  float m = 0.f;
-  for (int i = tid; i < HW; i += 512) m = fmaxr(m, plane[i]);
-  m = wave_max_f32(m);
+  unsigned m = 0;
+  for (int i = tid; i < HW; i += 512) m = m > wplane[i] ? m : wplane[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
   if ((tid & 63) == 0) s_max[tid >> 6] = m;
   __syncthreads();
   if (tid == 0) {
-    float t = 0.f;
-    for (int k = 0; k < 8; ++k) t = fmaxr(t, s_max[k]);
-    atomicAdd(wsum + (long)n * g.dgroup + grp, t);
+    unsigned t = 0;
+    for (int k = 0; k < 8; ++k) t = s_max[k] > t ? s_max[k] : t;
+    atomicAdd(wsum + (long)n * g.dgroup + grp, t);   // (<= K2 * P * 2^wshift < 2^32: the host's choice of wshift)
   }
 }
 
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
                                                                 float* __restrict__ dx, DcnGeom g,
                                                                 int band_rows, int req_add,
                                                                 const unsigned* __restrict__ cmax,
-                                                                const float* __restrict__ wsum) {
+                                                                const unsigned* __restrict__ wsum, int wshift) {
   extern __shared__ __attribute__((aligned(16))) float plane[];
   const int P = g.Ho * g.Wo, K2 = g.kh * g.kw;
   const int c0 = blockIdx.x * CC, n = blockIdx.z;
@@ -327,7 +337,9 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
   bool fx = false;
   float scale = 1.f;
   if (FX) {
-    const float bound = __uint_as_float(cmax[0]) * wsum[(long)n * g.dgroup + grp];
+    // (the integer weight sum is exact in a float up to 2^24 units; beyond that it is rounded to nearest:
+    // one more unit of margin)
+    const float bound = __uint_as_float(cmax[0]) * ((float)(wsum[(long)n * g.dgroup + grp] + 1u) / (float)(1u << wshift)) * 1.000001f;
     const unsigned bb = __float_as_uint(bound);
     const int e = (int)((bb >> 23) & 255);
     if (bound == 0.f) {
@@ -2185,7 +2197,7 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
 // four-channel kernel sums in fixed point (deform_col2im_chunk_kernel<.., true>)
 static int col2im_impl(const float* col, const float* offset, float* dx, int req, int N, int C, int H, int W,
                        int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
-                       int dgroup, void* stream, const unsigned* cmax, float* wsum) {
+                       int dgroup, void* stream, const unsigned* cmax, unsigned* wsum) {
   DcnGeom g;
   if (int e = make_geom(g, N, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dgroup))
     return e;
@@ -2207,18 +2219,23 @@ static int col2im_impl(const float* col, const float* offset, float* dx, int req
         nb4 <= 65535) {
       const size_t lds4 = (size_t)CC * rows4 * W * sizeof(float);
       const size_t ldsw = (size_t)H * W * sizeof(float);
-      const bool fx = cmax && wsum && ldsw <= 150 * 1024 && kh * kw <= 65535 && tuning("dcn_col2im_fx", 1) == 1;
+      // weights as multiples of 2^-wshift: K2 * P of them (every sample of an image on one pixel) stay below 2^32
+      int wshift = 20;
+      while (wshift > 0 && (double)kh * kw * P * (double)(1u << wshift) >= 4294967296.0) --wshift;
+      const bool fx = cmax && wsum && ldsw <= 150 * 1024 && kh * kw <= 65535 && wshift >= 8 &&
+                      tuning("dcn_col2im_fx", 1) == 1;
       if (fx) {
-        SD_HIP_CHECK(hipMemsetAsync(wsum, 0, sizeof(float) * (size_t)N * dgroup, st));
+        SD_HIP_CHECK(hipMemsetAsync(wsum, 0, sizeof(unsigned) * (size_t)N * dgroup, st));
         if (ldsw > 64 * 1024)
           SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_wsum_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-        hipLaunchKernelGGL(deform_col2im_wsum_kernel, dim3(kh * kw, dgroup, N), dim3(512), ldsw, st, offset, wsum, g);
+        hipLaunchKernelGGL(deform_col2im_wsum_kernel, dim3(kh * kw, dgroup, N), dim3(512), ldsw, st, offset, wsum, g,
+                           wshift);
         if (lds4 > 64 * 1024)
           SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
         hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T, true>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
-                           col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, cmax, wsum);
+                           col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, cmax, wsum, wshift);
         SD_LAUNCH_CHECK();
         return SD_OK;
       }
@@ -2226,7 +2243,7 @@ static int col2im_impl(const float* col, const float* offset, float* dx, int req
         SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T, false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
       hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T, false>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
-                         col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, nullptr, nullptr);
+                         col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, nullptr, nullptr, 0);
       SD_LAUNCH_CHECK();
       return SD_OK;
     }
@@ -2510,10 +2527,10 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
   // fixed-point col2im: max|dcol| out of the GEMM's epilogue (amax[4]) and N * dgroup weight-sum bounds
   // (amax[8..]), all inside the 512 bytes of slack behind the col matrix
   unsigned* cmax = nullptr;
-  float* wsum = nullptr;
+  unsigned* wsum = nullptr;
   if (8 + (long)N * dgroup <= 120 && tuning("deform_gemm_split", 2) >= 1) {
     cmax = amax + 4;
-    wsum = reinterpret_cast<float*>(amax + 8);
+    wsum = amax + 8;
   }
   if (req_x != SD_REQ_NULL || req_offset != SD_REQ_NULL) {
     // dcol[n] (K x P) = W^T (K x F) . dY[n] (F x P)
