@@ -386,15 +386,27 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
         for (int d = 0; d < 4; ++d) {
           const float w = fhv[d >> 1] * fwv[d & 1];
           if (w != 0.f) {
-            float* q = plane + base + (d >> 1) * g.W + (d & 1);
+            const int idx = base + (d >> 1) * g.W + (d & 1);
+            if (FX && fx) {
+              // two channels per 64-bit add: (channel 2 k + 1) * 2^32 + (channel 2 k), the low field sign-extended;
+              // both sums stay below 2^29 in magnitude, so the fields come apart again exactly (write-out)
+              long long* q64 = reinterpret_cast<long long*>(plane) + idx;
 #pragma unroll
-            for (int cc = 0; cc < CC; ++cc) {
-              const float gv = e == 0 ? cv[cc].x : e == 1 ? cv[cc].y : e == 2 ? cv[cc].z : cv[cc].w;
-              if (FX && fx)
-                __hip_atomic_fetch_add(reinterpret_cast<int*>(q + cc * band_elems), __float2int_rn((w * gv) * scale),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              else
+              for (int pr = 0; pr < CC / 2; ++pr) {
+                const float g0 = e == 0 ? cv[2 * pr].x : e == 1 ? cv[2 * pr].y : e == 2 ? cv[2 * pr].z : cv[2 * pr].w;
+                const float g1 = e == 0 ? cv[2 * pr + 1].x : e == 1 ? cv[2 * pr + 1].y : e == 2 ? cv[2 * pr + 1].z : cv[2 * pr + 1].w;
+                const long long lo = (long long)__float2int_rn((w * g0) * scale);
+                const long long hi = (long long)__float2int_rn((w * g1) * scale);
+                __hip_atomic_fetch_add(q64 + pr * band_elems, hi * 4294967296ll + lo, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            } else {
+              float* q = plane + idx;
+#pragma unroll
+              for (int cc = 0; cc < CC; ++cc) {
+                const float gv = e == 0 ? cv[cc].x : e == 1 ? cv[cc].y : e == 2 ? cv[cc].z : cv[cc].w;
                 lds_add_cas(q + cc * band_elems, w * gv);
+              }
             }
           }
         }
@@ -403,13 +415,27 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
   }
   __syncthreads();
   const float unscale = 1.0f / scale;   // exact
+  if (FX && fx) {
+    static_assert(CC % 2 == 0, "fixed point: two channels per 64-bit word");
+    for (int pr = 0; pr < CC / 2; ++pr) {
+      float* d0 = dx + (((long)n * g.C + c0 + 2 * pr) * g.H + row0) * g.W;
+      float* d1 = d0 + (long)g.H * g.W;
+      const long long* pl = reinterpret_cast<const long long*>(plane) + pr * band_elems;
+      for (int i = tid; i < band_elems; i += T) {
+        const long long sum = pl[i];
+        const int lo = (int)(unsigned)(sum & 0xffffffffll);
+        const int hi = (int)((sum - (long long)lo) >> 32);
+        const float v0 = (float)lo * unscale, v1 = (float)hi * unscale;
+        d0[i] = req_add ? d0[i] + v0 : v0;
+        d1[i] = req_add ? d1[i] + v1 : v1;
+      }
+    }
+    return;
+  }
   for (int cc = 0; cc < CC; ++cc) {
     float* d = dx + (((long)n * g.C + c0 + cc) * g.H + row0) * g.W;
     const float* pl = plane + cc * band_elems;
-    for (int i = tid; i < band_elems; i += T) {
-      const float v = (FX && fx) ? (float)__float_as_int(pl[i]) * unscale : pl[i];
-      d[i] = req_add ? d[i] + v : v;
-    }
+    for (int i = tid; i < band_elems; i += T) d[i] = req_add ? d[i] + pl[i] : pl[i];
   }
 }
 
