@@ -234,6 +234,8 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
 // possible sum, and the result does not depend on the order of the adds.  A non-finite bound (inf /
 // nan in dcol) keeps the compare-and-swap adds, which send inf / nan where the reference sends them.
 
+constexpr unsigned kCmaxSlots = 32;   // words the producing GEMM spreads its max|C| over (GemmArgs::cmax)
+
 // where a sample lands: LDS index of the (floor, floor) corner relative to the band and the factors of
 // the two rows / two columns (0 for a corner that does not exist, lies outside the band or has weight 0)
 __device__ __forceinline__ void col2im_geom(const DcnGeom& g, float inv_h, float inv_w, int row0, int row1,
@@ -339,7 +341,10 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
   if (FX) {
     // (the integer weight sum is exact in a float up to 2^24 units; beyond that it is rounded to nearest:
     // one more unit of margin)
-    const float bound = __uint_as_float(cmax[0]) * ((float)(wsum[(long)n * g.dgroup + grp] + 1u) / (float)(1u << wshift)) * 1.000001f;
+    unsigned cbits = 0;
+#pragma unroll
+    for (unsigned k = 0; k < kCmaxSlots; ++k) cbits = cbits > cmax[k] ? cbits : cmax[k];
+    const float bound = __uint_as_float(cbits) * ((float)(wsum[(long)n * g.dgroup + grp] + 1u) / (float)(1u << wshift)) * 1.000001f;
     const unsigned bb = __float_as_uint(bound);
     const int e = (int)((bb >> 23) & 255);
     if (bound == 0.f) {
@@ -1300,7 +1305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
     mfma_step();
   }
   // D layout of the 32x32 tile: element e of lane l -> row (e/4)*8 + (l/32)*4 + e%4, col l%32
-  float vmax = 0.f;
+  unsigned vbits = 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1316,16 +1321,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
           if (piece || a.mode == 2) atomicAdd(c, v);
           else if (a.mode == 0) *c = v;
           else *c += v;
-          // (NaN: fmaxf would drop it -- keep it as +inf so that consumers of the maximum see "not finite")
-          const float av = fabsf(v);
-          vmax = av == av ? fmaxr(vmax, av) : __uint_as_float(0x7f800000u);
+          // (the maximum of the bit patterns of |v|: two integer operations per element, and a NaN -- whose
+          // pattern lies above inf's -- survives as "not finite" where fmaxf would drop it)
+          const unsigned ab = __float_as_uint(v) & 0x7fffffffu;
+          vbits = vbits > ab ? vbits : ab;
         }
       }
     }
   if (a.cmax) {
+    // one atomic per workgroup into one of kCmaxSlots words (tens of thousands of atomics on ONE word
+    // serialise at the L2: +130 us on the col-gradient GEMM); readers take the maximum of the slots
+    __shared__ float s_vmax[4];
+    float vmax = __uint_as_float(vbits > 0x7f800000u ? 0x7f800000u : vbits);
     if (piece) vmax *= (float)a.ksplit;
     vmax = wave_max_f32(vmax);
-    if (lane == 0) atomicMax(a.cmax, __float_as_uint(vmax));
+    if (lane == 0) s_vmax[wave] = vmax;
+    __syncthreads();
+    if (tid == 0)
+      atomicMax(a.cmax + ((unsigned)blockIdx.x % kCmaxSlots),
+                __float_as_uint(fmaxr(fmaxr(s_vmax[0], s_vmax[1]), fmaxr(s_vmax[2], s_vmax[3]))));
   }
 }
 
@@ -1685,7 +1699,6 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
   f16_split_scale(a.amax[1], sb, invb);
 
   const uint4* abase = a.apre + (long)mt * a.nslab * 9 * 1024 + (wave & 3) * 256 + lane;   // + step * 1024
-  const int nsteps = a.nslab * 9;
   char* const bwr = Bs + half * (kFN * 16) + pl * 16;                          // this lane's B granule (hi)
   const char* const brd = Bs + (lane >> 5) * (kFN * 16) + (lane & 31) * 16;    // this lane's fragment rows
   const int nh = cpg / kFHalf, npair = nh / 2;   // half-slabs / 16-channel slabs of a group
@@ -2546,17 +2559,17 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
   hipStream_t st = (hipStream_t)stream;
   // operand maxima for the scaled fp16 split: {max|W|, max|dY|, max|x| >= max|col|}
   unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
-  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 32, st));
+  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16 + 4 * kCmaxSlots, st));
   launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
   launch_absmax(out_grad, (long)N * F, P, P, 0, 1, amax + 1, st);
   launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 2, st);
-  // fixed-point col2im: max|dcol| out of the GEMM's epilogue (amax[4]) and N * dgroup weight-sum bounds
-  // (amax[8..]), all inside the 512 bytes of slack behind the col matrix
+  // fixed-point col2im: max|dcol| out of the GEMM's epilogue (amax[4 .. 4 + kCmaxSlots)) and N * dgroup
+  // weight-sum bounds behind them, all inside the 512 bytes of slack behind the col matrix
   unsigned* cmax = nullptr;
   unsigned* wsum = nullptr;
-  if (8 + (long)N * dgroup <= 120 && tuning("deform_gemm_split", 2) >= 1) {
-    cmax = amax + 4;
-    wsum = amax + 8;
+  if (4 + kCmaxSlots + (long)N * dgroup <= 120 && tuning("deform_gemm_split", 2) >= 1) {
+    cmax = amax + 4;                // kCmaxSlots words
+    wsum = amax + 4 + kCmaxSlots;   // N * dgroup words
   }
   if (req_x != SD_REQ_NULL || req_offset != SD_REQ_NULL) {
     // dcol[n] (K x P) = W^T (K x F) . dY[n] (F x P)
