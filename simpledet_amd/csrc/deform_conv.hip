@@ -2559,18 +2559,20 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
   hipStream_t st = (hipStream_t)stream;
   // operand maxima for the scaled fp16 split: {max|W|, max|dY|, max|x| >= max|col|}
   unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
-  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16 + 4 * kCmaxSlots, st));
-  launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
-  launch_absmax(out_grad, (long)N * F, P, P, 0, 1, amax + 1, st);
-  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 2, st);
   // fixed-point col2im: max|dcol| out of the GEMM's epilogue (amax[4 .. 4 + kCmaxSlots)) and N * dgroup
-  // weight-sum bounds behind them, all inside the 512 bytes of slack behind the col matrix
+  // weight-sum bounds behind them, all inside the slack behind the col matrix (what is left of its 512
+  // bytes depends on how far the caller's pointer was from a 256-byte boundary)
   unsigned* cmax = nullptr;
   unsigned* wsum = nullptr;
-  if (4 + kCmaxSlots + (long)N * dgroup <= 120 && tuning("deform_gemm_split", 2) >= 1) {
+  const long slack_words = ((const char*)workspace + workspace_bytes - (const char*)amax) / 4;
+  if (4 + kCmaxSlots + (long)N * dgroup <= slack_words && tuning("deform_gemm_split", 2) >= 1) {
     cmax = amax + 4;                // kCmaxSlots words
     wsum = amax + 4 + kCmaxSlots;   // N * dgroup words
   }
+  SD_HIP_CHECK(hipMemsetAsync(amax, 0, cmax ? 16 + 4 * kCmaxSlots : 16, st));
+  launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
+  launch_absmax(out_grad, (long)N * F, P, P, 0, 1, amax + 1, st);
+  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 2, st);
   if (req_x != SD_REQ_NULL || req_offset != SD_REQ_NULL) {
     // dcol[n] (K x P) = W^T (K x F) . dY[n] (F x P)
     if (int e = gemm_f32_impl(1, 0, K, P, F, weight, K, 0, out_grad, P, (long)F * P, col, P,
