@@ -1822,7 +1822,11 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
     if (LDSX) {
       // windows that do not fit two half-slab buffers, more words than the loader wave moves per
       // step, or a misaligned x: the tile is left to the global-gather instance
-      const bool fits = a.x_aligned && 2 * kFHalf * G.wstride <= kFXFloats && 2 * G.n4 <= 64 * kFStage;
+      // (and a non-finite x -- its maximum says so: the LDS instance reads corners it weighs with 0, an outside
+      // sample's slot 0 or the neighbour behind a clamp, and 0 x inf would reach pixels the reference keeps
+      // finite; the global-gather instance reads exactly what the reference reads)
+      const bool fits = a.x_aligned && 2 * kFHalf * G.wstride <= kFXFloats && 2 * G.n4 <= 64 * kFStage &&
+                        ((a.amax[1] >> 23) & 255u) != 255u;
       if (!fits) {
         if (tid == 0) *flag = 1;
         return false;
@@ -2012,8 +2016,11 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
           const int g1 = inside ? o1 + wstart : 0, g2 = inside ? o2 + wstart : 0, d1 = (tin >> 28) & 1;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            r.va[c >> 2][c & 3] = xc[(long)c * plane + g1]; r.vb[c >> 2][c & 3] = xc[(long)c * plane + g1 + d1];
-            r.vc[c >> 2][c & 3] = xc[(long)c * plane + g2]; r.vd[c >> 2][c & 3] = xc[(long)c * plane + g2 + d1];
+            // (an outside sample contributes exactly 0 whatever x holds at index 0)
+            const float ta = xc[(long)c * plane + g1], tb = xc[(long)c * plane + g1 + d1];
+            const float tc = xc[(long)c * plane + g2], td = xc[(long)c * plane + g2 + d1];
+            r.va[c >> 2][c & 3] = inside ? ta : 0.f; r.vb[c >> 2][c & 3] = inside ? tb : 0.f;
+            r.vc[c >> 2][c & 3] = inside ? tc : 0.f; r.vd[c >> 2][c & 3] = inside ? td : 0.f;
           }
         }
       };

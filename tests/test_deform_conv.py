@@ -419,6 +419,30 @@ def test_fused_forward_without_col_matrix(ops, oracle, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("where", ["plane_start", "interior", "nan"])
+def test_fused_forward_with_non_finite_input(ops, where):
+    """An inf / nan in x may only reach the outputs whose samples touch it: the col-free forward then runs
+    its global-gather instance (which reads exactly the corners the reference reads) instead of the LDS
+    windows, whose weight-0 reads (slot 0 for outside samples, the neighbour behind a clamp) would carry
+    0 x inf to other pixels.  Same finite / non-finite pattern as im2col + GEMM, same finite values."""
+    import torch
+    x, off, w, kw = _case(71, N=2, C=32, H=12, W=16, F=16, dg=2, off_scale=3.0)
+    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
+    bad = np.nan if where == "nan" else np.inf
+    if where == "plane_start":
+        x[0, 5, 0, 0] = bad          # index 0 of a channel plane: what an outside sample's corner 0 points at
+    else:
+        x[1, 20, 6, 7] = bad
+    tx, to, tw = _t(x), _t(off), _t(w)
+    y = ops.deform_conv_forward(tx, to, tw, **a)
+    y_unf, _ = ops.deform_conv_forward(tx, to, tw, keep_col=True, **a)
+    fin, fin_u = torch.isfinite(y), torch.isfinite(y_unf)
+    assert torch.equal(fin, fin_u)
+    assert not bool(fin.all()) and bool(fin.any())
+    assert float((y[fin] - y_unf[fin]).abs().max()) <= _bar(y_unf[fin].cpu().numpy())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kshape", [(1, 9), (9, 1), (3, 3), (1, 1)])
 def test_nocol_entry_takes_any_kernel_shape(ops, oracle, kshape):
     """The fused kernel is for 3x3 taps; nine taps in a row (or any other shape) must take the im2col + GEMM
