@@ -1477,34 +1477,47 @@ static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
 // max|x| of a (batch, rows, cols) operand with row stride ld and batch stride bstride, as the bit
 // pattern of the largest |x| (non-negative floats order like unsigned integers; a NaN wins, and the
 // split then scales by 1): atomicMax into *out, which the caller zeroed.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, long rows, int cols,
-                                                     long ld, long bstride, int batch, unsigned* out) {
+struct AbsSeg {
+  const float* p;
+  long rows;
+  int cols;
+  long ld, bstride;
+  int batch;
+  unsigned* out;
+  int blocks;   // workgroups of the launch that work on this operand
+};
+
+// workgroup `bid` of `nblk` on one operand
+__device__ __forceinline__ void absmax_body(const AbsSeg& a, int bid, int nblk) {
+  const float* __restrict__ p = a.p;
+  const long rows = a.rows, ld = a.ld, bstride = a.bstride;
+  const int cols = a.cols, batch = a.batch;
   const long per = rows * cols, n = per * batch;
   unsigned m = 0;
   const bool dense = ld == cols && (bstride == per || batch == 1) && (((uintptr_t)p & 15) == 0);
   if (dense) {
     const long n4 = n >> 2;
     const uint4* p4 = reinterpret_cast<const uint4*>(p);
-    const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)nblk * 256;
+    long i = (long)bid * 256 + threadIdx.x;
     // four independent 16-byte loads in flight per lane (one dependent chain per lane runs at a
     // quarter of the HBM rate: 55 us for the 69 MB of x)
     for (; i + 3 * stride < n4; i += 4 * stride) {
       const uint4 v0 = p4[i], v1 = p4[i + stride], v2 = p4[i + 2 * stride], v3 = p4[i + 3 * stride];
-      const unsigned a = max(max(v0.x & 0x7fffffffu, v0.y & 0x7fffffffu), max(v0.z & 0x7fffffffu, v0.w & 0x7fffffffu));
-      const unsigned b = max(max(v1.x & 0x7fffffffu, v1.y & 0x7fffffffu), max(v1.z & 0x7fffffffu, v1.w & 0x7fffffffu));
-      const unsigned c = max(max(v2.x & 0x7fffffffu, v2.y & 0x7fffffffu), max(v2.z & 0x7fffffffu, v2.w & 0x7fffffffu));
-      const unsigned d = max(max(v3.x & 0x7fffffffu, v3.y & 0x7fffffffu), max(v3.z & 0x7fffffffu, v3.w & 0x7fffffffu));
-      m = max(m, max(max(a, b), max(c, d)));
+      const unsigned a_ = max(max(v0.x & 0x7fffffffu, v0.y & 0x7fffffffu), max(v0.z & 0x7fffffffu, v0.w & 0x7fffffffu));
+      const unsigned b_ = max(max(v1.x & 0x7fffffffu, v1.y & 0x7fffffffu), max(v1.z & 0x7fffffffu, v1.w & 0x7fffffffu));
+      const unsigned c_ = max(max(v2.x & 0x7fffffffu, v2.y & 0x7fffffffu), max(v2.z & 0x7fffffffu, v2.w & 0x7fffffffu));
+      const unsigned d_ = max(max(v3.x & 0x7fffffffu, v3.y & 0x7fffffffu), max(v3.z & 0x7fffffffu, v3.w & 0x7fffffffu));
+      m = max(m, max(max(a_, b_), max(c_, d_)));
     }
     for (; i < n4; i += stride) {
       const uint4 v = p4[i];
       m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-      m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+    for (long i2 = (n4 << 2) + (long)bid * 256 + threadIdx.x; i2 < n; i2 += (long)nblk * 256)
+      m = max(m, __float_as_uint(p[i2]) & 0x7fffffffu);
   } else {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    for (long i = (long)bid * 256 + threadIdx.x; i < n; i += (long)nblk * 256) {
       const long b = i / per, r = (i - b * per) / cols;
       const int c = (int)(i - b * per - r * cols);
       m = max(m, __float_as_uint(p[b * bstride + r * ld + c]) & 0x7fffffffu);
@@ -1519,17 +1532,33 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
   __syncthreads();
   if (threadIdx.x == 0) {
     m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-    if (m) atomicMax(out, m);
+    if (m) atomicMax(a.out, m);
   }
 }
 
-static void launch_absmax(const float* p, long rows, int cols, long ld, long bstride, int batch, unsigned* out,
-                          hipStream_t st) {
+// up to three operands in ONE launch (the layer's backward needs max|W|, max|dY| and max|x|: three
+// launches of 5-15 us each plus their gaps otherwise)
+__global__ __launch_bounds__(256) void absmax_kernel(AbsSeg s0, AbsSeg s1, AbsSeg s2) {
+  const int b = blockIdx.x;
+  if (b < s0.blocks) absmax_body(s0, b, s0.blocks);
+  else if (b < s0.blocks + s1.blocks) absmax_body(s1, b - s0.blocks, s1.blocks);
+  else absmax_body(s2, b - s0.blocks - s1.blocks, s2.blocks);
+}
+
+static AbsSeg absmax_seg(const float* p, long rows, int cols, long ld, long bstride, int batch, unsigned* out) {
+  AbsSeg a{p, rows, cols, ld, bstride, batch, out, 0};
   const long n = rows * cols * batch;
-  if (n <= 0) return;
+  if (n <= 0 || !p) return a;
   long blocks = (n + 256 * 16 - 1) / (256 * 16);   // >= 16 floats per lane
   if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, rows, cols, ld, bstride, batch, out);
+  a.blocks = (int)blocks;
+  return a;
+}
+
+static void launch_absmax(AbsSeg s0, AbsSeg s1 = AbsSeg{}, AbsSeg s2 = AbsSeg{}, hipStream_t st = nullptr) {
+  const int blocks = s0.blocks + s1.blocks + s2.blocks;
+  if (blocks <= 0) return;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, s0, s1, s2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2401,8 +2430,9 @@ extern "C" int sd_gemm_f32_ws(int transA, int transB, int M, int N, int K, const
     SD_HIP_CHECK(hipMemsetAsync(amax, 0, 8, st));
     // storage of op(A) (M x K): rows x cols = transA ? K x M : M x K, row stride lda; B likewise.
     // A batch stride of 0 is one shared matrix.
-    launch_absmax(A, transA ? K : M, transA ? M : K, lda, strideA, strideA == 0 ? 1 : batch, amax, st);
-    launch_absmax(B, transB ? N : K, transB ? K : N, ldb, strideB, strideB == 0 ? 1 : batch, amax + 1, st);
+    launch_absmax(absmax_seg(A, transA ? K : M, transA ? M : K, lda, strideA, strideA == 0 ? 1 : batch, amax),
+                  absmax_seg(B, transB ? N : K, transB ? K : N, ldb, strideB, strideB == 0 ? 1 : batch, amax + 1),
+                  AbsSeg{}, st);
     SD_LAUNCH_CHECK();
   }
   return gemm_f32_impl(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch,
@@ -2448,8 +2478,8 @@ extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const flo
   unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
   hipStream_t st = (hipStream_t)stream;
   SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
-  launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
-  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 1, st);
+  launch_absmax(absmax_seg(weight, 1, F * K, F * K, 0, 1, amax),
+                absmax_seg(x, (long)N * C, H * W, H * W, 0, 1, amax + 1), AbsSeg{}, st);
   // y[n] (F x P) = W (F x K) . col[n] (K x P)
   return gemm_f32_impl(0, 0, F, P, K, weight, K, 0, col, P, (long)K * P, y, P, (long)F * P, N, 0, amax,
                        stream);
@@ -2494,8 +2524,8 @@ extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, con
   const size_t apre_words = (size_t)mtiles * nslab * 9 * 1024;
   unsigned* amax = reinterpret_cast<unsigned*>(apre + apre_words);   // {max|W|, max|x|}
   SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
-  launch_absmax(weight, 1, F * C * 9, F * C * 9, 0, 1, amax, st);
-  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 1, st);
+  launch_absmax(absmax_seg(weight, 1, F * C * 9, F * C * 9, 0, 1, amax),
+                absmax_seg(x, (long)N * C, H * W, H * W, 0, 1, amax + 1), AbsSeg{}, st);
   {
     const long total = (long)apre_words / 2;   // one thread per (hi, lo) pair
     hipLaunchKernelGGL(dcn_prep_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight,
@@ -2577,9 +2607,9 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
     wsum = amax + 4 + kCmaxSlots;   // N * dgroup words
   }
   SD_HIP_CHECK(hipMemsetAsync(amax, 0, cmax ? 16 + 4 * kCmaxSlots : 16, st));
-  launch_absmax(weight, 1, F * K, F * K, 0, 1, amax, st);
-  launch_absmax(out_grad, (long)N * F, P, P, 0, 1, amax + 1, st);
-  launch_absmax(x, (long)N * C, H * W, H * W, 0, 1, amax + 2, st);
+  launch_absmax(absmax_seg(weight, 1, F * K, F * K, 0, 1, amax),
+                absmax_seg(out_grad, (long)N * F, P, P, 0, 1, amax + 1),
+                absmax_seg(x, (long)N * C, H * W, H * W, 0, 1, amax + 2), st);
   if (req_x != SD_REQ_NULL || req_offset != SD_REQ_NULL) {
     // dcol[n] (K x P) = W^T (K x F) . dY[n] (F x P)
     if (int e = gemm_f32_impl(1, 0, K, P, F, weight, K, 0, out_grad, P, (long)F * P, col, P,
