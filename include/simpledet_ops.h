@@ -58,7 +58,7 @@ const char* sd_last_dispatch(void);
  * 5 sd_gemm_f32_ws, the DCN products default to the scaled fp16 split (fp32-path accuracy), plain
  * sd_gemm_f32 to exact fp32.
  * sd_abi_version() returns the library's value; compare with this macro. */
-#define SD_ABI_VERSION 5
+#define SD_ABI_VERSION 6
 int sd_abi_version(void);
 /* kernel-variant knobs for A/B measurements (bench.py, tests); every variant computes the same
  * result.  Unknown keys are an error.  Knobs that disable parts of a kernel for profiling exist
@@ -513,6 +513,32 @@ int sd_deform_conv_bwd_cached(const float* out_grad, const float* x, const float
                               int req_weight, int N, int C, int H, int W, int F, int kh, int kw,
                               int pad, int stride, int dil, int dgroup, void* workspace,
                               size_t workspace_bytes, void* stream);
+
+/* The operator with ALL of DeformableConvolutionParam (upstream MXNet 1.6 deformable_convolution-inl.h:
+ * kernel, stride, dilate, pad, num_filter, num_group, num_deformable_group, no_bias) -- the call sites
+ * beside models/dcn/builder.py pass a bias (models/RepPoints/builder.py:215-245, no_bias=False) and
+ * num_group / bias through (models/sepc/sepc_dconv.py:5-16; models/tridentnet/resnet_v1.py:85-90).
+ *   weight (F, C / num_group, kh, kw): filter block g (F / num_group filters) sees input channels
+ *   [g C / num_group, (g + 1) C / num_group) (the col rows of those channels), as the reference's loop
+ *   over group_ does; bias (F) or NULL (= no_bias): y[n, f, :] += bias[f] after the products, as
+ *   `out += broadcast<1>(bias)` does.  d_bias (F) (+)= sum over n, pixels of out_grad
+ *   (`sumall_except_dim<1>`), its own req.
+ * forward: keep_col = 0 -> the col-free fused kernel where the shape allows (num_group = 1, see
+ *   sd_deform_conv_fwd_nocol; the bias is added in its epilogue), else im2col + one GEMM per group + a
+ *   bias pass; keep_col = 1 -> always the latter, and the col matrix stays in the workspace for
+ *   sd_deform_convolution_bwd(fwd_col = sd_deform_conv_col_of_workspace(workspace)).
+ * backward: fwd_col NULL -> recomputed.  Workspace: sd_deform_conv_workspace_bytes. */
+size_t sd_deform_convolution_fwd_workspace_bytes(int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                                 int stride, int dil, int dgroup, int num_group, int keep_col);
+int sd_deform_convolution_fwd(const float* x, const float* offset, const float* weight, const float* bias,
+                              float* y, int N, int C, int H, int W, int F, int kh, int kw, int pad, int stride,
+                              int dil, int dgroup, int num_group, int keep_col, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int sd_deform_convolution_bwd(const float* out_grad, const float* x, const float* offset, const float* weight,
+                              const float* fwd_col, float* d_x, float* d_offset, float* d_weight, float* d_bias,
+                              int req_x, int req_offset, int req_weight, int req_bias, int N, int C, int H,
+                              int W, int F, int kh, int kw, int pad, int stride, int dil, int dgroup,
+                              int num_group, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * _contrib_Proposal_v3  (mx.sym.contrib.Proposal_v3, models/FPN/builder.py:275-287) -- SURVEY 8(f)

@@ -10,7 +10,11 @@
  *   deformable_im2col_gpu_kernel      -> orc_deform_im2col
  *   deformable_col2im_gpu_kernel      -> orc_deform_col2im        (data gradient)
  *   deformable_col2im_coord_gpu_kernel-> orc_deform_col2im_coord  (offset gradient)
- *   forward = W(F x C*kh*kw) . col(C*kh*kw x Ho*Wo), group = 1, no bias
+ *   forward = W(F x C*kh*kw) . col(C*kh*kw x Ho*Wo), group = 1, no bias      -> orc_deform_conv_fwd
+ *   DeformableConvolutionOp::Forward / ::Backward with every parameter (num_group: one product per
+ *   filter block over its channel block's col rows; bias: `out += broadcast<1>(bias)`;
+ *   gbias = sumall_except_dim<1>(grad))                    -> orc_deform_convolution_fwd / _bwd
+ *   (the bias / num_group call sites: models/RepPoints/builder.py:215-245, models/sepc/sepc_dconv.py:5-16)
  * The reference's call sites fix the configuration: models/dcn/builder.py:14-17 (3x3, pad = dilate,
  * num_deformable_group = 4, no_bias, fp32).  There is no golden vector for it anywhere in the
  * reference; tests additionally check properties that do not depend on this restatement (zero
@@ -256,5 +260,98 @@ void orc_deform_conv_fwd(const float* x, const float* offset, const float* wt, f
       }
     }
   }
+  free(col);
+}
+
+/* DeformableConvolutionOp::Forward (deformable_convolution-inl.h, upstream 1.6.0): per image im2col, per
+ * group g  output_3d[g] = dot(weight_3d[g], col_buffer_3d[g]);  then, with a bias,
+ * out += broadcast<1>(bias).  weight (F, C/G, kh, kw); bias NULL = no_bias.  fp32 sums in k order. */
+void orc_deform_convolution_fwd(const float* x, const float* offset, const float* wt, const float* bias,
+                                float* y, int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                int stride, int dil, int dgroup, int num_group) {
+  const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+  const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  const long K = (long)C * kh * kw, P = (long)Ho * Wo, Kg = K / num_group, Fg = F / num_group;
+  float* col = (float*)malloc(sizeof(float) * (size_t)(K * P));
+  for (int n = 0; n < N; ++n) {
+    orc_deform_im2col(x + (long)n * C * H * W, offset + (long)n * dgroup * 2 * kh * kw * P, col, C,
+                      H, W, kh, kw, pad, pad, stride, stride, dil, dil, dgroup, Ho, Wo);
+    float* yn = y + (long)n * F * P;
+#pragma omp parallel for
+    for (long f = 0; f < F; ++f) {
+      const long g = f / Fg;
+      float* yr = yn + f * P;
+      memset(yr, 0, sizeof(float) * (size_t)P);
+      for (long k = 0; k < Kg; ++k) {
+        const float a = wt[f * Kg + k];
+        const float* cr = col + (g * Kg + k) * P;
+        for (long p = 0; p < P; ++p) yr[p] += a * cr[p];
+      }
+      if (bias)
+        for (long p = 0; p < P; ++p) yr[p] += bias[f];
+    }
+  }
+  free(col);
+}
+
+/* DeformableConvolutionOp::Backward: per image  col_buffer_3d[g] = dot(weight_3d[g].T, out_grad_3d[g]),
+ * deformable_col2im_coord -> d_offset, deformable_col2im -> d_x, then im2col again and
+ * dweight_3d[g] (+)= dot(out_grad_3d[g], col_buffer_3d[g].T) image after image; with a bias
+ * gbias = sumall_except_dim<1>(grad).  All four gradients are written (req = write); dcol in fp32
+ * with the sums in f order, dW and gbias in double (the reference sums them in fp32 in an order the
+ * library does not fix: the tests hold the product to a tolerance, not to bits). */
+void orc_deform_convolution_bwd(const float* dy, const float* x, const float* offset, const float* wt,
+                                float* dx, float* doff, float* dw, float* dbias, int N, int C, int H, int W,
+                                int F, int kh, int kw, int pad, int stride, int dil, int dgroup,
+                                int num_group) {
+  const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+  const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  const long K = (long)C * kh * kw, P = (long)Ho * Wo, Kg = K / num_group, Fg = F / num_group;
+  float* col = (float*)malloc(sizeof(float) * (size_t)(K * P));
+  double* dwd = (double*)calloc((size_t)(F * Kg), sizeof(double));
+  for (int n = 0; n < N; ++n) {
+    const float* xn = x + (long)n * C * H * W;
+    const float* on = offset + (long)n * dgroup * 2 * kh * kw * P;
+    const float* dyn = dy + (long)n * F * P;
+#pragma omp parallel for
+    for (long k = 0; k < K; ++k) {
+      const long g = k / Kg, kk = k - g * Kg;
+      float* cr = col + k * P;
+      memset(cr, 0, sizeof(float) * (size_t)P);
+      for (long f = g * Fg; f < (g + 1) * Fg; ++f) {
+        const float a = wt[f * Kg + kk];
+        const float* dr = dyn + f * P;
+        for (long p = 0; p < P; ++p) cr[p] += a * dr[p];
+      }
+    }
+    orc_deform_col2im_coord(col, xn, on, doff + (long)n * dgroup * 2 * kh * kw * P, C, H, W, kh, kw, pad, pad,
+                            stride, stride, dil, dil, dgroup, Ho, Wo);
+    memset(dx + (long)n * C * H * W, 0, sizeof(float) * (size_t)C * H * W);
+    orc_deform_col2im(col, on, dx + (long)n * C * H * W, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil,
+                      dgroup, Ho, Wo);
+    orc_deform_im2col(xn, on, col, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dgroup, Ho, Wo);
+#pragma omp parallel for
+    for (long f = 0; f < F; ++f) {
+      const long g = f / Fg;
+      const float* dr = dyn + f * P;
+      for (long k = 0; k < Kg; ++k) {
+        const float* cr = col + (g * Kg + k) * P;
+        double acc = 0.0;
+        for (long p = 0; p < P; ++p) acc += (double)dr[p] * (double)cr[p];
+        dwd[f * Kg + k] += acc;
+      }
+    }
+  }
+  for (long i = 0; i < F * Kg; ++i) dw[i] = (float)dwd[i];
+  if (dbias)
+    for (long f = 0; f < F; ++f) {
+      double acc = 0.0;
+      for (int n = 0; n < N; ++n) {
+        const float* dr = dy + ((long)n * F + f) * P;
+        for (long p = 0; p < P; ++p) acc += dr[p];
+      }
+      dbias[f] = (float)acc;
+    }
+  free(dwd);
   free(col);
 }

@@ -160,6 +160,13 @@ void orc_deform_col2im_coord(const float* col, const float* x, const float* offs
 void orc_deform_conv_fwd(const float* x, const float* offset, const float* wt, float* y, int N,
                          int C, int H, int W, int F, int kh, int kw, int pad, int stride, int dil,
                          int dgroup);
+void orc_deform_convolution_fwd(const float* x, const float* offset, const float* wt, const float* bias,
+                                float* y, int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                int stride, int dil, int dgroup, int num_group);
+void orc_deform_convolution_bwd(const float* dy, const float* x, const float* offset, const float* wt,
+                                float* dx, float* doff, float* dw, float* dbias, int N, int C, int H, int W,
+                                int F, int kh, int kw, int pad, int stride, int dil, int dgroup,
+                                int num_group);
 
 #ifdef __cplusplus
 }

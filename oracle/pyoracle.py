@@ -422,6 +422,41 @@ def deform_conv_fwd(x, offset, weight, pad=1, stride=1, dil=1, dgroup=1):
     return y
 
 
+def deform_convolution_fwd(x, offset, weight, bias=None, pad=1, stride=1, dil=1, dgroup=1, num_group=1):
+    """the operator with every parameter: weight (F, C/num_group, kh, kw), bias (F) or None -> y"""
+    x, px = _f(x)
+    offset, po = _f(offset)
+    weight, pw = _f(weight)
+    N, C, H, W = x.shape
+    F, Cg, kh, kw = weight.shape
+    assert Cg * num_group == C and F % num_group == 0
+    pb = None
+    if bias is not None:
+        bias, pb = _f(bias)
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    y = np.empty((N, F, Ho, Wo), np.float32)
+    cdll().orc_deform_convolution_fwd(px, po, pw, pb, y.ctypes, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup,
+                                      num_group)
+    return y
+
+
+def deform_convolution_bwd(dy, x, offset, weight, bias=False, pad=1, stride=1, dil=1, dgroup=1, num_group=1):
+    """-> d_x, d_offset, d_weight[, d_bias] (all written)"""
+    dy, pdy = _f(dy)
+    x, px = _f(x)
+    offset, po = _f(offset)
+    weight, pw = _f(weight)
+    N, C, H, W = x.shape
+    F, Cg, kh, kw = weight.shape
+    assert Cg * num_group == C and F % num_group == 0
+    dx, doff, dw = np.zeros_like(x), np.zeros_like(offset), np.zeros_like(weight)
+    db = np.zeros(F, np.float32) if bias else None
+    cdll().orc_deform_convolution_bwd(pdy, px, po, pw, dx.ctypes, doff.ctypes, dw.ctypes,
+                                      db.ctypes if bias else None, N, C, H, W, F, kh, kw, pad, stride, dil,
+                                      dgroup, num_group)
+    return (dx, doff, dw, db) if bias else (dx, doff, dw)
+
+
 # ------------------------------------------------------------------------------------------------
 # _contrib_Proposal_v3 (GPU path) and get_top_proposal
 # ------------------------------------------------------------------------------------------------

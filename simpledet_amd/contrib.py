@@ -101,44 +101,58 @@ def ROIPooling_v1(data, rois, pooled_size, spatial_scale):
 
 class _DeformConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, data, offset, weight, pad, stride, dilate, dg):
+    def forward(ctx, data, offset, weight, bias, pad, stride, dilate, dg, num_group, will_backward):
         ctx.save_for_backward(data, offset, weight)
-        ctx.cfg = (pad, stride, dilate, dg)
+        ctx.cfg = (pad, stride, dilate, dg, num_group, bias is not None)
         # the col matrix stays alive for the backward (which then skips its own im2col): 620 MB per
-        # layer at (16,256,50,84).  SIMPLEDET_AMD_DCN_CACHE_COL=0 turns that off process-wide: the forward
-        # then is the col-free fused kernel and the backward recomputes col.
-        if os.environ.get("SIMPLEDET_AMD_DCN_CACHE_COL", "1") != "0":
-            y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg, keep_col=True)
+        # layer at (16,256,50,84) -- only when a backward can follow (will_backward: grad mode on and
+        # some input requires a gradient, decided by the caller: in here grad mode is always off).
+        # Inference and SIMPLEDET_AMD_DCN_CACHE_COL=0 (process-wide) take the col-free fused kernel; the
+        # backward then recomputes col.
+        keep = will_backward and os.environ.get("SIMPLEDET_AMD_DCN_CACHE_COL", "1") != "0"
+        if keep:
+            y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg, keep_col=True,
+                                                    bias=bias, num_group=num_group)
         else:
-            y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg), None
+            y, ctx.fwd_ws = ops.deform_conv_forward(data, offset, weight, pad, stride, dilate, dg, bias=bias,
+                                                    num_group=num_group), None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         data, offset, weight = ctx.saved_tensors
-        pad, stride, dilate, dg = ctx.cfg
+        pad, stride, dilate, dg, num_group, has_bias = ctx.cfg
         need = ctx.needs_input_grad
         req = tuple("write" if n else "null" for n in need[:3])
-        dx, doff, dw = ops.deform_conv_backward(dy.contiguous(), data, offset, weight, pad, stride,
-                                                dilate, dg, req=req, fwd_ws=ctx.fwd_ws)
+        if has_bias:
+            req = req + ("write" if need[3] else "null",)
+        g = ops.deform_conv_backward(dy.contiguous(), data, offset, weight, pad, stride, dilate, dg, req=req,
+                                     fwd_ws=ctx.fwd_ws, num_group=num_group, bias=has_bias)
         ctx.fwd_ws = None
-        return (dx if need[0] else None, doff if need[1] else None, dw if need[2] else None, None,
-                None, None, None)
+        return (g[0] if need[0] else None, g[1] if need[1] else None, g[2] if need[2] else None,
+                g[3] if has_bias and need[3] else None, None, None, None, None, None, None)
 
 
-def DeformableConvolution(data, offset, weight, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
+def DeformableConvolution(data, offset, weight, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
                           pad=(0, 0), num_filter=None, num_group=1, num_deformable_group=1,
-                          no_bias=True):
-    """mx.sym.contrib.DeformableConvolution as the reference calls it (models/dcn/builder.py:14-17:
-    3x3, num_group=1, no_bias=True)."""
-    if num_group != 1 or not no_bias:
-        raise ValueError("only num_group=1, no_bias=True (the reference's configuration)")
+                          no_bias=False):
+    """mx.sym.contrib.DeformableConvolution with upstream's parameter set (no_bias defaults to False
+    there): models/dcn/builder.py:14-17 (no_bias=True, 4 deformable groups), models/RepPoints/builder.py:
+    215-245 (bias), models/sepc/sepc_dconv.py:12-16 (num_group / bias passed through)."""
+    if no_bias:
+        if bias is not None:
+            raise ValueError("no_bias=True but a bias was given")
+    elif bias is None:
+        raise ValueError("no_bias=False needs a bias (F,)")
     k, s, d, p = [v if isinstance(v, (tuple, list)) else (v, v) for v in (kernel, stride, dilate, pad)]
     if tuple(weight.shape[2:]) != tuple(k) or (num_filter is not None and weight.shape[0] != num_filter):
         raise ValueError("weight shape %s does not match kernel/num_filter" % (tuple(weight.shape),))
     if s[0] != s[1] or d[0] != d[1] or p[0] != p[1]:
         raise ValueError("square stride/dilate/pad only")
-    return _DeformConv.apply(data, offset, weight, p[0], s[0], d[0], num_deformable_group)
+    will_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                    for t in (data, offset, weight, bias))
+    return _DeformConv.apply(data, offset, weight, bias, p[0], s[0], d[0], num_deformable_group, int(num_group),
+                             will_backward)
 
 
 def ProposalTarget(rois, gt_boxes, num_classes, batch_images, image_rois, fg_thresh, bg_thresh_hi,

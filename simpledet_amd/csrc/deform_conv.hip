@@ -1358,12 +1358,9 @@ __global__ __launch_bounds__(256) void gemm_zero_tiles_kernel(GemmArgs a) {
 
 template <bool AK, bool BKC, int MODE>
 static int launch_gemm_split_m(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f32_split_kernel<AK, BKC, MODE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSplitPlane));
-    attr = true;
-  }
+  // (every call: the attribute is per device, and a process may drive several)
+  SD_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f32_split_kernel<AK, BKC, MODE>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSplitPlane));
   hipLaunchKernelGGL((gemm_f32_split_kernel<AK, BKC, MODE>), grid, dim3(256), 4 * kSplitPlane, st, g);
   return SD_OK;
 }
@@ -1613,6 +1610,7 @@ struct DcnFusedArgs {
   const float* x;
   const float* offset;
   const uint4* apre;     // pre-split weights, fragment order (dcn_prep_weight_kernel)
+  const float* bias;     // (F) or null: added to y in the epilogue (`out += broadcast<1>(bias)`)
   float* y;
   DcnGeom g;
   int F, mtiles, nslab, tiles_per_image, tile_w;
@@ -1996,7 +1994,10 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int f = mt * 256 + wave * 64 + i * 32 + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3);
-          if (f < a.F && pp < p1) yn[(long)f * P + pp] = (acc[i][j][e] * inva) * invb;
+          if (f < a.F && pp < p1) {
+            const float v = (acc[i][j][e] * inva) * invb;
+            yn[(long)f * P + pp] = a.bias ? v + a.bias[f] : v;
+          }
         }
       }
   } else if (wave < 7) {
@@ -2211,6 +2212,49 @@ __global__ __launch_bounds__(kFThreads) void dcn_fwd_fused_kernel(DcnFusedArgs a
     d[0] = __builtin_readcyclecounter() - p_begin; d[1] = p_wait; d[2] = p_setup; d[3] = wave;
   }
 #endif
+}
+
+// ---- bias (no_bias = false: models/RepPoints/builder.py:215-245, models/sepc/sepc_dconv.py:12-16) ----
+// y[n, f, :] += bias[f], after the products (the order of `out += broadcast<1>(bias)`,
+// deformable_convolution-inl.h Forward).  One workgroup per (n, f) row; the fused forward adds the bias
+// in its own epilogue and never comes here.
+__global__ __launch_bounds__(256) void dcn_bias_add_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                           int F, int P) {
+  const long row = blockIdx.x;
+  const float b = bias[row % F];
+  float* yr = y + row * P;
+  const int head = (int)((4 - (((uintptr_t)yr >> 2) & 3)) & 3);   // floats up to the first 16-byte boundary
+  for (int p = threadIdx.x; p < (head < P ? head : P); p += 256) yr[p] += b;
+  const int n4 = P > head ? (P - head) >> 2 : 0;
+  float4* y4 = reinterpret_cast<float4*>(yr + head);
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 v = y4[i];
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    y4[i] = v;
+  }
+  for (int p = head + 4 * n4 + threadIdx.x; p < P; p += 256) yr[p] += b;
+}
+
+// d_bias[f] (+)= sum over n, pixels of out_grad[n, f, :]  (`sumall_except_dim<1>`): one workgroup per
+// filter; every lane sums its pixels of every image in a fixed order, then a fixed tree -- the same bits
+// in every run.
+__global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ dbias,
+                                                            int N, int F, int P, int add) {
+  const int f = blockIdx.x;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float* r = dy + ((long)n * F + f) * P;
+    for (int p = threadIdx.x; p < P; p += 256) acc += r[p];
+  }
+  __shared__ float sm[256];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dbias[f] = add ? dbias[f] + sm[0] : sm[0];
 }
 
 static int make_geom(DcnGeom& g, int N, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
@@ -2454,13 +2498,30 @@ static unsigned* dcn_amax_slots(float* col, size_t col_floats) {
   return reinterpret_cast<unsigned*>(((uintptr_t)(col + col_floats) + 15) & ~(uintptr_t)15);
 }
 
-extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const float* weight,
-                                  float* y, int N, int C, int H, int W, int F, int kh, int kw,
-                                  int pad, int stride, int dil, int dgroup, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+static int check_groups(int C, int F, int num_group) {
+  SD_REQUIRE(num_group >= 1, "num_group must be positive");
+  SD_REQUIRE(C % num_group == 0, "input num_filter must divide group size");
+  SD_REQUIRE(F % num_group == 0, "output num_filter must divide group size");
+  return SD_OK;
+}
+
+static int launch_bias_add(float* y, const float* bias, int N, int F, int P, hipStream_t st) {
+  if (!bias || (long)N * F == 0) return SD_OK;
+  SD_REQUIRE((long)N * F < (1L << 31), "bias: too many rows");
+  hipLaunchKernelGGL(dcn_bias_add_kernel, dim3((unsigned)((long)N * F)), dim3(256), 0, st, y, bias, F, P);
+  SD_LAUNCH_CHECK();
+  return SD_OK;
+}
+
+// forward = im2col + one GEMM per group (+ bias pass); the col matrix stays in the workspace
+static int deform_conv_fwd_impl(const float* x, const float* offset, const float* weight, const float* bias,
+                                float* y, int N, int C, int H, int W, int F, int kh, int kw, int pad, int stride,
+                                int dil, int dgroup, int num_group, void* workspace, size_t workspace_bytes,
+                                void* stream) {
   DcnGeom g;
   if (int e = make_geom(g, N, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dgroup)) return e;
   SD_REQUIRE(F > 0, "num_filter must be positive");
+  if (int e = check_groups(C, F, num_group)) return e;
   if (N == 0) return SD_OK;
   SD_REQUIRE(x && offset && weight && y, "null tensor pointer");
   const size_t need = sd_deform_conv_workspace_bytes(N, C, H, W, kh, kw, pad, stride, dil);
@@ -2478,11 +2539,23 @@ extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const flo
   unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
   hipStream_t st = (hipStream_t)stream;
   SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
-  launch_absmax(absmax_seg(weight, 1, F * K, F * K, 0, 1, amax),
+  launch_absmax(absmax_seg(weight, 1, F * (K / num_group), F * (K / num_group), 0, 1, amax),
                 absmax_seg(x, (long)N * C, H * W, H * W, 0, 1, amax + 1), AbsSeg{}, st);
-  // y[n] (F x P) = W (F x K) . col[n] (K x P)
-  return gemm_f32_impl(0, 0, F, P, K, weight, K, 0, col, P, (long)K * P, y, P, (long)F * P, N, 0, amax,
-                       stream);
+  // y[n][grp] (F/G x P) = W[grp] (F/G x K/G) . col[n][grp] (K/G x P)
+  const int Fg = F / num_group, Kg = K / num_group;
+  for (int q = 0; q < num_group; ++q)
+    if (int e = gemm_f32_impl(0, 0, Fg, P, Kg, weight + (long)q * Fg * Kg, Kg, 0, col + (long)q * Kg * P, P,
+                              (long)K * P, y + (long)q * Fg * P, P, (long)F * P, N, 0, amax, stream))
+      return e;
+  return launch_bias_add(y, bias, N, F, P, st);
+}
+
+extern "C" int sd_deform_conv_fwd(const float* x, const float* offset, const float* weight,
+                                  float* y, int N, int C, int H, int W, int F, int kh, int kw,
+                                  int pad, int stride, int dil, int dgroup, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  return deform_conv_fwd_impl(x, offset, weight, nullptr, y, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup, 1,
+                              workspace, workspace_bytes, stream);
 }
 
 // ---- forward without a col matrix (fused sampling + GEMM) ----------------------------------------
@@ -2496,24 +2569,27 @@ extern "C" size_t sd_deform_conv_fwd_nocol_workspace_bytes(int N, int C, int H, 
   if (N <= 0 || C <= 0 || F <= 0) return 256;
   if (!dcn_fused_shape_ok(C, H, W, kh, kw, dgroup))
     return sd_deform_conv_workspace_bytes(N, C, H, W, kh, kw, pad, stride, dil);
+  const long Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+  const long Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 256;   // (the call itself fails in make_geom: "kernel size exceed input")
   const size_t mtiles = (F + 255) / 256, nslab = C / 16;
-  const size_t P = (size_t)((H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1) * ((W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1);
+  const size_t P = (size_t)Ho * (size_t)Wo;
   // the pre-split weights + the operand maxima + one flag per tile (at most one tile per pixel)
   return mtiles * nslab * 9 * 1024 * sizeof(uint4) + 512 + mtiles * (size_t)N * P * sizeof(int);
 }
 
-extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, const float* weight, float* y,
-                                        int N, int C, int H, int W, int F, int kh, int kw, int pad,
-                                        int stride, int dil, int dgroup, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+static int deform_conv_fwd_nocol_impl(const float* x, const float* offset, const float* weight, const float* bias,
+                                      float* y, int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                      int stride, int dil, int dgroup, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
   DcnGeom g;
   if (int e = make_geom(g, N, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dgroup)) return e;
   SD_REQUIRE(F > 0, "num_filter must be positive");
   if (N == 0) return SD_OK;
   SD_REQUIRE(x && offset && weight && y, "null tensor pointer");
   if (!dcn_fused_shape_ok(C, H, W, kh, kw, dgroup))
-    return sd_deform_conv_fwd(x, offset, weight, y, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup, workspace,
-                              workspace_bytes, stream);
+    return deform_conv_fwd_impl(x, offset, weight, bias, y, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup, 1,
+                                workspace, workspace_bytes, stream);
   const size_t need = sd_deform_conv_fwd_nocol_workspace_bytes(N, C, H, W, F, kh, kw, pad, stride, dil, dgroup);
   if (!workspace || workspace_bytes < need)
     return fail(SD_ERR_WORKSPACE, "DeformableConvolution (fused forward) workspace too small: %zu < %zu bytes",
@@ -2532,7 +2608,8 @@ extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, con
                        apre, F, C, mtiles, nslab, amax);
   }
   DcnFusedArgs a{};
-  a.x = x; a.offset = offset; a.apre = apre; a.y = y; a.g = g; a.F = F; a.mtiles = mtiles; a.nslab = nslab;
+  a.x = x; a.offset = offset; a.apre = apre; a.bias = bias; a.y = y; a.g = g; a.F = F; a.mtiles = mtiles;
+  a.nslab = nslab;
   a.amax = amax;
   a.x_aligned = ((uintptr_t)x & 15) == 0;
   // tiles per image: enough for <= 96 pixels each, then as many more as keeps the launch at the same
@@ -2554,14 +2631,11 @@ extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, con
   a.dbg = reinterpret_cast<long long*>(((uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_hi", 0) << 32) |
                                        (uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_lo", 0));
 #endif
-  static bool attr = false;
-  if (!attr) {
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)dcn_fwd_fused_kernel<true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFSmemBytes));
-    SD_HIP_CHECK(hipFuncSetAttribute((const void*)dcn_fwd_fused_kernel<false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFSmemBytes));
-    attr = true;
-  }
+  // (every call: the attribute is per device, and a process may drive several)
+  SD_HIP_CHECK(hipFuncSetAttribute((const void*)dcn_fwd_fused_kernel<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kFSmemBytes));
+  SD_HIP_CHECK(hipFuncSetAttribute((const void*)dcn_fwd_fused_kernel<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kFSmemBytes));
   const dim3 grid((unsigned)(a.tiles_per_image * 8 * cdiv(N, 8) * mtiles));
   hipLaunchKernelGGL(dcn_fwd_fused_kernel<true>, grid, dim3(kFThreads), kFSmemBytes, st, a);
   // tiles whose windows did not fit LDS (wild offsets) flagged themselves: the global-gather instance
@@ -2571,6 +2645,33 @@ extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, con
   return SD_OK;
 }
 
+extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, const float* weight, float* y,
+                                        int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                        int stride, int dil, int dgroup, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  return deform_conv_fwd_nocol_impl(x, offset, weight, nullptr, y, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup,
+                                    workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t sd_deform_convolution_fwd_workspace_bytes(int N, int C, int H, int W, int F, int kh, int kw,
+                                                            int pad, int stride, int dil, int dgroup,
+                                                            int num_group, int keep_col) {
+  if (!keep_col && num_group == 1)
+    return sd_deform_conv_fwd_nocol_workspace_bytes(N, C, H, W, F, kh, kw, pad, stride, dil, dgroup);
+  return sd_deform_conv_workspace_bytes(N, C, H, W, kh, kw, pad, stride, dil);
+}
+
+extern "C" int sd_deform_convolution_fwd(const float* x, const float* offset, const float* weight,
+                                         const float* bias, float* y, int N, int C, int H, int W, int F, int kh,
+                                         int kw, int pad, int stride, int dil, int dgroup, int num_group,
+                                         int keep_col, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!keep_col && num_group == 1)
+    return deform_conv_fwd_nocol_impl(x, offset, weight, bias, y, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup,
+                                      workspace, workspace_bytes, stream);
+  return deform_conv_fwd_impl(x, offset, weight, bias, y, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup,
+                              num_group, workspace, workspace_bytes, stream);
+}
+
 // `fwd_col`: the col matrix a forward of the same (x, offset) left in ITS workspace
 // (sd_deform_conv_col_of_workspace), or null.  With it the backward skips its own im2col
 // (0.29 of 1.85 ms on the (16,256,50,84) layer): 620 MB kept per layer between the two calls, which
@@ -2578,13 +2679,15 @@ extern "C" int sd_deform_conv_fwd_nocol(const float* x, const float* offset, con
 // Backward) because its workspace is shared between operators.
 static int deform_conv_bwd_impl(const float* out_grad, const float* x, const float* offset,
                                 const float* weight, const float* fwd_col, float* d_x,
-                                float* d_offset, float* d_weight, int req_x, int req_offset,
-                                int req_weight, int N, int C, int H, int W, int F, int kh, int kw,
-                                int pad, int stride, int dil, int dgroup, void* workspace,
+                                float* d_offset, float* d_weight, float* d_bias, int req_x, int req_offset,
+                                int req_weight, int req_bias, int N, int C, int H, int W, int F, int kh, int kw,
+                                int pad, int stride, int dil, int dgroup, int num_group, void* workspace,
                                 size_t workspace_bytes, void* stream) {
   DcnGeom g;
   if (int e = make_geom(g, N, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dgroup)) return e;
   SD_REQUIRE(F > 0, "num_filter must be positive");
+  if (int e = check_groups(C, F, num_group)) return e;
+  SD_REQUIRE(req_bias == SD_REQ_NULL || req_bias == SD_REQ_WRITE || req_bias == SD_REQ_ADD, "bad req %d", req_bias);
   if (N == 0) return SD_OK;
   SD_REQUIRE(out_grad && x && offset && weight, "null tensor pointer");
   const size_t need = sd_deform_conv_workspace_bytes(N, C, H, W, kh, kw, pad, stride, dil);
@@ -2593,7 +2696,14 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
                 workspace_bytes, need);
   float* col = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const int K = C * kh * kw, P = g.Ho * g.Wo;
+  const int Fg = F / num_group, Kg = K / num_group;
   hipStream_t st = (hipStream_t)stream;
+  if (req_bias != SD_REQ_NULL) {
+    SD_REQUIRE(d_bias, "d_bias is null");
+    hipLaunchKernelGGL(dcn_bias_grad_kernel, dim3(F), dim3(256), 0, st, out_grad, d_bias, N, F, P,
+                       req_bias == SD_REQ_ADD ? 1 : 0);
+    SD_LAUNCH_CHECK();
+  }
   // operand maxima for the scaled fp16 split: {max|W|, max|dY|, max|x| >= max|col|}
   unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
   // fixed-point col2im: max|dcol| out of the GEMM's epilogue (amax[4 .. 4 + kCmaxSlots)) and N * dgroup
@@ -2607,14 +2717,15 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
     wsum = amax + 4 + kCmaxSlots;   // N * dgroup words
   }
   SD_HIP_CHECK(hipMemsetAsync(amax, 0, cmax ? 16 + 4 * kCmaxSlots : 16, st));
-  launch_absmax(absmax_seg(weight, 1, F * K, F * K, 0, 1, amax),
+  launch_absmax(absmax_seg(weight, 1, F * Kg, F * Kg, 0, 1, amax),
                 absmax_seg(out_grad, (long)N * F, P, P, 0, 1, amax + 1),
                 absmax_seg(x, (long)N * C, H * W, H * W, 0, 1, amax + 2), st);
   if (req_x != SD_REQ_NULL || req_offset != SD_REQ_NULL) {
-    // dcol[n] (K x P) = W^T (K x F) . dY[n] (F x P)
-    if (int e = gemm_f32_impl(1, 0, K, P, F, weight, K, 0, out_grad, P, (long)F * P, col, P,
-                              (long)K * P, N, 0, amax, stream, cmax))
-      return e;
+    // dcol[n][grp] (K/G x P) = W[grp]^T (K/G x F/G) . dY[n][grp] (F/G x P)
+    for (int q = 0; q < num_group; ++q)
+      if (int e = gemm_f32_impl(1, 0, Kg, P, Fg, weight + (long)q * Fg * Kg, Kg, 0, out_grad + (long)q * Fg * P, P,
+                                (long)F * P, col + (long)q * Kg * P, P, (long)K * P, N, 0, amax, stream, cmax))
+        return e;
     if (int e = sd_deform_col2im_coord(col, x, offset, d_offset, req_offset, N, C, H, W, kh, kw, pad,
                                        pad, stride, stride, dil, dil, dgroup, stream))
       return e;
@@ -2631,10 +2742,12 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
       return e;
     }
     if (req_weight == SD_REQ_WRITE)
-      SD_HIP_CHECK(hipMemsetAsync(d_weight, 0, sizeof(float) * (size_t)F * K, st));
-    // dW (F x K) += sum_n dY[n] (F x P) . col[n]^T (P x K): images in grid.z, atomic accumulate
-    return gemm_f32_impl(0, 1, F, K, P, out_grad, P, (long)F * P, col, P, (long)K * P, d_weight, K, 0,
-                         N, 2, amax + 1, stream);
+      SD_HIP_CHECK(hipMemsetAsync(d_weight, 0, sizeof(float) * (size_t)F * Kg, st));
+    // dW[grp] (F/G x K/G) += sum_n dY[n][grp] (F/G x P) . col[n][grp]^T (P x K/G): images in grid.z, atomic accumulate
+    for (int q = 0; q < num_group; ++q)
+      if (int e = gemm_f32_impl(0, 1, Fg, Kg, P, out_grad + (long)q * Fg * P, P, (long)F * P, col + (long)q * Kg * P,
+                                P, (long)K * P, d_weight + (long)q * Fg * Kg, Kg, 0, N, 2, amax + 1, stream))
+        return e;
   }
   return SD_OK;
 }
@@ -2645,9 +2758,9 @@ extern "C" int sd_deform_conv_bwd(const float* out_grad, const float* x, const f
                                   int N, int C, int H, int W, int F, int kh, int kw, int pad,
                                   int stride, int dil, int dgroup, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-  return deform_conv_bwd_impl(out_grad, x, offset, weight, nullptr, d_x, d_offset, d_weight, req_x,
-                              req_offset, req_weight, N, C, H, W, F, kh, kw, pad, stride, dil,
-                              dgroup, workspace, workspace_bytes, stream);
+  return deform_conv_bwd_impl(out_grad, x, offset, weight, nullptr, d_x, d_offset, d_weight, nullptr, req_x,
+                              req_offset, req_weight, SD_REQ_NULL, N, C, H, W, F, kh, kw, pad, stride, dil,
+                              dgroup, 1, workspace, workspace_bytes, stream);
 }
 
 extern "C" const float* sd_deform_conv_col_of_workspace(const void* fwd_workspace) {
@@ -2664,7 +2777,20 @@ extern "C" int sd_deform_conv_bwd_cached(const float* out_grad, const float* x, 
   SD_REQUIRE(fwd_col, "fwd_col is null (use sd_deform_conv_bwd)");
   SD_REQUIRE((const void*)fwd_col != sd_deform_conv_col_of_workspace(workspace),
              "the backward's workspace must not be the forward's (dcol would overwrite col)");
-  return deform_conv_bwd_impl(out_grad, x, offset, weight, fwd_col, d_x, d_offset, d_weight, req_x,
-                              req_offset, req_weight, N, C, H, W, F, kh, kw, pad, stride, dil,
-                              dgroup, workspace, workspace_bytes, stream);
+  return deform_conv_bwd_impl(out_grad, x, offset, weight, fwd_col, d_x, d_offset, d_weight, nullptr, req_x,
+                              req_offset, req_weight, SD_REQ_NULL, N, C, H, W, F, kh, kw, pad, stride, dil,
+                              dgroup, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sd_deform_convolution_bwd(const float* out_grad, const float* x, const float* offset,
+                                         const float* weight, const float* fwd_col, float* d_x, float* d_offset,
+                                         float* d_weight, float* d_bias, int req_x, int req_offset, int req_weight,
+                                         int req_bias, int N, int C, int H, int W, int F, int kh, int kw, int pad,
+                                         int stride, int dil, int dgroup, int num_group, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  SD_REQUIRE(!fwd_col || (const void*)fwd_col != sd_deform_conv_col_of_workspace(workspace),
+             "the backward's workspace must not be the forward's (dcol would overwrite col)");
+  return deform_conv_bwd_impl(out_grad, x, offset, weight, fwd_col, d_x, d_offset, d_weight, d_bias, req_x,
+                              req_offset, req_weight, req_bias, N, C, H, W, F, kh, kw, pad, stride, dil, dgroup,
+                              num_group, workspace, workspace_bytes, stream);
 }

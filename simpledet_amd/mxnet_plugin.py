@@ -609,7 +609,12 @@ def _build_ops(mx):
 
     ops["assign_layer_fpn"] = (AssignLayerFPNProp, None)
 
-    # ---- _contrib_DeformableConvolution: data, offset, weight -> output (no_bias, num_group 1) ----
+    # ---- _contrib_DeformableConvolution: data, offset, weight[, bias] -> output.  Upstream MXNet 1.6
+    #      DeformableConvolutionParam: kernel, stride, dilate, pad, num_filter, num_group,
+    #      num_deformable_group, workspace, no_bias (default False), layout.  Call sites:
+    #      models/dcn/builder.py:14-17 (no_bias=True), models/RepPoints/builder.py:215-245 (bias),
+    #      models/sepc/sepc_dconv.py:12-16 (num_group / bias passed through),
+    #      models/tridentnet/resnet_v1.py:85-90 (weight / bias shared between branches) ----
     class DeformConv(CustomOp):
         def __init__(self, g):
             super().__init__()
@@ -624,79 +629,98 @@ def _build_ops(mx):
 
         def forward(self, is_train, req, in_data, out_data, aux):
             _no_add(req)
-            x, off, w = in_data
-            _wait(x, off, w)
+            x, off, w = in_data[:3]
+            b = in_data[3] if self.g["bias"] else None
+            _wait(*in_data)
             g = self.g
             N, C, H, W = x.shape
-            if not (is_train and g["cache_col"]):
-                # no col matrix: deformable sampling fused into the GEMM (a few MB of workspace instead
-                # of N*C*9*Ho*Wo*4 bytes; shapes the fused kernel does not take run im2col + GEMM behind
-                # the same entry point)
-                lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes.restype = ctypes.c_size_t
-                n = int(lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes(
-                    N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"]))
-                ws = _scratch(x, n)
-                lib().call("sd_deform_conv_fwd_nocol", _ptr(x), _ptr(off), _ptr(w), _ptr(out_data[0]), N, C,
-                           H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"],
-                           _ptr(ws), ctypes.c_size_t(n), None)
-                self._fwd_ws = None
-                _sync()
-                return
-            ws, n = self._ws(x)
-            lib().call("sd_deform_conv_fwd", _ptr(x), _ptr(off), _ptr(w), _ptr(out_data[0]), N, C, H,
-                       W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"],
+            # training with cache_col: im2col + GEMM, the col matrix stays alive until this node's backward,
+            # which then skips its own im2col (620 MB per layer at the baseline; cache_col="False" trades it
+            # for the fused col-free forward and a backward that recomputes col).  Otherwise no col matrix:
+            # deformable sampling fused into the GEMM (a few MB of workspace instead of N*C*9*Ho*Wo*4 bytes;
+            # shapes the fused kernel does not take run im2col + GEMM behind the same entry point)
+            keep = 1 if (is_train and g["cache_col"]) else 0
+            n = int(lib().cdll.sd_deform_convolution_fwd_workspace_bytes(
+                N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], g["G"], keep))
+            ws = _scratch(x, n)
+            lib().call("sd_deform_convolution_fwd", _ptr(x), _ptr(off), _ptr(w), _ptr(b), _ptr(out_data[0]), N, C,
+                       H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], g["G"], keep,
                        _ptr(ws), ctypes.c_size_t(n), None)
-            # training with cache_col: the col matrix stays alive until this node's backward, which then
-            # skips its own im2col (620 MB per layer at the baseline; cache_col="False" trades it for
-            # the fused col-free forward and a backward that recomputes col)
-            self._fwd_ws = (ws, tuple(x.shape))
+            self._fwd_ws = (ws, tuple(x.shape)) if keep else None
             _sync()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-            x, off, w = in_data
-            _wait(out_grad[0], x, off, w)
+            x, off, w = in_data[:3]
+            _wait(out_grad[0], *in_data)
             g = self.g
             N, C, H, W = x.shape
             ws, n = self._ws(x)
             kept = getattr(self, "_fwd_ws", None)
             self._fwd_ws = None
+            col = None
             if kept is not None and kept[1] == tuple(x.shape):
-                col = lib().cdll.sd_deform_conv_col_of_workspace(_ptr(kept[0]))
-                lib().call("sd_deform_conv_bwd_cached", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w),
-                           ctypes.c_void_p(col), _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]),
-                           _req(req[0]), _req(req[1]), _req(req[2]), N, C, H, W, g["F"], g["kh"],
-                           g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], _ptr(ws),
-                           ctypes.c_size_t(n), None)
-            else:
-                lib().call("sd_deform_conv_bwd", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w),
-                           _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]), _req(req[0]),
-                           _req(req[1]), _req(req[2]), N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"],
-                           g["stride"], g["dil"], g["dg"], _ptr(ws), ctypes.c_size_t(n), None)
+                col = ctypes.c_void_p(lib().cdll.sd_deform_conv_col_of_workspace(_ptr(kept[0])))
+            has_b = g["bias"]
+            lib().call("sd_deform_convolution_bwd", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w), col,
+                       _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]), _ptr(in_grad[3]) if has_b else None,
+                       _req(req[0]), _req(req[1]), _req(req[2]), _req(req[3]) if has_b else REQ["null"],
+                       N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], g["G"],
+                       _ptr(ws), ctypes.c_size_t(n), None)
             _sync()
 
     class DeformConvProp(CustomOpProp):
+        # the op's own parameter names (+ cache_col, this adapter's attribute); anything else, and any
+        # value the kernels do not take, makes install()'s alias hand the call back to the constructor it
+        # replaced (sd_supports) -- the graph then holds the native operator for that node
+        PARAMS = ("kernel", "num_filter", "stride", "dilate", "pad", "num_group", "num_deformable_group", "no_bias",
+                  "workspace", "layout", "cache_col")
+
         def __init__(self, kernel, num_filter, stride="(1,1)", dilate="(1,1)", pad="(0,0)",
                      num_group="1", num_deformable_group="1", no_bias="False", workspace="1024",
                      layout="None", cache_col="True"):
             # cache_col is this adapter's own attribute: keep the forward's col matrix for the
             # backward of the same node (training only)
             super().__init__(need_top_grad=True)
+            why = self.sd_supports(dict(kernel=kernel, num_filter=num_filter, stride=stride, dilate=dilate, pad=pad,
+                                        num_group=num_group, num_deformable_group=num_deformable_group,
+                                        layout=layout))
+            if why:
+                raise ValueError("DeformableConvolution: " + why)
             k, s, d, p = (_tuple(kernel, 2, int), _tuple(stride, 2, int), _tuple(dilate, 2, int),
                           _tuple(pad, 2, int))
-            if int(num_group) != 1:
-                raise ValueError("DeformableConvolution: only num_group=1 (the reference's setting)")
-            if not _bool(no_bias):
-                raise ValueError("DeformableConvolution: only no_bias=True (models/dcn/builder.py:17)")
-            if s[0] != s[1] or d[0] != d[1] or p[0] != p[1]:
-                raise ValueError("DeformableConvolution: square stride/dilate/pad only")
             self.g = dict(kh=k[0], kw=k[1], stride=s[0], dil=d[0], pad=p[0], F=int(num_filter),
-                          dg=int(num_deformable_group),
+                          dg=int(num_deformable_group), G=int(num_group), bias=not _bool(no_bias),
                           # SIMPLEDET_AMD_DCN_CACHE_COL=0: process-wide off switch (no node keeps 620 MB
                           # between its forward and backward, whatever its attribute says)
                           cache_col=_bool(cache_col) and os.environ.get("SIMPLEDET_AMD_DCN_CACHE_COL", "1") != "0")
 
+        @classmethod
+        def sd_supports(cls, params):
+            """'' when the kernels take this parameter set, else the reason (install()'s alias then falls
+            back to the native constructor).  params: str-valued, as MXNet hands them to a CustomOpProp."""
+            for k in params:
+                if k not in cls.PARAMS:
+                    return "parameter %r is not one this operator takes" % k
+            try:
+                k = _tuple(params.get("kernel", "(0,0)"), 2, int)
+                s, d, p = (_tuple(params.get(n, dflt), 2, int) for n, dflt in
+                           (("stride", "(1,1)"), ("dilate", "(1,1)"), ("pad", "(0,0)")))
+                int(params.get("num_filter", "0")), int(params.get("num_group", "1"))
+                int(params.get("num_deformable_group", "1"))
+            except Exception as e:
+                return "unparsable parameter (%s)" % e
+            if len(k) != 2 or len(s) != 2 or len(d) != 2 or len(p) != 2:
+                return "2-D convolutions only"
+            if s[0] != s[1] or d[0] != d[1] or p[0] != p[1]:
+                return "square stride/dilate/pad only"
+            if str(params.get("layout", "None")) not in ("None", "NCHW"):
+                return "layout NCHW only"
+            if int(params.get("num_group", "1")) < 1 or int(params.get("num_deformable_group", "1")) < 1:
+                return "num_group / num_deformable_group must be positive"
+            return ""
+
         def list_arguments(self):
-            return ["data", "offset", "weight"]
+            return ["data", "offset", "weight"] + (["bias"] if self.g["bias"] else [])
 
         def list_outputs(self):
             return ["output"]
@@ -706,16 +730,23 @@ def _build_ops(mx):
             d = in_shape[0]
             if len(d) != 4:
                 raise ValueError("Input data should be 4D in batch-num_filter-y-x")
+            if d[1] % g["G"] or g["F"] % g["G"]:
+                raise ValueError("input / output num_filter must divide group size")
+            if d[1] % g["dg"]:
+                raise ValueError("input num_filter must divide deformable group size")
             Ho = (d[2] + 2 * g["pad"] - (g["dil"] * (g["kh"] - 1) + 1)) // g["stride"] + 1
             Wo = (d[3] + 2 * g["pad"] - (g["dil"] * (g["kw"] - 1) + 1)) // g["stride"] + 1
             off = (d[0], g["dg"] * 2 * g["kh"] * g["kw"], Ho, Wo)
-            w = (g["F"], d[1], g["kh"], g["kw"])
-            return [d, off, w], [(d[0], g["F"], Ho, Wo)]
+            w = (g["F"], d[1] // g["G"], g["kh"], g["kw"])
+            ins = [d, off, w] + ([(g["F"],)] if g["bias"] else [])
+            return ins, [(d[0], g["F"], Ho, Wo)]
 
         def create_operator(self, ctx, shapes, dtypes):
             return DeformConv(self.g)
 
         def declare_backward_dependency(self, out_grad, in_data, out_data):
+            # (the bias itself is not needed by the backward: deformable_convolution-inl.h Backward reads
+            # out_grad, data, offset, weight)
             return [out_grad[0], in_data[0], in_data[1], in_data[2]]
 
     ops["_contrib_DeformableConvolution"] = (DeformConvProp, ("contrib", "DeformableConvolution"))
@@ -1087,19 +1118,58 @@ def register(mx=None):
     return out
 
 
+def _namespaces(mx, ns):
+    """Every namespace object the reference reaches an operator through: `mx.sym` (= `mx.symbol`) or
+    `mx.sym.contrib`, and for contrib operators also the old `mx.contrib.symbol` / `mx.contrib.sym`
+    module, which MXNet 1.x still fills with the same constructors as separate attributes
+    (models/tridentnet/resnet_v1.py:85 builds its DeformableConvolution through it)."""
+    out = []
+
+    def add(t):
+        if t is not None and all(t is not o for o in out):
+            out.append(t)
+    for root in (getattr(mx, "sym", None), getattr(mx, "symbol", None)):
+        if root is not None:
+            add(getattr(root, ns) if ns else root)
+    if ns == "contrib":
+        old = getattr(mx, "contrib", None)
+        for a in ("symbol", "sym"):
+            add(getattr(old, a, None) if old is not None else None)
+    return out
+
+
 def install(mx=None):
     """register() + alias the reference's symbol constructors to mx.sym.Custom, e.g.
     mx.sym.contrib.ROIAlign_v2(data=d, rois=r, pooled_size=(7,7), spatial_scale=0.25) builds
     mx.sym.Custom(d, r, op_type='sd__contrib_ROIAlign_v2', pooled_size='(7, 7)', ...) and returns
-    only the visible outputs, so symbol/builder.py and the config/ graphs stay unchanged."""
+    only the visible outputs, so symbol/builder.py and the config/ graphs stay unchanged.
+
+    The constructor an alias replaces is kept (`<namespace>._sd_reference_<name>`, and on the alias as
+    `_sd_original`).  An operator whose prop class has `sd_supports(params)` (DeformableConvolution) hands
+    a call with parameters the kernels do not take BACK to that constructor: the node is then the native
+    operator, exactly what the graph held without install() (`_state["fallbacks"]` lists them)."""
     props = register(mx)
     mx = _state["mx"]
+    _state["fallbacks"] = []
 
-    def make(name, prop):
+    def make(name, prop, original):
         def ctor(*args, **kwargs):
+            # MXNet's generated constructors skip inputs / attributes given as None
+            # (models/sepc/sepc_dconv.py:13: `bias=bias if not no_bias else None`)
+            kwargs = {k: v for k, v in kwargs.items() if v is not None}
             name_kw = kwargs.pop("name", None)
             params = {k: _param_str(v) for k, v in kwargs.items() if not _is_symbol(mx, v)}
             inputs = {k: v for k, v in kwargs.items() if _is_symbol(mx, v)}
+            supports = getattr(prop, "sd_supports", None)
+            why = supports(params) if supports is not None else ""
+            if why:
+                if original is None:
+                    raise ValueError("%s: %s (and no native constructor to fall back to)" % (name, why))
+                _state["fallbacks"].append((name, name_kw, why))
+                native = {k: v for k, v in kwargs.items() if k != "cache_col"}
+                if name_kw is not None:
+                    native["name"] = name_kw
+                return original(*args, **native)
             sym = mx.sym.Custom(*args, op_type=_PREFIX + name, name=name_kw, **inputs, **params)
             p = prop(**params)
             nvis = getattr(p, "num_visible_outputs", len(p.list_outputs()))
@@ -1108,14 +1178,20 @@ def install(mx=None):
                 return sym
             return sym[0] if nvis == 1 else mx.sym.Group([sym[i] for i in range(nvis)])
         ctor.__name__ = name
+        ctor._sd_alias = True
+        ctor._sd_original = original
         return ctor
 
     for name, (prop, where) in _state["table"].items():
         if where is None:
             continue
         ns, attr = where
-        target = getattr(mx.sym, ns) if ns else mx.sym
-        setattr(target, attr, make(name, props[name]))
+        for target in _namespaces(mx, ns):
+            cur = getattr(target, attr, None)
+            # a second install(): the first one's original stays the original
+            original = cur._sd_original if getattr(cur, "_sd_alias", False) else cur
+            setattr(target, attr, make(name, props[name], original))
+            setattr(target, "_sd_reference_" + attr, original)
     # the fused FPN extractor has no single reference symbol to alias: rebind the builder method
     # that emits the subgraph (no reference file is edited)
     _state["fpn_patched"] = patch_fpn_roi_align(mx=mx)
@@ -1125,11 +1201,40 @@ def install(mx=None):
     return props
 
 
+def _head_op(mx, sym):
+    """(operator name, attrs) of the node behind a symbol: real MXNet through the graph JSON (a
+    multi-output symbol's heads all point at one node here), the graph-recording test stub through
+    `op_type`.  CustomOps report ('Custom', {'op_type': ...})."""
+    if hasattr(sym, "tojson"):
+        try:
+            import json
+            g = json.loads(sym.tojson())
+            node = g["nodes"][g["heads"][0][0]]
+            return node.get("op"), dict(node.get("attrs", node.get("attr", node.get("param", {}))) or {})
+        except Exception:
+            pass
+    node = sym
+    while getattr(node, "op_type", None) in ("_output", "Group"):
+        node = node.parent if node.op_type == "_output" else node.inputs[0]
+    return getattr(node, "op_type", None), dict(getattr(node, "params", {}) or {})
+
+
 def patch_mxnext(mxnext=None, mx=None):
-    """Point the mxnext wrappers on the hot path at the aliased symbol constructors, by name, so that
-    the routing does not depend on how mxnext binds `mx.sym.*` internally.  mxnext
-    (github.com/RogerChern/mxnext) is not part of the reference tree; the signatures are the ones the
-    reference's call sites use:
+    """Point the mxnext wrappers on the hot path at the aliased symbol constructors WHERE THAT IS KNOWN TO
+    BE A NO-OP FOR THE GRAPH'S MEANING.  mxnext (github.com/RogerChern/mxnext) is not part of the
+    reference tree, so which operator a wrapper builds is not assumed: each saved original is called
+    once with placeholder Variables and the reference's own keyword arguments, and the operator of the
+    node it returns decides --
+      * already an `sd_*` Custom node (the wrapper looks `mx.sym.*` up at call time): nothing to do;
+      * the native operator this plugin replaces under the same name (`_contrib_ROIAlign_v2`,
+        `ProposalTarget`, `_contrib_Proposal_v3`, `_contrib_DecodeBBox`): the wrapper captured the
+        constructor before install(); it is rebound to a function with the call sites' signature that
+        builds the alias;
+      * anything else (`_contrib_Proposal`, `_contrib_Proposal_v2`, `MultiProposal`, a TVM op ...), or a
+        probe that raises: LEFT ALONE -- `proposal.cu`, `proposal_v2.cu` and `proposal_v3.cu` differ in the
+        +1 box convention, the dw / dh clamp and the min-size filter, rebinding would change the RPN's
+        numbers silently.
+    Call sites whose signatures the probes use:
         X.roi_align(feat, rois=, out_size=, stride=, name=)      symbol/builder.py:885, models/FPN/builder.py:592
         X.proposal_target(rois=, gt_boxes=, ..., name=)           symbol/builder.py:304, models/FPN/builder.py:347
         X.proposal(cls_prob=, bbox_pred=, im_info=, ..., iou_loss=, output_score=)   symbol/builder.py:241
@@ -1138,7 +1243,8 @@ def patch_mxnext(mxnext=None, mx=None):
                                                                   models/FPN/builder.py:319-321
     (mxnext.tvm.proposal -- the "nnvm" proposal some configs select for the fine levels -- is left
     alone: it is un-vendored and nothing in the reference tree pins its results.)
-    Returns the list of patched names ([] when mxnext is not importable)."""
+    Returns the list of rebound names ([] when mxnext is not importable); `_state["mxnext_probe"]`
+    holds what every probe saw."""
     mx = mx or _state["mx"]
     if mxnext is None:
         try:
@@ -1147,6 +1253,8 @@ def patch_mxnext(mxnext=None, mx=None):
         except Exception:
             return []
     done = []
+    seen = _state["mxnext_probe"] = {}
+    V = lambda n: mx.sym.Variable("_sd_probe_" + n)
 
     def roi_align(feat, rois, out_size, stride, name=None, **kw):
         return mx.sym.contrib.ROIAlign_v2(data=feat, rois=rois, pooled_size=(int(out_size), int(out_size)),
@@ -1161,10 +1269,45 @@ def patch_mxnext(mxnext=None, mx=None):
     def decode_bbox(**kw):
         return mx.sym.contrib.DecodeBBox(**kw)
 
-    for attr, fn in (("roi_align", roi_align), ("proposal_target", proposal_target),
-                     ("proposal", proposal), ("decode_bbox", decode_bbox)):
+    # wrapper -> (replacement, the native operator it must turn out to build, a probe call)
+    table = {
+        "roi_align": (roi_align, "_contrib_ROIAlign_v2",
+                      lambda f: f(V("feat"), rois=V("rois"), out_size=7, stride=16, name="_sd_probe")),
+        "proposal_target": (proposal_target, "ProposalTarget",
+                            lambda f: f(rois=V("rois"), gt_boxes=V("gt"), num_classes=81, class_agnostic=False,
+                                        batch_images=1, proposal_without_gt=False, image_rois=64, fg_fraction=0.25,
+                                        fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0, bbox_weight=(1., 1., 1., 1.),
+                                        bbox_mean=(0., 0., 0., 0.), bbox_std=(.1, .1, .2, .2), name="_sd_probe")),
+        "proposal": (proposal, "_contrib_Proposal_v3",
+                     lambda f: f(cls_prob=V("cls"), bbox_pred=V("box"), im_info=V("info"), name="_sd_probe",
+                                 feature_stride=16, scales=(8,), ratios=(0.5, 1.0, 2.0), rpn_pre_nms_top_n=12,
+                                 rpn_post_nms_top_n=6, threshold=0.7, rpn_min_size=0, iou_loss=False,
+                                 output_score=True)),
+        "decode_bbox": (decode_bbox, "_contrib_DecodeBBox",
+                        lambda f: f(rois=V("rois"), bbox_pred=V("box"), im_info=V("info"), name="_sd_probe",
+                                    bbox_mean=(0., 0., 0., 0.), bbox_std=(.1, .1, .2, .2), class_agnostic=False)),
+    }
+    for attr, (fn, native, probe) in table.items():
+        cur = getattr(mxnext, attr, None)
+        if cur is None:
+            continue
+        orig = cur._sd_original if getattr(cur, "_sd_alias", False) else cur   # (a second install())
         try:
-            setattr(mxnext, "_sd_reference_" + attr, getattr(mxnext, attr, None))
+            op, attrs = _head_op(mx, probe(orig))
+        except Exception as e:
+            seen[attr] = "probe failed: %s" % (e,)
+            continue
+        short = native[len("_contrib_"):] if native.startswith("_contrib_") else native
+        if op == "Custom" and str(attrs.get("op_type", "")).startswith(_PREFIX) or str(op).startswith(_PREFIX):
+            seen[attr] = "late binding: already builds %s" % (attrs.get("op_type", op),)
+            continue
+        if op not in (native, short):
+            seen[attr] = "builds %s, not %s: left alone" % (op, native)
+            continue
+        seen[attr] = "builds %s at import-time binding: rebound" % (op,)
+        fn._sd_alias, fn._sd_original = True, orig
+        try:
+            setattr(mxnext, "_sd_reference_" + attr, orig)
             setattr(mxnext, attr, fn)
             done.append("mxnext." + attr)
         except Exception:
@@ -1172,12 +1315,20 @@ def patch_mxnext(mxnext=None, mx=None):
     try:
         import importlib
         m = importlib.import_module("mxnext.tvm.get_top_proposal")
+        cur = m.get_top_proposal
+        orig = cur._sd_original if getattr(cur, "_sd_alias", False) else cur
 
         def get_top_proposal(F, bbox, score, top_n, batch_size=None, name="get_top_proposal", **kw):
+            # TWO results, (bbox, score), as every call site unpacks them: models/FPN/builder.py:319-323 returns
+            # the wrapper's result from get_all_proposal(), and :345 (and symbol/builder.py:36,92,302,
+            # models/maskrcnn/builder.py:113,182, ...: all 18 callers) does
+            # `(proposal, proposal_score) = self.get_all_proposal(...)` before `rois=proposal`.  A plain tuple
+            # of two single-output symbols: nothing multi-output can reach an operator argument by accident.
             sym = mx.sym.Custom(bbox=bbox, score=score, op_type=_PREFIX + "get_top_proposal",
                                 top_n=_param_str(top_n), name=name)
-            return mx.sym.Group([sym[0], sym[1]])
-        m._sd_reference_get_top_proposal = m.get_top_proposal
+            return sym[0], sym[1]
+        get_top_proposal._sd_alias, get_top_proposal._sd_original = True, orig
+        m._sd_reference_get_top_proposal = orig
         m.get_top_proposal = get_top_proposal
         done.append("mxnext.tvm.get_top_proposal.get_top_proposal")
     except Exception:

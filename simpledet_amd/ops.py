@@ -819,60 +819,66 @@ def _dcn_ws(x, kh, kw, pad, stride, dilate):
 
 
 def deform_conv_forward(x, offset, weight, pad=1, stride=1, dilate=1, num_deformable_group=1,
-                        keep_col=False):
-    """DeformableConvolution forward (num_group=1, no_bias): y (N,F,Ho,Wo).  keep_col=True returns
-    (y, workspace): the workspace holds the col matrix; handed to deform_conv_backward(fwd_ws=...)
-    it saves the backward its own im2col."""
+                        keep_col=False, bias=None, num_group=1):
+    """DeformableConvolution forward: y (N,F,Ho,Wo).  weight (F, C / num_group, kh, kw); bias (F) or None
+    (= no_bias).  keep_col=True returns (y, workspace): the workspace holds the col matrix; handed to
+    deform_conv_backward(fwd_ws=...) it saves the backward its own im2col."""
     _chk(x, "data", ndim=4)
     _chk(offset, "offset", ndim=4)
     _chk(weight, "weight", ndim=4)
     N, C, H, W = x.shape
     F, Cw, kh, kw = weight.shape
-    if Cw != C:
-        raise ValueError("weight channels %d != data channels %d (num_group must be 1)" % (Cw, C))
+    num_group = int(num_group)
+    if num_group < 1 or C % num_group or F % num_group:
+        raise ValueError("num_group %d must divide data channels %d and num_filter %d" % (num_group, C, F))
+    if Cw * num_group != C:
+        raise ValueError("weight channels %d != data channels %d / num_group %d" % (Cw, C, num_group))
+    if bias is not None:
+        _chk(bias, "bias", ndim=1)
+        if bias.shape[0] != F:
+            raise ValueError("bias has %d entries, num_filter is %d" % (bias.shape[0], F))
     Ho, Wo = _dcn_out_hw(H, W, kh, kw, pad, stride, dilate)
     if tuple(offset.shape) != (N, num_deformable_group * 2 * kh * kw, Ho, Wo):
         raise ValueError("offset shape %s != %s" % (tuple(offset.shape),
                                                      (N, num_deformable_group * 2 * kh * kw, Ho, Wo)))
     y = torch.empty((N, F, Ho, Wo), device=x.device, dtype=torch.float32)
-    if not keep_col:
-        # no col matrix: sampling fused into the GEMM (3x3, C / groups % 16 == 0, H*W % 4 == 0); other
-        # shapes run im2col + GEMM behind the same entry point, which its workspace size accounts for
-        lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes.restype = ctypes.c_size_t
-        n = int(lib().cdll.sd_deform_conv_fwd_nocol_workspace_bytes(N, C, H, W, F, kh, kw, pad, stride, dilate,
-                                                                    int(num_deformable_group)))
-        ws = torch.empty(n, device=x.device, dtype=torch.uint8)
-        lib().call("sd_deform_conv_fwd_nocol", _p(x), _p(offset), _p(weight), _p(y), N, C, H, W, F, kh, kw,
-                   pad, stride, dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
-        return y
-    ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
-    lib().call("sd_deform_conv_fwd", _p(x), _p(offset), _p(weight), _p(y), N, C, H, W, F, kh, kw,
-               pad, stride, dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
-    return y, ws
+    # keep_col = False: no col matrix where the shape allows -- sampling fused into the GEMM (3x3, num_group 1,
+    # C / groups % 16 == 0, H*W % 4 == 0); other shapes run im2col + GEMM behind the same entry point, which
+    # its workspace size accounts for
+    n = int(lib().cdll.sd_deform_convolution_fwd_workspace_bytes(N, C, H, W, F, kh, kw, pad, stride, dilate,
+                                                                 int(num_deformable_group), num_group,
+                                                                 int(bool(keep_col))))
+    ws = torch.empty(n, device=x.device, dtype=torch.uint8)
+    lib().call("sd_deform_convolution_fwd", _p(x), _p(offset), _p(weight), _p(bias) if bias is not None else None,
+               _p(y), N, C, H, W, F, kh, kw, pad, stride, dilate, int(num_deformable_group), num_group,
+               int(bool(keep_col)), _p(ws), ctypes.c_size_t(n), _stream())
+    return (y, ws) if keep_col else y
 
 
 def deform_conv_backward(out_grad, x, offset, weight, pad=1, stride=1, dilate=1,
                          num_deformable_group=1, req=("write", "write", "write"), grads=None,
-                         fwd_ws=None):
-    """-> (d_data, d_offset, d_weight).  fwd_ws: the workspace deform_conv_forward(keep_col=True)
-    returned for the same (x, offset): its col matrix is reused (sd_deform_conv_bwd_cached)."""
+                         fwd_ws=None, num_group=1, bias=False):
+    """-> (d_data, d_offset, d_weight[, d_bias]).  fwd_ws: the workspace deform_conv_forward(keep_col=True)
+    returned for the same (x, offset): its col matrix is reused.  bias=True (the op had a bias): a fourth
+    req / gradient, d_bias (F) = sum over images and pixels of out_grad."""
     _chk(out_grad, "out_grad", ndim=4)
     N, C, H, W = x.shape
     F, _, kh, kw = weight.shape
     r = [REQ[v] if isinstance(v, str) else int(v) for v in req]
+    if bias and len(r) == 3:
+        r.append(REQ["write"])
     if grads is None:
         grads = (torch.empty_like(x), torch.empty_like(offset), torch.empty_like(weight))
+        if bias:
+            grads = grads + (torch.empty(F, device=x.device, dtype=torch.float32),)
     ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
+    col = None
     if fwd_ws is not None:
-        col = (fwd_ws.data_ptr() + 255) & ~255  # sd_deform_conv_col_of_workspace
-        lib().call("sd_deform_conv_bwd_cached", _p(out_grad), _p(x), _p(offset), _p(weight),
-                   ctypes.c_void_p(col), _p(grads[0]), _p(grads[1]), _p(grads[2]), r[0], r[1], r[2], N, C,
-                   H, W, F, kh, kw, pad, stride, dilate, int(num_deformable_group), _p(ws),
-                   ctypes.c_size_t(n), _stream())
-        return grads
-    lib().call("sd_deform_conv_bwd", _p(out_grad), _p(x), _p(offset), _p(weight), _p(grads[0]),
-               _p(grads[1]), _p(grads[2]), r[0], r[1], r[2], N, C, H, W, F, kh, kw, pad, stride,
-               dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n), _stream())
+        col = ctypes.c_void_p((fwd_ws.data_ptr() + 255) & ~255)  # sd_deform_conv_col_of_workspace
+    lib().call("sd_deform_convolution_bwd", _p(out_grad), _p(x), _p(offset), _p(weight), col, _p(grads[0]),
+               _p(grads[1]), _p(grads[2]), _p(grads[3]) if bias else None, r[0], r[1], r[2],
+               r[3] if bias else REQ["null"], N, C, H, W, F, kh, kw, pad, stride, dilate,
+               int(num_deformable_group), int(num_group), _p(ws), ctypes.c_size_t(n), _stream())
     return grads
 
 

@@ -74,21 +74,32 @@ def dcn_col(x, offset, kernel=(3, 3), pad=1, stride=1, dil=1, dgroup=1):
     return val.reshape(N, C, kh * kw, Ho, Wo)
 
 
-def dcn_forward(x, offset, weight, pad=1, stride=1, dil=1, dgroup=1):
-    """-> y (N, F, Ho, Wo) in fp64"""
-    F, C, kh, kw = weight.shape
+def dcn_forward(x, offset, weight, pad=1, stride=1, dil=1, dgroup=1, bias=None, num_group=1):
+    """-> y (N, F, Ho, Wo) in fp64.  weight (F, C / num_group, kh, kw): filter block g sees the channel
+    block g (the definition of a grouped convolution); bias (F) added per filter."""
+    F, Cg, kh, kw = weight.shape
+    N, C = x.shape[:2]
     col = dcn_col(x, offset, (kh, kw), pad, stride, dil, dgroup)
-    return torch.einsum("fck,nckhw->nfhw", weight.double().reshape(F, C, kh * kw), col)
+    Ho, Wo = col.shape[-2:]
+    colg = col.reshape(N, num_group, Cg, kh * kw, Ho, Wo)
+    wg = weight.double().reshape(num_group, F // num_group, Cg, kh * kw)
+    y = torch.einsum("gfck,ngckhw->ngfhw", wg, colg).reshape(N, F, Ho, Wo)
+    if bias is not None:
+        y = y + bias.double().reshape(1, F, 1, 1)
+    return y
 
 
-def dcn_grads(x, offset, weight, dy, pad=1, stride=1, dil=1, dgroup=1):
-    """autograd gradients of <dcn_forward(x, offset, weight), dy> -> (y, dx, doffset, dweight), fp64"""
+def dcn_grads(x, offset, weight, dy, pad=1, stride=1, dil=1, dgroup=1, bias=None, num_group=1):
+    """autograd gradients of <dcn_forward(x, offset, weight[, bias]), dy> -> (y, dx, doffset, dweight[, dbias]),
+    fp64"""
     xr = x.double().clone().requires_grad_(True)
     orr = offset.double().clone().requires_grad_(True)
     wr = weight.double().clone().requires_grad_(True)
-    y = dcn_forward(xr, orr, wr, pad, stride, dil, dgroup)
+    br = bias.double().clone().requires_grad_(True) if bias is not None else None
+    y = dcn_forward(xr, orr, wr, pad, stride, dil, dgroup, br, num_group)
     (y * dy.double()).sum().backward()
-    return y.detach(), xr.grad, orr.grad, wr.grad
+    out = (y.detach(), xr.grad, orr.grad, wr.grad)
+    return out + (br.grad,) if bias is not None else out
 
 
 def keep_off_the_kinks(offset, H, W, kernel=(3, 3), pad=1, stride=1, dil=1, dgroup=1, margin=2e-3):

@@ -544,3 +544,111 @@ def test_backward_with_the_forward_col_matrix(ops):
     out.backward(dy)
     assert torch.equal(out.detach(), y) and torch.equal(offr.grad, a[1])
     assert close(xr.grad, a[0]) and close(wr.grad, a[2])
+
+
+# ---- the operator with a bias and num_group (models/RepPoints/builder.py:215-245, models/sepc/sepc_dconv.py:5-16)
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, C=64, H=12, W=16, F=24, dg=4, bias=True),                       # fused forward + bias epilogue
+    dict(N=2, C=256, H=50, W=84, F=256, dg=1, bias=True, off_scale=2.0),      # the RepPoints head: 256 -> 256, one dgroup
+    dict(N=1, C=64, H=25, W=44, F=300, dg=4, bias=True, off_scale=2.0),       # two filter tiles
+    dict(N=2, C=64, H=25, W=42, F=24, dg=4, bias=True),                       # H*W % 4 != 0: im2col + GEMM + bias pass
+    dict(N=3, C=8, H=9, W=11, F=6, dg=1, bias=True),                          # tiny, unaligned rows
+    dict(N=2, C=64, H=12, W=16, F=24, dg=4, bias=True, G=2),                  # filter groups
+    dict(N=2, C=32, H=9, W=11, F=12, dg=2, bias=False, G=4),
+    dict(N=2, C=24, H=10, W=12, F=8, dg=3, bias=True, G=2, stride=2),         # filter groups != deformable groups
+    dict(N=2, C=32, H=12, W=16, F=16, dg=2, bias=True, G=1, pad=2, dil=2),
+])
+def test_full_operator_bias_and_groups(ops, oracle, cfg):
+    """sd_deform_convolution_fwd / _bwd against the oracle's DeformableConvolutionOp restatement: y and the
+    four gradients, col-free and col-keeping forward (same bits whenever both are im2col + GEMM), the
+    backward with and without the kept col, req = add on every gradient."""
+    import torch
+    cfg = dict(cfg)
+    has_bias, G = cfg.pop("bias"), cfg.pop("G", 1)
+    x, off, w, kw = _case(61, **cfg)
+    if x.shape[1] >= 256:
+        w *= 0.25
+    F = w.shape[0]
+    w = np.ascontiguousarray(w[:, : x.shape[1] // G])
+    b = (np.random.RandomState(62).standard_normal(F) * 3).astype(np.float32) if has_bias else None
+    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"], num_group=G)
+    tx, to, tw, tb = _t(x), _t(off), _t(w), (_t(b) if has_bias else None)
+    want = oracle.deform_convolution_fwd(x, off, w, b, num_group=G, **_nok(kw))
+    y = ops.deform_conv_forward(tx, to, tw, bias=tb, **a)
+    yk, fws = ops.deform_conv_forward(tx, to, tw, bias=tb, keep_col=True, **a)
+    for got in (y, yk):
+        err = float(np.abs(got.cpu().numpy() - want).max())
+        assert err <= _bar(want), err
+    if has_bias:   # the bias really is added after the products: y - y(no bias) == bias up to one rounding
+        y0 = ops.deform_conv_forward(tx, to, tw, **a)
+        d = (y - y0).cpu().numpy() - b.reshape(1, -1, 1, 1)
+        assert float(np.abs(d).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))
+    dy = np.random.RandomState(63).standard_normal(want.shape).astype(np.float32)
+    wg = oracle.deform_convolution_bwd(dy, x, off, w, bias=has_bias, num_group=G, **_nok(kw))
+    tdy = _t(dy)
+    names = ("d_data", "d_offset", "d_weight", "d_bias")
+    for fw in (None, fws):
+        g = ops.deform_conv_backward(tdy, tx, to, tw, fwd_ws=fw, bias=has_bias, **a)
+        assert len(g) == len(wg)
+        for nm, got, wnt in zip(names, g, wg):
+            err = float(np.abs(got.cpu().numpy() - wnt).max())
+            assert err <= _bar(wnt), (nm, fw is not None, err, float(np.abs(wnt).max()))
+    # req = add on everything: gradients land on top of what the buffers held
+    g0 = [torch.full_like(t, 2.0) for t in (tx, to, tw)] + ([torch.full((F,), 2.0, device="cuda")] if has_bias else [])
+    ops.deform_conv_backward(tdy, tx, to, tw, req=("add",) * len(g0), grads=tuple(g0), bias=has_bias, **a)
+    for nm, got, wnt in zip(names, g0, wg):
+        assert float(np.abs(got.cpu().numpy() - (wnt + 2)).max()) <= _bar(wnt), nm
+    # req = null on the bias leaves it alone
+    if has_bias:
+        gb = torch.full((F,), 5.0, device="cuda")
+        ops.deform_conv_backward(tdy, tx, to, tw, req=("write", "write", "write", "null"),
+                                 grads=(torch.empty_like(tx), torch.empty_like(to), torch.empty_like(tw), gb),
+                                 bias=True, **a)
+        assert float((gb - 5.0).abs().max()) == 0
+    # d_bias is a fixed-order sum: the same bits in every run
+    if has_bias:
+        g1 = ops.deform_conv_backward(tdy, tx, to, tw, bias=True, **a)
+        g2 = ops.deform_conv_backward(tdy, tx, to, tw, bias=True, **a)
+        assert torch.equal(g1[3], g2[3])
+
+
+@pytest.mark.gpu
+def test_autograd_mirror_with_bias_and_groups(ops):
+    """contrib.DeformableConvolution(data, offset, weight, bias, num_group=...) == the raw calls; under
+    no_grad (or when nothing needs a gradient) the forward keeps no col matrix."""
+    import torch
+    from simpledet_amd import contrib
+    torch.manual_seed(7)
+    N, C, H, W, F, G = 2, 32, 12, 16, 16, 2
+    x = torch.randn(N, C, H, W, device="cuda")
+    off = torch.randn(N, 2 * 18, H, W, device="cuda")
+    w = torch.randn(F, C // G, 3, 3, device="cuda") * 0.1
+    b = torch.randn(F, device="cuda")
+    a = dict(pad=1, stride=1, dilate=1, num_deformable_group=2, num_group=G)
+    y = ops.deform_conv_forward(x, off, w, bias=b, **a)
+    dy = torch.randn_like(y)
+    g = ops.deform_conv_backward(dy, x, off, w, bias=True, **a)
+    xr, offr, wr, br = (t.clone().requires_grad_(True) for t in (x, off, w, b))
+    out = contrib.DeformableConvolution(xr, offr, wr, br, kernel=(3, 3), pad=(1, 1), num_filter=F, num_group=G,
+                                        num_deformable_group=2)
+    out.backward(dy)
+    close = lambda u, v: float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max()))
+    assert close(out.detach(), y) and torch.equal(offr.grad, g[1]) and torch.equal(br.grad, g[3])
+    assert close(xr.grad, g[0]) and close(wr.grad, g[2])
+    with pytest.raises(ValueError):
+        contrib.DeformableConvolution(x, off, w, None, kernel=(3, 3), pad=(1, 1), num_group=G)   # no_bias=False, no bias
+    # no gradient wanted: the col-free path (its workspace is a few MB, not N*C*9*Ho*Wo*4 bytes)
+    calls = []
+    real = ops.deform_conv_forward
+    try:
+        ops.deform_conv_forward = lambda *p, **k: (calls.append(k.get("keep_col", False)), real(*p, **k))[1]
+        with torch.no_grad():
+            contrib.DeformableConvolution(xr, offr, wr, br, kernel=(3, 3), pad=(1, 1), num_group=G,
+                                          num_deformable_group=2)
+        contrib.DeformableConvolution(x, off, w, b, kernel=(3, 3), pad=(1, 1), num_group=G, num_deformable_group=2)
+        contrib.DeformableConvolution(xr, offr, wr, br, kernel=(3, 3), pad=(1, 1), num_group=G,
+                                      num_deformable_group=2)
+    finally:
+        ops.deform_conv_forward = real
+    assert calls == [False, False, True]

@@ -214,3 +214,43 @@ def test_backward_weights_use_the_absolute_frame_not_the_forwards_patch_frame(or
     assert fwd_w != bwd_w                                              # not bit-adjoint ...
     assert abs(fwd_w - exact) < 2e-7 and abs(bwd_w - exact) < 4e-6     # ... both right to fp32 rounding of their frame
     assert abs(fwd_w - bwd_w) < 4e-6
+
+
+# ---- the operator with a bias and num_group > 1 (models/RepPoints/builder.py:215-245, models/sepc/sepc_dconv.py:5-16)
+FULL = {
+    "bias": dict(bias=True, G=1),
+    "bias_one_dgroup": dict(bias=True, G=1, dg=1, C=8),            # RepPoints: num_deformable_group default 1
+    "groups2": dict(bias=False, G=2, C=8, F=6, dg=2),
+    "groups4_bias": dict(bias=True, G=4, C=16, F=8, dg=2, H=10, W=12),
+    "groups_ne_dgroups": dict(bias=True, G=2, C=12, F=4, dg=3),    # filter groups and deformable groups differ
+    "stride2_bias": dict(bias=True, G=1, stride=2, H=14, W=15),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_operator_oracle_against_autograd(oracle, name):
+    """orc_deform_convolution_fwd / _bwd (the restated DeformableConvolutionOp::Forward / ::Backward with
+    num_group and bias) against the independent fp64 statement + autograd: y, d_x, d_offset, d_weight,
+    d_bias on full tensors."""
+    cfg = dict(FULL[name])
+    has_bias, G = cfg.pop("bias"), cfg.pop("G")
+    x, off, w, kw = _case(41, **cfg)
+    F = w.shape[0]
+    w = np.ascontiguousarray(w[:, : x.shape[1] // G])                 # (F, C / G, kh, kw)
+    b = np.random.RandomState(42).standard_normal(F).astype(np.float32) if has_bias else None
+    geo = (kw["kernel"], kw["pad"], kw["stride"], kw["dil"], kw["dgroup"])
+    off = R.keep_off_the_kinks(_t(off), x.shape[2], x.shape[3], *geo).numpy()
+    yo = oracle.deform_convolution_fwd(x, off, w, b, num_group=G, **_nok(kw))
+    dy = np.random.RandomState(43).standard_normal(yo.shape).astype(np.float32)
+    ref = R.dcn_grads(_t(x), _t(off), _t(w), _t(dy), *geo[1:], bias=_t(b) if has_bias else None, num_group=G)
+    got = oracle.deform_convolution_bwd(dy, x, off, w, bias=has_bias, num_group=G, **_nok(kw))
+    assert _rel(yo, ref[0].numpy()) <= 1e-5
+    for nm, g_, r_ in zip(("d_x", "d_offset", "d_weight", "d_bias"), got, ref[1:]):
+        assert _rel(g_, r_.numpy()) <= 1e-5, (nm, _rel(g_, r_.numpy()))
+    if G == 1 and not has_bias:
+        return
+    # and the group / bias plumbing reduces to the plain operator: one group, zero bias == orc_deform_conv_fwd
+    if G == 1:
+        y0 = oracle.deform_conv_fwd(x, off, w, **_nok(kw))
+        np.testing.assert_array_equal(oracle.deform_convolution_fwd(x, off, w, None, num_group=1, **_nok(kw)), y0)
+        np.testing.assert_allclose(yo - b.reshape(1, -1, 1, 1), y0, atol=2e-6 * max(1.0, float(np.abs(yo).max())))

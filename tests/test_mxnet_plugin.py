@@ -79,8 +79,25 @@ def test_other_props_shapes(plugin):
                                                 num_deformable_group="4", no_bias="True")
     ins, outs = p.infer_shape([(2, 256, 50, 84), None, None])
     assert ins[1] == (2, 72, 50, 84) and ins[2] == (256, 256, 3, 3) and outs == [(2, 256, 50, 84)]
-    with pytest.raises(ValueError, match="no_bias"):
-        props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="8")
+    assert p.list_arguments() == ["data", "offset", "weight"]
+    # upstream's defaults: no_bias = False -> a fourth argument (models/RepPoints/builder.py:215-226);
+    # num_group: weight (F, C / G, kh, kw) (models/sepc/sepc_dconv.py:12-16)
+    p = props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="8", pad="(1,1)", num_group="2")
+    assert p.list_arguments() == ["data", "offset", "weight", "bias"]
+    ins, outs = p.infer_shape([(2, 16, 10, 12), None, None, None])
+    assert ins == [(2, 16, 10, 12), (2, 18, 10, 12), (8, 8, 3, 3), (8,)] and outs == [(2, 8, 10, 12)]
+    assert p.declare_backward_dependency(["dy"], ["x", "o", "w", "b"], ["y"]) == ["dy", "x", "o", "w"]
+    with pytest.raises(ValueError, match="group"):
+        props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="8", num_group="3").infer_shape(
+            [(2, 16, 10, 12), None, None, None])
+    # what the kernels do not take is refused by the prop (install()'s alias never gets here: it hands
+    # such calls back to the native constructor, tests/test_reference_config_sweep.py)
+    with pytest.raises(ValueError, match="square"):
+        props["_contrib_DeformableConvolution"](kernel="(3,3)", num_filter="8", stride="(1,2)")
+    sup = props["_contrib_DeformableConvolution"].sd_supports
+    assert sup(dict(kernel="(3, 3)", num_filter="8", no_bias="False", num_group="4")) == ""
+    assert "layout" in sup(dict(kernel="(3, 3)", num_filter="8", layout="NHWC"))
+    assert "not one" in sup(dict(kernel="(3, 3)", num_filter="8", cudnn_tune="off"))
 
 
 def test_proposal_v3_prop(plugin):
@@ -321,3 +338,47 @@ def test_fused_fpn_roi_align_adapter_on_gpu(plugin, oracle, pooled):
     for g, wv in zip(gin[:-1], wd):
         assert np.abs(g.t.cpu().numpy() - wv).max() <= 1e-4
     assert float(gin[-1].t.abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(no_bias="True", G=1), dict(no_bias="False", G=1), dict(no_bias="False", G=2)])
+def test_deformable_convolution_adapter_on_gpu(plugin, oracle, cfg):
+    """The DeformableConvolution CustomOp as MXNet would drive it: arguments data, offset, weight[, bias],
+    training forward (col kept) -> backward with the kept col, inference forward (col-free), req = add on
+    the bias gradient; against the oracle's DeformableConvolutionOp restatement."""
+    import torch
+    _, props, _ = plugin
+    w = mx_stub.wrap
+    G, has_b = cfg["G"], cfg["no_bias"] == "False"
+    rs = np.random.RandomState(5)
+    N, C, H, W, F, dg = 2, 32, 12, 16, 16, 2
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    off = (rs.standard_normal((N, dg * 18, H, W)) * 1.5).astype(np.float32)
+    wt = (rs.standard_normal((F, C // G, 3, 3)) * 0.2).astype(np.float32)
+    b = rs.standard_normal(F).astype(np.float32) if has_b else None
+    prop = props["_contrib_DeformableConvolution"](kernel="(3, 3)", num_filter=str(F), pad="(1, 1)",
+                                                   num_deformable_group=str(dg), num_group=str(G),
+                                                   no_bias=cfg["no_bias"])
+    ishape, oshape = prop.infer_shape([x.shape] + [None] * (3 if has_b else 2))
+    assert ishape[1] == off.shape and ishape[2] == wt.shape
+    op = prop.create_operator(None, None, None)
+    tin = [w(torch.from_numpy(a).cuda()) for a in ((x, off, wt, b) if has_b else (x, off, wt))]
+    want = oracle.deform_convolution_fwd(x, off, wt, b, pad=1, stride=1, dil=1, dgroup=dg, num_group=G)
+    bar = lambda v: 1e-4 * max(1.0, float(np.abs(v).max()) / 32.0)
+    for is_train in (False, True):
+        tout = [w(torch.empty(oshape[0], device="cuda"))]
+        op.forward(is_train, ["write"], tin, tout, [])
+        assert float(np.abs(tout[0].t.cpu().numpy() - want).max()) <= bar(want), is_train
+    assert op._fwd_ws is not None                      # training: the col matrix waits for the backward
+    dy = rs.standard_normal(want.shape).astype(np.float32)
+    wg = oracle.deform_convolution_bwd(dy, x, off, wt, bias=has_b, pad=1, stride=1, dil=1, dgroup=dg, num_group=G)
+    grads = [w(torch.empty(a.shape, device="cuda")) for a in ((x, off, wt, b) if has_b else (x, off, wt))]
+    req = ["write"] * 3
+    if has_b:
+        grads[3].t.fill_(1.5)
+        req.append("add")
+    op.backward(req, [w(torch.from_numpy(dy).cuda())], tin, tout, grads, [])
+    assert op._fwd_ws is None
+    for i, (g_, r_) in enumerate(zip(grads, wg)):
+        r_ = r_ + 1.5 if i == 3 else r_
+        assert float(np.abs(g_.t.cpu().numpy() - r_).max()) <= bar(r_), i

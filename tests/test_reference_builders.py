@@ -48,7 +48,8 @@ def test_faster_r50v1_fpn_1x_train_and_test_symbols_route_to_the_plugin():
         cfg = importlib.import_module("config.faster_r50v1_fpn_1x")
         plug, _ = _install(R)
         assert plug._state["fpn_patched"] is True
-        assert "mxnext.roi_align" in plug._state["mxnext_patched"]
+        # (this mxnext stand-in looks mx.sym.* up at call time: the probes see sd_* nodes, nothing is rebound)
+        assert plug._state["mxnext_probe"]["roi_align"].startswith("late binding")
         train = _model_param(cfg.get_config(True)).train_symbol
         ops = _ops(train)
         # the FPN extractor: ONE fused node instead of assign + 4 x ROIAlign_v2 + add_n
@@ -189,9 +190,13 @@ def test_mxnext_wrappers_are_aliased_explicitly(late):
         mx = R.mx
         SB = importlib.import_module("symbol.builder")
         plug, _ = _install(R)
-        assert set(plug._state["mxnext_patched"]) >= {"mxnext.roi_align", "mxnext.proposal_target", "mxnext.proposal",
-                                                      "mxnext.decode_bbox",
-                                                      "mxnext.tvm.get_top_proposal.get_top_proposal"}
+        wrappers = {"mxnext.roi_align", "mxnext.proposal_target", "mxnext.proposal", "mxnext.decode_bbox"}
+        assert "mxnext.tvm.get_top_proposal.get_top_proposal" in plug._state["mxnext_patched"]
+        if late:    # call-time lookup: the probes find sd_* nodes already, nothing to rebind
+            assert not wrappers & set(plug._state["mxnext_patched"])
+            assert all(v.startswith("late binding") for v in plug._state["mxnext_probe"].values())
+        else:       # import-time binding: the probes find the native operators of the same names -> rebound
+            assert wrappers <= set(plug._state["mxnext_patched"])
 
         class RoiParam:
             fp16 = False
@@ -202,5 +207,34 @@ def test_mxnext_wrappers_are_aliased_explicitly(late):
         assert ra.params == {"pooled_size": "(7, 7)", "spatial_scale": "0.0625"}
         top = importlib.import_module("mxnext.tvm.get_top_proposal").get_top_proposal(
             mx.symbol, bbox=mx.sym.var("b"), score=mx.sym.var("s"), top_n=2000, batch_size=2)
+        # (bbox, score), as models/FPN/builder.py:345 unpacks it; each a single-output symbol (a
+        # multi-output symbol must never reach `rois=` -- the stand-in's operators now refuse one)
         b, s = top
         assert RS.source(b).op_type == "sd_get_top_proposal" and RS.source(b) is RS.source(s)
+        assert (b.nout, b.index, s.nout, s.index) == (1, 0, 1, 1)
+        with pytest.raises(TypeError):
+            mx.sym.ProposalTarget(rois=RS.source(b), gt_boxes=mx.sym.var("gt"), num_classes=81, batch_images=1,
+                                  image_rois=64, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.0)
+
+
+def test_a_wrapper_that_builds_another_operator_is_left_alone():
+    """mxnext is not vendored, so `X.proposal` may bind `_contrib_Proposal` (proposal.cu: other +1
+    convention, clamp and min-size filter than proposal_v3.cu).  patch_mxnext() probes the saved original
+    and rebinds only a wrapper that builds the operator the plugin replaces under the same name."""
+    with RS.reference_modules(late_binding=False) as R:
+        mx, X = R.mx, R.X
+        frozen_proposal = lambda **kw: RS.Symbol("Proposal", [v for v in kw.values() if isinstance(v, RS.Symbol)],
+                                                 {k: v for k, v in kw.items() if not isinstance(v, RS.Symbol)},
+                                                 kw.get("name"), 2)
+        X.proposal = frozen_proposal
+        broken = lambda **kw: (_ for _ in ()).throw(RuntimeError("tvm runtime missing"))
+        X.decode_bbox = broken
+        plug, _ = _install(R)
+        assert X.proposal is frozen_proposal and "left alone" in plug._state["mxnext_probe"]["proposal"]
+        assert X.decode_bbox is broken and plug._state["mxnext_probe"]["decode_bbox"].startswith("probe failed")
+        assert "mxnext.roi_align" in plug._state["mxnext_patched"]
+        # a second install() keeps the FIRST originals (ADVICE r4, low)
+        first = X._sd_reference_roi_align
+        plug2, _ = _install(R)
+        assert X._sd_reference_roi_align is first and not getattr(first, "_sd_alias", False)
+        assert not getattr(mx.sym.contrib._sd_reference_ROIAlign_v2, "_sd_alias", False)
