@@ -77,6 +77,11 @@ def parse():
     ap.add_argument("--no-ops", action="store_true",
                     help="skip the per-operator secondary measurements (bench_ops.py)")
     ap.add_argument("--no-extra", action="store_true", help="skip the un-fused 4-op graph path")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="HIP events (forward / backward split for the roofline) are recorded in every "
+                         "n-th step of the timed region: an event record is a marker packet with a release "
+                         "fence between two launches (+3-4 us each, measured: tools/event_cost_bench.py), "
+                         "three per step inflate the very step they time by ~6 %%; 1 = every step")
     return ap.parse_args()
 
 
@@ -87,6 +92,38 @@ def kernel_source_sha():
     for f in ("roi_align.hip", "common.h", "runtime.hip"):
         h.update(open(os.path.join(ROOT, "simpledet_amd", "csrc", f), "rb").read())
     return h.hexdigest()
+
+
+def nms_l2_hit_rates():
+    """north_star: "rocprof reports ... L2-hit for NMS".  PMC counters cannot be read inside this run; the
+    newest committed profile of the secondary ops (profiles/*_ops_pmc_summary.json, tools/prof_ops.sh:
+    rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum over bench_ops.run) is quoted -- only when it was taken with
+    the nms.hip / soft_nms.hip / common.h of this tree (per-file sha256 recorded by
+    tools/summarize_profile.py).  -> ({kernel: l2_hit_rate}, source) or (None, why not)."""
+    import glob
+    import hashlib
+    import re
+    need = {}
+    for f in ("nms.hip", "soft_nms.hip", "common.h"):
+        need[f] = hashlib.sha256(open(os.path.join(ROOT, "simpledet_amd", "csrc", f), "rb").read()).hexdigest()
+    cands = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_ops_pmc_summary.json"))
+             if re.match(r"^r\d+[a-z]?_ops_pmc_summary\.json$", os.path.basename(f))]
+    for path in sorted(cands)[::-1]:
+        try:
+            prof = json.load(open(path))
+            sha = prof.get("source_sha256") or {}
+            if any(sha.get(f) != h for f, h in need.items()):
+                continue
+            out = {}
+            for name, d in prof["kernels"].items():
+                m = re.search(r"sd::(nms_\w+|soft_nms_kernel)", name)
+                if m and "l2_hit_rate" in d:
+                    out[m.group(1)] = round(d["l2_hit_rate"], 4)
+            if out:
+                return out, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, "no committed *_ops_pmc_summary.json was taken with the current nms.hip / soft_nms.hip / common.h"
 
 
 def algorithmic_bytes(n_img, n_roi, channels, shapes, pooled=49):
@@ -265,11 +302,19 @@ def main():
         return max(vals), vals
 
     # ---- THE timed region: exactly K steps of the path on every rank, nothing else in it ----
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    # HIP events inside it split forward / backward for the roofline -- on every `event_stride`-th step
+    # only: a record between two launches is a marker packet + release fence that
+    # costs the step it times 3-4 us (profiles/r05b_event_cost.txt), and with three of them in every step
+    # the timed region measured its own instrumentation (0.1928 against 0.1817 ms per step, same box).
+    stride = max(1, int(args.event_stride))
+    # (steps s/2, s/2 + s, ...: not step 0, whose first launch follows the barrier's synchronise into an empty
+    # queue -- its event interval would time the launch latency, not the kernel)
+    event_steps = [i for i in range(args.steps) if i % stride == stride // 2] or [args.steps - 1]
+    events = {i: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for i in event_steps}
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i])
+        step(events.get(i))
     barrier()
     elapsed_local = time.perf_counter() - t0
     elapsed, vals = max_over_ranks(elapsed_local)
@@ -285,8 +330,10 @@ def main():
             scaling["grad_allreduce"] = legs_grad_allreduce(step, reducer, barrier, max_over_ranks, args, world,
                                                             grad_mb, t_single, elapsed)
 
-    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    fwd_samples = [events[i][0].elapsed_time(events[i][1]) for i in event_steps]
+    bwd_samples = [events[i][1].elapsed_time(events[i][2]) for i in event_steps]
+    fwd_ms = float(np.mean(fwd_samples))
+    bwd_ms = float(np.mean(bwd_samples))
     ms_per_step = elapsed * 1e3 / args.steps
     total_images = args.images * world * args.steps
     value = total_images / elapsed
@@ -406,6 +453,11 @@ def main():
         "avg_launch_ms": fwd_ms,
         "kernel_note": "names reported by the library for the dispatch it took (sd_last_dispatch); avg_launch_ms "
                        "spans every launch of the forward op incl. its rois-only pre-pass",
+        "event_steps": event_steps,
+        "event_note": "HIP events on the torch stream the kernels are launched on, inside the timed region, on "
+                      "every %d-th step (a record between launches costs 3-4 us of the step it times)" % stride,
+        "fwd_ms_min_max": [float(min(fwd_samples)), float(max(fwd_samples))],
+        "bwd_ms_min_max": [float(min(bwd_samples)), float(max(bwd_samples))],
         "backward": {
             "kernel": bwd_kernel,
             "achieved": alg / (bwd_ms * 1e-3) / 1e9,
@@ -500,6 +552,12 @@ def main():
         del feats, d_feats, dy
         torch.cuda.empty_cache()
         extra["ops"] = bench_ops.run(args.seed, cpu=not args.no_cpu_baseline)
+        l2, l2_src = nms_l2_hit_rates()
+        for key, kernels in (("nms", ("nms_sort_kernel", "nms_mask_kernel", "nms_scan_kernel")),
+                             ("soft_nms", ("soft_nms_kernel",))):
+            if key in extra["ops"]:
+                extra["ops"][key]["l2_hit"] = ({k: l2[k] for k in kernels if k in l2} if l2 else None)
+                extra["ops"][key]["l2_hit_source"] = l2_src
         if cpu_baseline is not None and "cpu_ms" in extra["ops"]["nms"]:
             # north_star: GPU vs CPU throughput of RoIAlign fwd+bwd + NMS on the same inputs
             gpu_ms = ms_per_step + extra["ops"]["nms"]["ms"]

@@ -62,6 +62,11 @@ def main(out):
     for f in ("roi_align.hip", "common.h", "runtime.hip"):
         h.update(open(os.path.join(root, "simpledet_amd", "csrc", f), "rb").read())
     res["kernel_source_sha256"] = h.hexdigest()
+    # ... and per file, for the quotes that concern other kernels (bench.py: NMS L2 hit rates need nms.hip /
+    # soft_nms.hip / common.h unchanged)
+    res["source_sha256"] = {}
+    for f in sorted(glob.glob(os.path.join(root, "simpledet_amd", "csrc", "*.h*"))):
+        res["source_sha256"][os.path.basename(f)] = hashlib.sha256(open(f, "rb").read()).hexdigest()
     json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
 
