@@ -378,6 +378,33 @@ def test_soft_nms_ties_duplicates_and_full_size(ops, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threads", [256, 128, 64])
+def test_soft_nms_nan_inf_scores_and_lane_count_boundaries(ops, oracle, threads):
+    """NaN / +-inf scores (a NaN score only ever wins as box i itself: cpu_nms.pyx:116-130 starts the running
+    maximum from it and `maxscore < x` is false for NaN on either side), ties, duplicates, every method, ragged
+    counts, sizes around the lane-count boundaries -- at every workgroup width the kernel is built for."""
+    from simpledet_amd._lib import lib
+    rs = np.random.RandomState(9)
+    d = synth.nms_dets(3, 400)
+    d[:, 4] = np.round(d[:, 4] * 8) / 8
+    d[100:150] = d[:50]
+    weird = synth.nms_dets(6, 400, mode="clustered")
+    weird[[5, 77, 300], 4] = np.nan
+    weird[[9, 200], 4] = np.inf
+    weird[[11], 4] = -np.inf
+    dets = np.stack([d, synth.nms_dets(4, 400, mode="all_overlap"), weird])
+    lib().set_tuning("soft_nms_threads", threads)
+    try:
+        for method in (0, 1, 2):
+            _soft_check(ops, oracle, dets, np.array([400, 400, 400]), 0.5, 0.3, 0.01, method)
+        for Nmax in (1, 63, 64, 65, 127, 129, 255, 256, 257, 511, 513, 1000, 1025, 2049):
+            b = np.stack([synth.nms_dets(70 + Nmax + p, Nmax) for p in range(2)])
+            _soft_check(ops, oracle, b, np.array([Nmax, int(rs.randint(0, Nmax + 1))]), 0.5, 0.5, 0.001, 1)
+    finally:
+        lib().set_tuning("soft_nms_threads", 256)
+
+
+@pytest.mark.gpu
 def test_soft_nms_matches_reference_cython_fixture(ops):
     g = np.load(os.path.join(GOLD, "cython_nms.npz"))
     for seed in range(3):
