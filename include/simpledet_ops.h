@@ -182,10 +182,9 @@ int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const 
  * digits than the reference's fp32 adds would give it.  Non-finite dY and extreme weight pile-ups
  * switch a workgroup to fp32 compare-and-swap adds by themselves.  Callers that need fp32-relative
  * sums everywhere select those adds for every workgroup with
- *     sd_set_tuning("roi_align_bwd_packed", 0)   (packed arg-max)
- *     sd_set_tuning("roi_align_bwd", 1) + sd_set_tuning("roi_align_bwd_accum", 0)   (float arg-max planes)
- * at ~1.3-2.5 x the time; those paths sum in the order the hardware serves the adds, like the
- * reference.
+ *     sd_set_tuning("roi_align_bwd_fx", 0)
+ * (packed arg-max and float arg-max planes alike) at ~1.2-1.5 x the time; the sums then depend on the order
+ * in which the hardware serves the adds, like the reference's.
  *   EXCEPTION: sd_roi_align_v2_bwd on a single map with C % 4 == 0 whose four planes fit 72 KB of LDS
  * (the C4 family) runs roi_align_bwd_flt4_kernel by default, which already sums with fp32
  * compare-and-swap adds in hardware order: fp32-relative accuracy, NOT bit-reproducible run to run.

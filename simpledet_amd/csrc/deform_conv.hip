@@ -1377,10 +1377,7 @@ static int launch_gemm_split(const GemmArgs& g, dim3 grid, hipStream_t st) {
 // SIMD; 192-wide: ~96 TF, 2 waves per SIMD); ties go to the narrower tile (more waves resident).
 template <bool AK, bool BKC>
 static void launch_gemm_j(const GemmArgs& g, int J, dim3 grid, hipStream_t st) {
-  const bool k32 = tuning("deform_gemm_bk", 16) == 32;
-  if (J == 1 && k32) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 1, 32>), grid, dim3(256), 0, st, g);
-  else if (J == 2 && k32) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 2, 32>), grid, dim3(256), 0, st, g);
-  else if (J == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 1, 16>), grid, dim3(256), 0, st, g);
+  if (J == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 1, 16>), grid, dim3(256), 0, st, g);
   else if (J == 2) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 2, 16>), grid, dim3(256), 0, st, g);
   else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 3, 16>), grid, dim3(256), 0, st, g);
 }
@@ -1443,8 +1440,8 @@ static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
     return SD_OK;
   }
   g.tiles_m = cdiv(g.M, BM);
-  int J = tuning("deform_gemm_j", 0);
-  if (J < 1 || J > 3) {
+  int J = 0;
+  {
     double best = -1.0;
     for (int j = 1; j <= 3; ++j) {
       const int tn = cdiv(g.N, 64 * j);
@@ -2292,12 +2289,10 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
     constexpr int T = 256;
     const int vec = (((H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0) |
                     (tuning("dcn_window", 1) ? 0 : 2);
-    int nt = tuning("dcn_im2col_nt", 1);  // bit 0 non-temporal; bits 1-2: profiling build only
-#ifndef SD_PROFILING
-    nt &= 1;
-#endif
-    int nsplit = tuning("dcn_im2col_split", 1);
-    if (nsplit < 1 || nsplit > C / dgroup) nsplit = 1;
+    // bit 0: non-temporal col stores (the product's setting); bits 1-2 switch parts off, profiling build only
+    const int nt = 1 | (SD_PROF_TUNING("dcn_im2col_nt", 1) & 6);
+    // (channel splits per (image, group, pixel tile): 2-8 measured in round 3, no gain -- one)
+    const int nsplit = 1;
     if (kh * kw == 9)
       hipLaunchKernelGGL((deform_im2col_lds_kernel<T, 9>), dim3(cdiv(P, T), dgroup * nsplit, N),
                          dim3(T), lds, (hipStream_t)stream, x, offset, col, g, nsplit, vec, nt);

@@ -140,7 +140,6 @@ struct FwdArgs {
   float* coords;         // with amax8: (B*R, 2, 3*P) sample-coordinate table the backward decodes with
   int nslice;  // channel slices per RoI (one workgroup each)
   int fbslice; // band kernel: channel slices of a RoI on its exact per-element path (one workgroup each)
-  const int* order;  // optional locality order of the RoIs (a permutation of [0, B*R)), or null
   int ablate;  // profiling only: 1 stop after the tables
   long long* dbg;                     // profiling build only: per-wave phase clocks (or null)
   int half_io;                        // 1: the feature maps and `out` are fp16 (band kernel only)
@@ -207,8 +206,7 @@ struct FwdSmem {
     int hcnt[PH], wcnt[PW];  // -1: empty axis bin (end <= start); else sample-loop iterations
     int binflag[PP];         // 1: the bin pools something (reference !is_empty)
     int lvl;                 // assigned level, -1 none, -2 RoI index past the end
-    int n;                   // RoI index (through the locality order when one is given)
-    int qr, qc;              // quadrant of the RoI this entry stands for (0, 0 unless POOL > PH)
+    int n;                   // RoI index
     int fb_row, fb_col;      // a sample loop ran 3 times -> exact per-element fallback
     int any_valid;
     float box[4];
@@ -318,15 +316,14 @@ __global__ __launch_bounds__(64) void roi_coords_kernel(const float* rois, int n
   }
 }
 
-// POOL: the op's pooled size when it is a multiple of the PH x PW tile the kernel works on: a
-// 14x14 RoI is handled as four 7x7 quadrants ("virtual RoIs" with bin rows / columns 7q .. 7q+6 of
-// the 14-bin axes), each with the 7x7 kernel's tile, registers and occupancy; only the axis tables,
-// the coordinate-table indices and the output indices know about the quadrant.
-template <int PH, int PW, int NROI, bool PK, bool LEAN, int POOL = PH, int NWAVE_ = 8>
+// (round 5: the 64-VGPR "lean" build, the 7x7-quadrant form of 14x14 pooling and the locality order of
+// the RoIs were perf variants of this FALLBACK -- the band-resident kernel below is the product path --
+// and are gone; what is left is one kernel per pooled size.)
+template <int PH, int PW, int NROI, bool PK, int NWAVE_ = 8>
 __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW, NROI, NWAVE_>& s,
                                                const int bid) {
-  static_assert(PH == PW && POOL % PH == 0, "square tiles, whole quadrants");
-  constexpr int NQA = POOL / PH, NQ = NQA * NQA;     // quadrants per axis / per RoI
+  static_assert(PH == PW, "square tiles");
+  constexpr int POOL = PH;
   constexpr int PPG = POOL * POOL;                    // outputs per (RoI, channel)
   constexpr int PPSG = amax_stride(PPG);
   constexpr int D = 1;  // channels in flight per wave (deeper batches measured slower)
@@ -343,7 +340,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
   constexpr int CHUNK = ITER < 8 ? ITER : 8;    // loads kept in flight per lane
   constexpr int NCHUNK = (ITER + CHUNK - 1) / CHUNK;
   constexpr int NI = (PP + kWave - 1) / kWave;  // bins per lane
-  constexpr bool REGW = NI == 1 && !LEAN;       // keep the bin's 16 weights in registers
+  constexpr bool REGW = NI == 1;                // keep the bin's 16 weights in registers
   constexpr bool CACHE_GOFF = ITER <= 8;        // keep the fill offsets in registers
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -353,7 +350,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
   // its own channel slice.
   const int nslice = a.nslice;
   const int grp = bid / nslice, slice = bid % nslice;
-  const int nroi_total = a.B * a.R * NQ;  // (virtual RoIs)
+  const int nroi_total = a.B * a.R;
   const int nch = a.C / nslice;  // channels of this workgroup
   const int cbeg = slice * nch;
 
@@ -362,9 +359,8 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
     const int i = wave >> 1, slot = grp * NROI + i;
     typename S::Roi& t = s.roi[i];
     int lvl = -2, cnt = 0, n = 0;
-    const int quad = slot % NQ, qr = quad / NQA, qc = quad % NQA;
     if (slot < nroi_total) {
-      n = a.order ? a.order[slot / NQ] : slot / NQ;
+      n = slot;
       const float* r = a.rois + (long)n * 4;
       const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
       lvl = 0;
@@ -375,11 +371,11 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
         const int H = a.L.H[lvl], W = a.L.W[lvl];
         const float scale = a.L.scale[lvl];
         if ((wave & 1) == 0 && lane < PH) {
-          cnt = axis_samples(qr * PH + lane, POOL, y1, y2, scale, H, W, &t.hval[2 * lane], &t.alpha[2 * lane],
+          cnt = axis_samples(lane, POOL, y1, y2, scale, H, W, &t.hval[2 * lane], &t.alpha[2 * lane],
                              &t.rowoff[4 * lane]);
           t.hcnt[lane] = cnt;
         } else if ((wave & 1) == 1 && lane < PW) {
-          cnt = axis_samples(qc * PW + lane, POOL, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
+          cnt = axis_samples(lane, POOL, x1, x2, scale, W, 1, &t.wval[2 * lane], &t.beta[2 * lane],
                              &t.coloff[4 * lane]);
           t.wcnt[lane] = cnt;
         }
@@ -392,7 +388,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
     const int fb = __any(cnt >= 3);
     if (lane == 0) {
       if (wave & 1) t.fb_col = fb;
-      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; t.n = n; t.qr = qr; t.qc = qc; }
+      else { t.fb_row = fb; t.lvl = lvl; t.any_valid = 0; t.n = n; }
     }
   }
   __syncthreads();
@@ -424,14 +420,14 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
       if (t.lvl < 0) continue;
       const bool row = j < 3 * PH;
       const int jj = row ? j : j - 3 * PH, k = jj % 3;
-      const int p = jj / 3 + (row ? t.qr * PH : t.qc * PW);  // bin row / column of the whole RoI
+      const int p = jj / 3;  // bin row / column
       // recomputed, not taken from hval / wval: those hold only the samples the loop reached, and
       // the table is written in full so that its content does not depend on LDS leftovers
       const int lv = t.lvl;
       const float v = row ? sample_coord(p, POOL, t.box[1], t.box[3], a.L.scale[lv], a.L.H[lv], k)
                           : sample_coord(p, POOL, t.box[0], t.box[2], a.L.scale[lv], a.L.W[lv], k);
       float* base = a.coords + (long)t.n * kCoordWords * (POOL + POOL);
-      const int jg = (row ? 0 : 3 * POOL) + p * 3 + k;  // (quadrants sharing a row / column write the same values)
+      const int jg = (row ? 0 : 3 * POOL) + p * 3 + k;
       base[jg] = v;
       store_tap(base + 3 * (POOL + POOL) + 2 * jg, v, row ? a.L.H[t.lvl] : a.L.W[t.lvl]);
     }
@@ -468,11 +464,9 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
     if (lvl == -3) continue;
     const long obase = ((long)n * a.C + cbeg) * PPG;
     const long abase = ((long)n * a.C + cbeg) * PPSG;
-    // output index of bin (p, q) of this quadrant inside the RoI's POOL x POOL block
-    auto gidx = [&](int bin) { return (t.qr * PH + bin / PW) * POOL + t.qc * PW + bin % PW; };
     if (lvl < 0) {  // every per-level op sees a zero box
       for (int e = tid; e < nch * PP; e += THREADS) {
-        const int c = e / PP, g = gidx(e % PP);
+        const int c = e / PP, g = e % PP;
         a.out[obase + (long)c * PPG + g] = 0.f;
         if (PK) {
           a.amax8[abase + (long)c * PPSG + g] = 255;
@@ -487,9 +481,9 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
       const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
       const float scale = a.L.scale[lvl];
       for (int e = tid; e < nch * PP; e += THREADS) {
-        const int c = e / PP, bin = e % PP, g = gidx(bin);
+        const int c = e / PP, bin = e % PP, g = bin;
         FwdOut o = roi_align_fwd_elem(base + (long)c * plane, H, W, t.box[0], t.box[1], t.box[2],
-                                      t.box[3], scale, t.qr * PH + bin / PW, t.qc * PW + bin % PW, POOL, POOL);
+                                      t.box[3], scale, bin / PW, bin % PW, POOL, POOL);
         if (a.L.nlvl > 1) o.val = o.val + 0.0f;
         a.out[obase + (long)c * PPG + g] = o.val;
         if (PK) {
@@ -513,9 +507,6 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
     if (lvl < 0 || __builtin_amdgcn_readfirstlane(t.fb_row | t.fb_col)) continue;  // (-3: ablated)
     const long obase = ((long)n * a.C + cbeg) * PPG;
     const long abase = ((long)n * a.C + cbeg) * PPSG;
-    const int qr = __builtin_amdgcn_readfirstlane(t.qr), qc = __builtin_amdgcn_readfirstlane(t.qc);
-    // output index of bin (p, q) of this quadrant inside the RoI's POOL x POOL block
-    auto gidx = [&](int bin) { return POOL == PH ? bin : (qr * PH + bin / PW) * POOL + qc * PW + bin % PW; };
     const int W = a.L.W[lvl];
     const long plane = (long)a.L.H[lvl] * W;
     const float* base = a.L.data[lvl] + ((long)(n / a.R) * a.C + cbeg) * plane;
@@ -528,7 +519,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
         for (int b = 0; b < NI; ++b) {
           const int bin = lane + b * kWave;
           if (bin < PP) {
-            const int g = gidx(bin);
+            const int g = bin;
             a.out[ob + g] = 0.f;
             if (PK) {
               a.amax8[abase + (long)c * PPSG + g] = 255;
@@ -624,11 +615,6 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
       float* px = PK ? nullptr : a.ax + obase + (long)wave * PPG;
       float* py = PK ? nullptr : a.ay + obase + (long)wave * PPG;
       unsigned char* pk = PK ? a.amax8 + abase + (long)wave * PPSG : nullptr;
-      int gi[POOL == PH ? 1 : NI];  // quadrants: output index of this lane's bins
-      if (POOL != PH) {
-#pragma unroll
-        for (int b = 0; b < NI; ++b) gi[b] = gidx(lane + b * kWave < PP ? lane + b * kWave : 0);
-      }
       for (int c0 = wave; c0 < nch; c0 += D * NWAVE) {
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -667,7 +653,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
                   }
                 }
                 if (a.L.nlvl > 1) maxval = maxval + 0.0f;
-                const int g = POOL == PH ? bin : gi[POOL == PH ? 0 : b];
+                const int g = bin;
                 po[g + d * NWAVE * PPG] = maxval;
                 if (PK) {
                   if (!(SD_ABLATE(a, 4))) pk[g + d * NWAVE * PPSG] = (unsigned char)(bk < 0 ? 255 : bk);
@@ -698,42 +684,7 @@ __device__ __forceinline__ void fwd_tiled_body(const FwdArgs& a, FwdSmem<PH, PW,
 template <int PH, int PW, int NROI, bool PK>
 __global__ __launch_bounds__(512) void roi_align_fwd_tiled(FwdArgs a) {
   __shared__ FwdSmem<PH, PW, NROI> s;
-  fwd_tiled_body<PH, PW, NROI, PK, false>(a, s, blockIdx.x);
-}
-
-// The same kernel held to 64 VGPRs (weights re-read from LDS per channel) and two RoIs of tables:
-// four workgroups = 8 waves per SIMD fit a CU instead of three (1 -> 2 -> 3 -> 4 workgroups per
-// CU: 238 -> 149 -> 127 -> 110 us in the profiling build, 104 -> 98-100 us in the product).
-// Where the time goes at 4 workgroups per CU (rocprofv3 PMC, profiles/r02e_fwd_pmc.txt): the
-// texture-address unit is busy ~75-85% of the kernel (7 tap gathers + 2 stores per RoI x channel,
-// ~16 clocks each), 39% of the wave time is VMEM issue stall, LDS is ~40% busy and the VALU 38%.
-// What did not help, each bit-exact and measured: requesting the next channel's
-// taps before reducing this one, with hand-placed s_waitcnt so that store acknowledgements leave
-// the critical path (100.7 vs 100.8 us: not latency bound); fetching the RoI's window with
-// 16-byte loads (2.4 instead of 7 loads, 110 us) or only the distinct rows (5.4 loads, 108 us):
-// the per-lane-addressed LDS reads those need cost more than the gathers they save.
-template <int NROI, bool PK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_tiled_lean(
-    FwdArgs a) {
-  __shared__ FwdSmem<7, 7, NROI> s;
-  fwd_tiled_body<7, 7, NROI, PK, true>(a, s, blockIdx.x);
-}
-
-// 14x14 pooling (mask head) as four 7x7 quadrants per RoI on the same 64-VGPR / 34 KB build
-// (the 14x14 tile kernel needs 169 VGPRs and 114 KB of LDS: one workgroup per CU).
-template <int NROI, bool PK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void roi_align_fwd_quad14(
-    FwdArgs a) {
-  __shared__ FwdSmem<7, 7, NROI> s;
-  fwd_tiled_body<7, 7, NROI, PK, true, 14>(a, s, blockIdx.x);
-}
-
-// ... and with the float arg-max planes (the drop-in ROIAlign_v2 outputs): the 7x7 build at three
-// workgroups per CU (it needs more registers than 64)
-template <int NROI>
-__global__ __launch_bounds__(512) void roi_align_fwd_quad14_float(FwdArgs a) {
-  __shared__ FwdSmem<7, 7, NROI> s;
-  fwd_tiled_body<7, 7, NROI, false, false, 14>(a, s, blockIdx.x);
+  fwd_tiled_body<PH, PW, NROI, PK>(a, s, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1601,8 +1552,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_atomic(BwdArgs a) {
 }
 
 // Per-level plane kernel (knob roi_align_bwd = 1; also the fallback when the fused kernel does not
-// apply).  Besides the float compare-and-swap planes (lds_add_cas, common.h) it keeps a 64-bit
-// fixed-point variant (knob roi_align_bwd_accum = 1): a per-workgroup power-of-two scale chosen
+// apply).  64-bit fixed-point planes: a per-workgroup power-of-two scale chosen
 // from max|dY| of the workgroup's own items (no overflow by construction), every tap value still
 // computed in float exactly as the reference does, only the summation exact instead of
 // float-in-arbitrary-order -- a bit-reproducible backward.  It is not faster (ds_add_u64 sustains
@@ -1620,8 +1570,8 @@ __device__ __forceinline__ void lds_add_i32(int* p, float v, float scale) {
 }
 
 // One workgroup owns CPB channel planes (rows [row0,row1) of them) of one image in LDS.
-//   FX = true : int64 fixed-point planes (8 B per pixel), float-CAS fallback on non-finite dY
-//   FX = false: float planes (4 B per pixel) with a CAS loop (A/B variant)
+//   FX = true : int64 fixed-point planes (8 B per pixel), float-CAS fallback on non-finite dY (the only
+//   instantiation; FX = false -- float planes with a CAS loop -- was the round-1 A/B twin)
 template <int PP, int CPB, int THREADS, bool FX>
 __global__ __launch_bounds__(THREADS) void roi_align_bwd_plane(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1841,195 +1791,17 @@ struct BwdFusedArgs {
   int unit_base[SD_MAX_FPN_LEVELS];  // first unit of launch-order level li
   int lists_units;                   // (level, image, band) units the list pre-pass covers
   int half_io;                       // dy and dx are fp16 (packed arg-max, wide kernel only)
+  int float_adds;                    // 1: every workgroup sums with fp32 compare-and-swap adds (tuning key roi_align_bwd_fx = 0)
 };
 
-template <int PP, int THREADS, bool PK>
-__global__ __launch_bounds__(THREADS) void roi_align_bwd_fused(BwdFusedArgs a) {
-  constexpr int PW = PP == 49 ? 7 : 14, PH = PW;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int U = 4;  // items per lane per trip: 3*U independent global loads in flight
-  const int tid = threadIdx.x;
-  // ---- block -> (level, image, band, channel) ----
-  int li = 0;
-  while (li + 1 < a.nlaunch && (int)blockIdx.x >= a.block_end[li]) ++li;
-  const int lvl = a.order[li];
-  const int b0 = (int)blockIdx.x - (li ? a.block_end[li - 1] : 0);
-  const int H = a.L.H[lvl], W = a.L.W[lvl];
-  const float scale = a.L.scale[lvl];
-  const int nbands = a.nbands[lvl];
-  int u, c;
-  if (a.C % kNumXCD == 0) {  // an XCD keeps a contiguous channel range: dY/argmax lines stay in one L2
-    const int xcd = b0 % kNumXCD, j = b0 / kNumXCD, per = a.C / kNumXCD;
-    c = xcd * per + (j % per);
-    u = j / per;
-  } else {
-    c = b0 % a.C;
-    u = b0 / a.C;
-  }
-  const int img = u / nbands, band = u % nbands;
-  const int row0 = band * a.band_rows[lvl];
-  const int row1 = iminr(row0 + a.band_rows[lvl], H);
-  const int band_elems = (row1 - row0) * W;
-  const int plane_pad = (band_elems + 3) & ~3;
-  float* plane = smem;
-  int* list = reinterpret_cast<int*>(smem + plane_pad);
-  int* nlist = list + a.R;
-
-  {
-    float4* p4 = reinterpret_cast<float4*>(smem);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
-  }
-  if (tid == 0) *nlist = 0;
-  __syncthreads();
-  // ---- RoIs of this image that belong to this level and can touch this band ----
-  for (int r = tid; r < (SD_ABLATE(a, 4) ? 0 : a.R); r += THREADS) {
-    const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
-    bool take = true;
-    if (a.filter) take = fpn_level(rb.x, rb.y, rb.z, rb.w, a.L) == lvl;
-    if (take && nbands > 1) {
-      // conservative row range of every tap of this RoI (taps lie within the clipped bins +-1)
-      float s = fminr(fmaxr(rb.y * scale, 0.f), (float)(H - 1));
-      float e = fminr(fmaxr(rb.w * scale, 0.f), (float)(H - 1));
-      float lo = fminr(s, e) - 2.f, hi = fmaxr(s, e) + 2.f;
-      if (hi < (float)row0 || lo > (float)(row1 - 1)) take = false;
-    }
-    if (take) list[atomicAdd(nlist, 1)] = r;
-  }
-  __syncthreads();
-  int nitems = *nlist * PP;
-  if (SD_ABLATE(a, 1)) nitems = 0;
-  // wave-uniform bases + 32-bit lane offsets (the launcher checks R*C*PP < 2^31)
-  const int roi_stride = a.C * PP;
-  const long img_base = (long)img * a.R * roi_stride + (long)c * PP;
-  const float* dyb = a.dy + img_base;
-  const float* axb = PK ? nullptr : a.ax + img_base;
-  const float* ayb = PK ? nullptr : a.ay + img_base;
-  const unsigned char* amb =
-      PK ? a.amax8 + ((long)img * a.R * a.C + c) * amax_stride(PP) : nullptr;
-  // packed path: the forward's (neighbours, fraction) pairs of this image's RoIs
-  const float* tapb =
-      PK ? a.coords + (long)img * a.R * kCoordWords * (PH + PW) + 3 * (PH + PW) : nullptr;
-
-  for (int it0 = tid; it0 < nitems; it0 += U * THREADS) {
-    // per item: packed (low | high << 16) neighbour rows / columns (< 0: nothing to add), the two
-    // interpolation fractions and the gradient
-    int py[U], px[U];
-    float fy[U], fx[U], vg[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const int it = it0 + k * THREADS;
-      py[k] = -1;
-      px[k] = -1;
-      fy[k] = fx[k] = vg[k] = 0.f;
-      if (it < nitems) {
-        const int r = list[it / PP];
-        int bin = it % PP;
-        if (PP == 196 && !(SD_ABLATE(a, 64))) {
-          // 14x14: most bins are narrower than a pixel, so 64 consecutive bins pile their taps onto
-          // a few pixels (5.5 CAS rounds per instruction, simulated); every third bin spreads a
-          // wave instruction over the whole RoI (3.8 rounds) at the price of 12-byte lane strides
-          bin *= 3;
-          bin -= bin >= 392 ? 392 : (bin >= 196 ? 196 : 0);
-        }
-        const int idx = r * roi_stride + bin;
-        if (PK) {
-          const int code = amb[r * (a.C * amax_stride(PP)) + bin];
-          if (code != 255) {
-            const float* tb = tapb + r * (kCoordWords * (PH + PW));
-            const float2 ey = *reinterpret_cast<const float2*>(tb + 2 * ((bin / PW) * 3 + code / 3));
-            const float2 ex =
-                *reinterpret_cast<const float2*>(tb + 2 * (3 * PH + (bin % PW) * 3 + code % 3));
-            py[k] = __float_as_int(ey.x);
-            fy[k] = ey.y;
-            px[k] = __float_as_int(ex.x);
-            fx[k] = ex.y;
-          }
-        } else {  // float arg-max planes: only the loads here, the arithmetic after all of them
-          fx[k] = axb[idx];
-          fy[k] = ayb[idx];
-          py[k] = 0;
-        }
-        vg[k] = dyb[idx];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      if (!PK && py[k] == 0) {
-        const float a_x = fx[k], a_y = fy[k];
-        py[k] = -1;
-        if (a_x != -1.f && a_y != -1.f) {
-          const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
-          const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
-          const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
-          const int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
-          fy[k] = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow) / (float)(hhigh - hlow);
-          fx[k] = (wleft == wright) ? 0.5f : (a_x - (float)wleft) / (float)(wright - wleft);
-          py[k] = hlow | (hhigh << 16);
-          px[k] = wleft | (wright << 16);
-        }
-      }
-      if ((py[k] | px[k]) >= 0) {
-        const float g = vg[k], alpha = fy[k], beta = fx[k];
-        const int hlow = py[k] & 0xffff, hhigh = py[k] >> 16;
-        const int wleft = px[k] & 0xffff, wright = px[k] >> 16;
-        const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
-        const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
-        const int o0 = (hlow - row0) * W, o1 = (hhigh - row0) * W;
-        if (SD_ABLATE(a, 24)) {  // profiling only: plain read-modify-write (8) / one store per item (16)
-          if (SD_ABLATE(a, 8)) {
-            if (hlow >= row0 && hlow < row1) {
-              plane[o0 + wleft] += w00;
-              plane[o0 + wright] += w01;
-            }
-            if (hhigh >= row0 && hhigh < row1) {
-              plane[o1 + wleft] += w10;
-              plane[o1 + wright] += w11;
-            }
-          } else if (hlow >= row0 && hlow < row1) {
-            plane[o0 + wleft] = w00 + w01 + w10 + w11;
-          }
-          continue;
-        }
-        if (hlow >= row0 && hlow < row1) {
-          lds_add_cas(plane + o0 + wleft, w00);
-          lds_add_cas(plane + o0 + wright, w01);
-        }
-        if (hhigh >= row0 && hhigh < row1) {
-          lds_add_cas(plane + o1 + wleft, w10);
-          lds_add_cas(plane + o1 + wright, w11);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (SD_ABLATE(a, 2)) return;
-  const long off = (((long)img * a.C + c) * H + row0) * W;
-  float* dst = a.dx[lvl] + off;
-  if (((off | band_elems) & 3) == 0) {
-    float4* d4 = reinterpret_cast<float4*>(dst);
-    for (int i = tid; i < band_elems / 4; i += THREADS) {
-      float4 v = reinterpret_cast<const float4*>(plane)[i];
-      if (a.req == SD_REQ_ADD) {
-        const float4 o = d4[i];
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
-      d4[i] = v;
-    }
-  } else {
-    for (int i = tid; i < band_elems; i += THREADS)
-      dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// fused backward of the packed path, wide-load version
+// fused backward, wide-load kernel
 // ------------------------------------------------------------------------------------------------
-// Same decomposition as roi_align_bwd_fused (workgroup = (level, image, row band, channel), band of
-// the gradient plane in LDS, written to HBM once).  What changed is the item loop, which the SQ
-// counters showed to be bound by the NUMBER of vector-memory instructions (a wave64 load occupies
-// the address unit ~16 clocks whatever its width): the old loop issued four loads per (RoI, bin)
-// item -- arg-max byte, two 8-byte table entries, gradient -- 2.0 M wave instructions per launch.
+// Workgroup = (level, image, row band, channel), band of the gradient plane in LDS, written to HBM
+// once.  The item loop is built around the NUMBER of vector-memory instructions (a wave64 load
+// occupies the address unit ~16 clocks whatever its width; the round-1 kernel, removed in round 5,
+// issued four loads per (RoI, bin) item -- arg-max byte, two 8-byte table entries, gradient -- 2.0 M
+// wave instructions per launch).
 // Here
 //   * a lane owns FOUR consecutive bins of one RoI: one aligned 4-byte load brings their four
 //     arg-max codes (rows are padded to whole dwords, amax_stride) and one 16-byte load the four
@@ -2288,7 +2060,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   const int am_stride = a.C * PPS;
   const float* cob = a.coords + (long)img * a.R * CW;
 
-  bool use_fx = !(SD_ABLATE(a, 64));  // (ablate 64, profiling build: the float compare-and-swap adds)
+  bool use_fx = !a.float_adds;  // (`roi_align_bwd_fx` = 0: fp32 compare-and-swap adds in every workgroup)
   float fx_scale = 1.f, fx_inv = 1.f;
   struct Item {
     float4 g;       // gradients of bins b0 .. b0+3
@@ -2658,8 +2430,9 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   // packed arg-max: the wide-load kernel (roi_align_bwd_packed4); its coordinate tables share the
   // LDS with the band, so the band budget is a little smaller
   const bool flt = !a.amax8 && a.ax && a.ay;  // float arg-max planes: the same kernel without tables
-  const bool wide = (a.amax8 || flt) && tuning("roi_align_bwd_packed", 1) == 1;
-  const int tch = tuning("roi_align_bwd_tch", a.PP == 49 ? 32 : 16);
+  SD_REQUIRE(a.amax8 || flt, "RoIAlign backward needs the forward's arg-max (packed bytes or the two float planes)");
+  a.float_adds = tuning("roi_align_bwd_fx", 1) == 0 ? 1 : 0;
+  const int tch = a.PP == 49 ? 32 : 16;   // RoIs per staged coordinate-table chunk
   const int ne = a.PP == 49 ? 3 * 14 : 3 * 28;  // sample coordinates per RoI
   a.ablate = SD_PROF_TUNING("roi_align_bwd_ablate", 0);
   if ((long)a.R * a.C * a.PP >= (1L << 31)) return SD_ERR_UNSUPPORTED;  // 32-bit lane offsets
@@ -2681,7 +2454,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   long units = 0;
   // bands of every level for a band budget and a table entry size (words per sample coordinate)
   auto plan = [&](long budget, int entry_words) -> int {
-    const size_t tab_bytes = (wide && !flt) ? (size_t)tch * ne * entry_words * 4 : 0;
+    const size_t tab_bytes = !flt ? (size_t)tch * ne * entry_words * 4 : 0;
     lds_max = 0;
     nl = 0;
     units = 0;
@@ -2695,7 +2468,7 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
       nb = (a.L.H[l] + rows - 1) / rows;
       a.band_rows[l] = rows;
       a.nbands[l] = nb;
-      if (wide && (long)rows * a.L.W[l] >= 65535) return SD_ERR_UNSUPPORTED;  // 16-bit band offsets
+      if ((long)rows * a.L.W[l] >= 65535) return SD_ERR_UNSUPPORTED;  // 16-bit band offsets
       const size_t lds =
           (size_t)((((long)rows * a.L.W[l] + 3) & ~3L) * 4) + tab_bytes + (size_t)(a.R + 8 + 16) * 4;
       if (lds > 150 * 1024) return SD_ERR_UNSUPPORTED;
@@ -2712,29 +2485,25 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   const int lists_mode = tuning("roi_align_bwd_lists", 1);  // 1 lists + taps, 2 lists only, 0 none
   bool use_taps = false, use_lists = false;
   size_t list_bytes = 0;
-  if (wide && !flt && workspace && ((uintptr_t)workspace & 15) == 0 && lists_mode == 1) {
-    if (int e = plan((long)tuning("roi_align_bwd_lds_kb", 27) * 1024, 2)) return e;
+  if (!flt && workspace && ((uintptr_t)workspace & 15) == 0 && lists_mode == 1) {
+    if (int e = plan(27L * 1024, 2)) return e;
     list_bytes = (((size_t)units * (a.R + 2) * sizeof(int)) + 15) & ~(size_t)15;
     use_taps = workspace_bytes >= list_bytes + (size_t)units * a.R * 2 * ne * sizeof(float);
     use_lists = use_taps;
   }
   if (!use_taps) {
-    if (int e = plan((long)tuning("roi_align_bwd_lds_kb", 36) * 1024, 1)) return e;
+    if (int e = plan(36L * 1024, 1)) return e;
     list_bytes = (((size_t)units * (a.R + 2) * sizeof(int)) + 15) & ~(size_t)15;
-    use_lists = wide && workspace && lists_mode >= 1 && workspace_bytes >= list_bytes;
+    use_lists = workspace && lists_mode >= 1 && workspace_bytes >= list_bytes;
   }
   // Launch order = expected duration of ONE workgroup, longest first: a level that fits in one
   // band sees all of its image's RoIs in every workgroup (2x the items of a P2 band at the
   // baseline), so the few-band levels go first and the many short P2 bands fill the tail.
-  // (knob roi_align_bwd_order = 1: most workgroups first, the previous order)
-  const bool by_count = tuning("roi_align_bwd_order", 0) == 1;
   for (int i = 0; i < nl; ++i)
     for (int j = i + 1; j < nl; ++j)
-      if (by_count ? work[a.order[j]] > work[a.order[i]]
-                   : (a.nbands[a.order[j]] < a.nbands[a.order[i]] ||
-                      (a.nbands[a.order[j]] == a.nbands[a.order[i]] &&
-                       (long)a.L.H[a.order[j]] * a.L.W[a.order[j]] >
-                           (long)a.L.H[a.order[i]] * a.L.W[a.order[i]]))) {
+      if (a.nbands[a.order[j]] < a.nbands[a.order[i]] ||
+          (a.nbands[a.order[j]] == a.nbands[a.order[i]] &&
+           (long)a.L.H[a.order[j]] * a.L.W[a.order[j]] > (long)a.L.H[a.order[i]] * a.L.W[a.order[i]])) {
         const int t = a.order[i];
         a.order[i] = a.order[j];
         a.order[j] = t;
@@ -2773,148 +2542,29 @@ static int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* wor
   }
   if (prepass != 0 && !(a.ws_list && a.ws_taps)) return SD_ERR_UNSUPPORTED;
   if (prepass == 1) return SD_OK;
-  int threads = tuning("roi_align_bwd_threads", 0);
-  if (threads != 256 && threads != 512) threads = 512;
-  if (wide) {
-    if (a.half_io) {   // fp16 I/O: the default configuration of the wide kernel (512 threads, default chunk)
-      if (flt || threads != 512 || tch != (a.PP == 49 ? 32 : 16)) return SD_ERR_UNSUPPORTED;
-#define SD_BWDH(PHv, TCHv)                                                                       \
+  // the wide-load kernel: 512 lanes, coordinate tables staged 32 (7x7) / 16 (14x14) RoIs at a time
+  // MODE 0: packed arg-max, tables derived per workgroup; 1: tap tables from the list pre-pass; 2: float arg-max planes
+#define SD_BWDW(PHv, TCHv, HALFv)                                                                \
   do {                                                                                           \
-    auto k = a.ws_taps ? roi_align_bwd_packed4<PHv, PHv, 512, TCHv, 1, true>                     \
-                       : roi_align_bwd_packed4<PHv, PHv, 512, TCHv, 0, true>;                    \
+    auto k = flt ? roi_align_bwd_packed4<PHv, PHv, 512, TCHv, 2, false>                          \
+                 : a.ws_taps ? roi_align_bwd_packed4<PHv, PHv, 512, TCHv, 1, HALFv>              \
+                             : roi_align_bwd_packed4<PHv, PHv, 512, TCHv, 0, HALFv>;             \
     if (lds_max > 64 * 1024)                                                                     \
       SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)lds_max));                                           \
     hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(512), lds_max, st, a);                     \
   } while (0)
-      if (a.PP == 49) SD_BWDH(7, 32); else SD_BWDH(14, 16);
-#undef SD_BWDH
-      note_dispatch("%ssd::roi_align_bwd_packed4<%d,%d,512,%d,%d,true>", prepass == 0 && a.ws_list ? "sd::roi_align_bwd_lists + " : "",
-                    a.PP == 49 ? 7 : 14, a.PP == 49 ? 7 : 14, tch, a.ws_taps ? 1 : 0);
-      SD_LAUNCH_CHECK();
-      return SD_OK;
-    }
-#define SD_BWDW(PHv, T, TCHv)                                                                    \
-  do {                                                                                           \
-    auto k = flt ? roi_align_bwd_packed4<PHv, PHv, T, TCHv, 2>                                   \
-                 : a.ws_taps ? roi_align_bwd_packed4<PHv, PHv, T, TCHv, 1>                       \
-                             : roi_align_bwd_packed4<PHv, PHv, T, TCHv, 0>;                      \
-    if (lds_max > 64 * 1024)                                                                     \
-      SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds_max));                                           \
-    hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(T), lds_max, st, a);                       \
-  } while (0)
-#define SD_BWDW_T(PHv, TCHv)                                         \
-  do {                                                               \
-    if (threads == 256) SD_BWDW(PHv, 256, TCHv); else SD_BWDW(PHv, 512, TCHv); \
-  } while (0)
-    if (a.PP == 49) {
-      if (tch == 64) SD_BWDW_T(7, 64); else if (tch == 16) SD_BWDW_T(7, 16); else SD_BWDW_T(7, 32);
-    } else {
-      if (tch == 32) SD_BWDW_T(14, 32); else if (tch == 8) SD_BWDW_T(14, 8); else SD_BWDW_T(14, 16);
-    }
-#undef SD_BWDW_T
-#undef SD_BWDW
-    note_dispatch("%ssd::roi_align_bwd_packed4<%d,%d,%d,%d,%d>", prepass == 0 && a.ws_list ? "sd::roi_align_bwd_lists + " : "",
-                  a.PP == 49 ? 7 : 14, a.PP == 49 ? 7 : 14, threads, tch, flt ? 2 : (a.ws_taps ? 1 : 0));
-    SD_LAUNCH_CHECK();
-    return SD_OK;
-  }
-  if (a.half_io) return SD_ERR_UNSUPPORTED;   // (the per-item fallback kernel has no fp16 form)
-#define SD_BWDF2(PPv, T, PKv)                                                                    \
-  do {                                                                                           \
-    auto k = roi_align_bwd_fused<PPv, T, PKv>;                                                   \
-    if (lds_max > 64 * 1024)                                                                     \
-      SD_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds_max));                                           \
-    hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(T), lds_max, st, a);                       \
-  } while (0)
-#define SD_BWDF(PPv, T)                                 \
-  do {                                                  \
-    if (a.amax8) SD_BWDF2(PPv, T, true);                \
-    else SD_BWDF2(PPv, T, false);                       \
-  } while (0)
-  if (a.PP == 49) {
-    if (threads == 256) SD_BWDF(49, 256); else SD_BWDF(49, 512);
+  if (a.half_io) {   // fp16 I/O: packed arg-max only
+    if (flt) return SD_ERR_UNSUPPORTED;
+    if (a.PP == 49) SD_BWDW(7, 32, true); else SD_BWDW(14, 16, true);
   } else {
-    if (threads == 256) SD_BWDF(196, 256); else SD_BWDF(196, 512);
+    if (a.PP == 49) SD_BWDW(7, 32, false); else SD_BWDW(14, 16, false);
   }
-#undef SD_BWDF
-#undef SD_BWDF2
-  note_dispatch("sd::roi_align_bwd_fused<%d> (per-item fallback)", a.PP);
+#undef SD_BWDW
+  note_dispatch("%ssd::roi_align_bwd_packed4<%d,%d,512,%d,%d%s>", prepass == 0 && a.ws_list ? "sd::roi_align_bwd_lists + " : "",
+                a.PP == 49 ? 7 : 14, a.PP == 49 ? 7 : 14, tch, flt ? 2 : (a.ws_taps ? 1 : 0), a.half_io ? ",true" : "");
   SD_LAUNCH_CHECK();
   return SD_OK;
-}
-
-// Locality order for the forward: RoIs grouped by (level, image, coarse cell) so that an XCD's L2
-// (4 MB) holds the feature slice the concurrently running workgroups read -- a whole P4/P5 slice
-// fits, so those levels are fetched from HBM once instead of once per RoI.  Counting sort in one
-// workgroup; the order inside a bucket is arbitrary (results are stored by RoI index).
-constexpr int kOrderCells = 8;  // cells per axis
-constexpr int kOrderMaxBuckets = 4096;
-__global__ __launch_bounds__(1024) void roi_order_kernel(const float* rois, int nroi, int R,
-                                                         RoiLevels L, int B, float img_w,
-                                                         float img_h, int* order) {
-  __shared__ int hist[kOrderMaxBuckets + 1];
-  __shared__ int wsum[16];
-  const int tid = threadIdx.x;
-  const int nlv = L.nlvl + 1;  // + "no level"
-  const int nbuckets = nlv * B * kOrderCells * kOrderCells;
-  for (int i = tid; i <= nbuckets; i += 1024) hist[i] = 0;
-  __syncthreads();
-  constexpr int PER = 16;  // RoIs per thread (nroi <= 16384)
-  int bucket[PER], slot[PER];
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = tid + k * 1024;
-    bucket[k] = -1;
-    if (i < nroi) {
-      const float4 r = *reinterpret_cast<const float4*>(rois + (long)i * 4);
-      int lvl = L.nlvl > 1 ? fpn_level(r.x, r.y, r.z, r.w, L) : 0;
-      // coarsest level first: its slice is the smallest and stays resident
-      const int lv = lvl < 0 ? nlv - 1 : (L.nlvl - 1 - lvl);
-      const float cx = 0.5f * (r.x + r.z), cy = 0.5f * (r.y + r.w);
-      int gx = (int)(cx / img_w * kOrderCells), gy = (int)(cy / img_h * kOrderCells);
-      gx = iminr(imaxr(gx, 0), kOrderCells - 1);
-      gy = iminr(imaxr(gy, 0), kOrderCells - 1);
-      if (gy & 1) gx = kOrderCells - 1 - gx;  // boustrophedon: consecutive cells are neighbours
-      bucket[k] = ((lv * B + i / R) * kOrderCells + gy) * kOrderCells + gx;
-      slot[k] = atomicAdd(&hist[bucket[k]], 1);
-    }
-  }
-  __syncthreads();
-  // exclusive prefix sum over the buckets (block scan, 4 buckets per thread)
-  int v[4], sum = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int bi = tid * 4 + k;
-    v[k] = bi < nbuckets ? hist[bi] : 0;
-    sum += v[k];
-  }
-  int incl = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o);
-    if ((tid & 63) >= o) incl += t;
-  }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
-  int run = base + incl - sum;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int bi = tid * 4 + k;
-    if (bi < nbuckets) hist[bi] = run;
-    run += v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = tid + k * 1024;
-    if (i < nroi) order[hist[bucket[k]] + slot[k]] = i;
-  }
 }
 
 __global__ __launch_bounds__(256) void fpn_assign_kernel(const float* rois, int n_rois,
@@ -2967,39 +2617,21 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   if (bplan_done) *bplan_done = false;
   const long count = (long)a.B * a.R * a.C * a.PH * a.PW;
   if (count == 0) return SD_OK;
-  // 0 naive, 1 tiled (default; the 64-VGPR build for the packed 7x7 path), 3 tiled without the
-  // 64-VGPR build
+  // 0: the naive per-element kernel only, 1 (default): band-resident kernel, tiled kernels where it does not apply
   const int variant = tuning("roi_align_fwd", 1);
   a.ablate = SD_PROF_TUNING("roi_align_fwd_ablate", 0);
   a.dbg = reinterpret_cast<long long*>(((uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_hi", 0) << 32) |
                                        (uintptr_t)(unsigned)SD_PROF_TUNING("roi_align_dbg_lo", 0));
   const int nroi = a.B * a.R;
-  a.order = nullptr;
-  const int nbuckets = (a.L.nlvl + 1) * a.B * kOrderCells * kOrderCells;
-  if (variant >= 1 && workspace && workspace_bytes >= (size_t)nroi * sizeof(int) + 16 &&
-      nroi <= 16384 && nbuckets <= kOrderMaxBuckets && tuning("roi_align_fwd_order", 0)) {
-    int* order = reinterpret_cast<int*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-    int l0 = 0;
-    for (int l = 1; l < a.L.nlvl; ++l)
-      if (a.L.stride[l] >= 0 && a.L.scale[l] > a.L.scale[l0]) l0 = l;
-    const float img_w = (float)a.L.W[l0] / a.L.scale[l0], img_h = (float)a.L.H[l0] / a.L.scale[l0];
-    hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, st, a.rois, nroi, a.R, a.L, a.B,
-                       img_w, img_h, order);
-    SD_LAUNCH_CHECK();
-    a.order = order;
-  }
-  // channel slices (workgroups) per RoI: largest divisor of C not above the knob
-  int want = tuning("roi_align_fwd_slices", 8);
-  if (want < 1) want = 1;
+  // tiled fallback: 8 channel slices (workgroups) per RoI -- the largest divisor of C not above that
   a.nslice = 1;
-  for (int d = 1; d <= a.C && d <= want; ++d)
+  for (int d = 1; d <= a.C && d <= 8; ++d)
     if (a.C % d == 0) a.nslice = d;
   // the band kernel's exact path (a handful of RoIs per launch, after the band work): 32 slices -- with 8
   // the few workgroups that own a flagged RoI finish 1.5-2 us after everybody else (same-box A/B, 4 pairs)
   // (single-level calls keep 8: a per-level op of the unfused FPN graph sees three quarters of its RoIs as
   // "void" rows of the exact path, which then wants fuller workgroups: 63.6 -> 81.8 us with 32)
-  int wantfb = tuning("roi_align_fwd_fb_slices", a.L.nlvl > 1 ? 32 : 8);
-  if (wantfb < 1) wantfb = 1;
+  const int wantfb = a.L.nlvl > 1 ? 32 : 8;
   a.fbslice = 1;
   for (int d = 1; d <= a.C && d <= wantfb; ++d)
     if (a.C % d == 0) a.fbslice = d;
@@ -3007,17 +2639,15 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
   bool wide = true;
   for (int l = 0; l < a.L.nlvl; ++l)
     if (a.L.stride[l] >= 0 && a.L.W[l] < 2) wide = false;
-  const int rpw = tuning("roi_align_fwd_rois", 4);  // RoIs per workgroup (table amortisation)
-  const int padlds = SD_PROF_TUNING("roi_align_fwd_padlds", 0);  // profiling build: occupancy sweep
   // ---- band-resident forward (default): pre-pass + one launch; needs the workspace ----
-  if (variant == 1 && wide && !a.order && ((a.PH == 7 && a.PW == 7) || (a.PH == 14 && a.PW == 14)) &&
+  if (variant == 1 && wide && ((a.PH == 7 && a.PW == 7) || (a.PH == 14 && a.PW == 14)) &&
       a.R <= 65535 && workspace && tuning("roi_align_fwd_band", 1)) {
     BandArgs A{};
     BandPlan& P = A.p;
     const int POOL = a.PH;
     bool ok = true;
     int units = 0;
-    const int gmax = tuning("roi_align_fwd_g", 8);
+    constexpr int gmax = 8;   // most planes per fill
     int nvalid_lv = 0;
     for (int l = 0; l < a.L.nlvl; ++l) nvalid_lv += a.L.stride[l] >= 0;
     for (int l = 0; l < a.L.nlvl; ++l) {
@@ -3044,7 +2674,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       // (packed arg-max only: with the three fp32 outputs of the drop-in op the stores dominate, and
       // a RoI whose bin rows sit in one band is written as whole 196-byte rows -- C4: 254 vs 334 us;
       // the extra rounds re-read planes that are still in L2)
-      if (by_items > nbn && a.amax8 && tuning("roi_align_fwd_split", 1)) nbn = by_items;
+      if (by_items > nbn && a.amax8) nbn = by_items;
       if (nbn > H) nbn = H;
       if (nbn > kBandMaxBands) nbn = kBandMaxBands;   // (more items than that: rounds)
       int owned = (H + nbn - 1) / nbn;
@@ -3077,12 +2707,13 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     const size_t need = 16 + 2 * ent + 2 * valb + itemb + segb + al16(nroi) + kBandMaxUnits * sizeof(int);
     int wg = 0;
     P.nunits = units;
-    P.grab = tuning("roi_align_fwd_grab", 4);
-    P.gbias = tuning("roi_align_fwd_gbias", 0);
-    P.tail = tuning("roi_align_fwd_tail", 0);
-    P.tail_planes = tuning("roi_align_fwd_tail_planes", 8);
-    if (P.tail_planes < 1) P.tail_planes = 1;
-    if (P.grab < 1) P.grab = 1;
+    // channels a workgroup reserves at a time: 4 (single-channel grabs +7 %: the 196-byte rows of
+    // neighbouring channels merge in one CU's L2); no cost bias for multi-plane units and no shrinking
+    // reservations at a unit's end (15 / 30 % and 1..8-plane tails: measured, no effect -- round 3)
+    P.grab = 4;
+    P.gbias = 0;
+    P.tail = 0;
+    P.tail_planes = 8;
     {
       // virtual units = sum over units of ceil(items / CAP) <= units + floor(all items / CAP), and a RoI
       // has at most POOL items: beyond the table's size the launch goes to the tiled kernels (the
@@ -3091,8 +2722,7 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
       const long cap_launch = (long)np * kBandWaves * (kWave / POOL);
       if (units + (long)nroi * POOL / cap_launch > kBandMaxUnits) ok = false;
     }
-    wg = tuning("roi_align_fwd_wgs", kNumCU);  // persistent workgroups, one per CU
-    if (wg < 1) wg = 1;
+    wg = kNumCU;  // persistent workgroups, one per CU
     if (ok && need <= workspace_bytes) {
       char* w = reinterpret_cast<char*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
       P.rowent = reinterpret_cast<uint4*>(w); w += ent;
@@ -3161,27 +2791,12 @@ static int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace = nullptr,
     return fail(SD_ERR_UNSUPPORTED, "fp16 RoIAlign runs on the band-resident kernel only: it needs the workspace, "
                 "7x7 or 14x14 pooling, W in [2, 4095] and roi_align_fwd = 1, roi_align_fwd_band = 1");
   note_dispatch("sd::roi_align_fwd (tiled / naive fallback kernels: no workspace or a shape the band kernel does not take)");
-  if (variant == 1 && a.amax8 && wide && a.PH == 7 && a.PW == 7 && rpw >= 2) {
-    // packed arg-max (the fused op): the 64-VGPR build, four workgroups per CU
-    hipLaunchKernelGGL((roi_align_fwd_tiled_lean<2, true>), dim3(cdiv(nroi, 2) * a.nslice), dim3(512), padlds, st, a);
-  } else if (variant >= 1 && wide && a.PH == 7 && a.PW == 7) {
-#define SD_FWD77(NROI)                                                                           \
-  do {                                                                                           \
-    if (a.amax8)                                                                                 \
-      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, true>),                                \
-                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), padlds, st, a);           \
-    else                                                                                         \
-      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, NROI, false>),                               \
-                         dim3(cdiv(nroi, NROI) * a.nslice), dim3(512), padlds, st, a);           \
-  } while (0)
-    if (rpw >= 4) SD_FWD77(4); else if (rpw >= 2) SD_FWD77(2); else SD_FWD77(1);
-#undef SD_FWD77
-  } else if (variant == 1 && a.amax8 && wide && a.PH == 14 && a.PW == 14 && !a.order) {
-    hipLaunchKernelGGL((roi_align_fwd_quad14<2, true>), dim3(cdiv(nroi * 4, 2) * a.nslice), dim3(512), padlds,
-                       st, a);
-  } else if (variant == 1 && !a.amax8 && wide && a.PH == 14 && a.PW == 14 && !a.order && rpw >= 4) {
-    hipLaunchKernelGGL((roi_align_fwd_quad14_float<4>), dim3(cdiv(nroi * 4, 4) * a.nslice), dim3(512), padlds,
-                       st, a);
+  if (variant >= 1 && wide && a.PH == 7 && a.PW == 7) {
+    // four RoIs per workgroup share one set of axis tables
+    if (a.amax8)
+      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 4, true>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_tiled<7, 7, 4, false>), dim3(cdiv(nroi, 4) * a.nslice), dim3(512), 0, st, a);
   } else if (variant >= 1 && wide && a.PH == 14 && a.PW == 14) {
     if (a.amax8)
       hipLaunchKernelGGL((roi_align_fwd_tiled<14, 14, 1, true>), dim3(nroi * a.nslice), dim3(512), 0,
@@ -3204,10 +2819,10 @@ template <int PP>
 static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
   // LDS budget per workgroup: a plane larger than it is cut into row bands; several small planes
   // (CPB channels) share a workgroup only while that still leaves >= 1024 workgroups
-  const bool fx = tuning("roi_align_bwd_accum", 1) == 1;  // 1 int64 fixed point, 0 float CAS
+  constexpr bool fx = true;   // int64 fixed-point planes (bit-reproducible sums; float CAS inside on non-finite dY)
   const long esz = fx ? 8 : 4;
   const long plane_bytes = (long)a.H * a.W * esz;
-  const long budget = (long)tuning("roi_align_bwd_lds_kb", 72) * 1024;
+  const long budget = 72L * 1024;
   int cpb = 1;
   a.nbands = 1;
   a.band_rows = a.H;
@@ -3227,9 +2842,7 @@ static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
   SD_REQUIRE(lds <= 160 * 1024, "RoIAlign backward needs %zu B of LDS (W=%d R=%d too large)", lds,
              a.W, a.R);
   const int grid = a.B * a.nbands * (a.C / cpb);
-  int threads = tuning("roi_align_bwd_threads", 0);
-  if (threads != 256 && threads != 512 && threads != 1024)
-    threads = lds > 96 * 1024 ? 1024 : (lds > 24 * 1024 ? 512 : 256);
+  const int threads = lds > 96 * 1024 ? 1024 : (lds > 24 * 1024 ? 512 : 256);
 #define SD_BWD_LAUNCH(CPB, T, FX)                                                               \
   do {                                                                                          \
     auto k = roi_align_bwd_plane<PP, CPB, T, FX>;                                               \
@@ -3251,8 +2864,7 @@ static int launch_bwd_plane(BwdArgs& a, hipStream_t st) {
     else if (cpb == 4) SD_BWD_T(4, FX); \
     else SD_BWD_T(8, FX);              \
   } while (0)
-  if (fx) SD_BWD_C(true);
-  else SD_BWD_C(false);
+  SD_BWD_C(true);
 #undef SD_BWD_C
 #undef SD_BWD_T
 #undef SD_BWD_LAUNCH

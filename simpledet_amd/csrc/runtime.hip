@@ -30,57 +30,38 @@ struct Knob {
 };
 // every knob a kernel launcher reads must be listed here (sd_set_tuning rejects unknown keys)
 Knob g_knobs[] = {
-    {"roi_align_fwd", 0, false},         // 0 naive (reference structure), 1 LDS-tiled (default), 3 tiled at 3 WG/CU
-#ifdef SD_PROFILING
-    {"roi_align_fwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
-    {"roi_align_bwd_ablate", 0, false},  // profiling build only (results are wrong when != 0)
-    {"roi_align_fwd_padlds", 0, false},  // profiling build only: extra dynamic LDS bytes (occupancy sweep)
-    {"roi_align_dbg_lo", 0, false},      // profiling build only: device buffer for per-wave phase clocks
-    {"roi_align_dbg_hi", 0, false},
-    {"gemm_ablate", 0, false},           // profiling build only: skip the A (1) / B (2) prefetch of the split GEMM
-    {"gemm_dbg_cap", 0, false},          // profiling build only: waves the buffer above has room for (split GEMM)
-#endif
-    {"roi_align_fwd_order", 0, false},   // 1: locality order of the RoIs (-25% L2-miss reads, same time; default 0)
-    {"roi_align_fwd_rois", 0, false},    // RoIs per workgroup (1, 2 or 4; default 1: more in flight was measured slower)
-    {"roi_align_fwd_slices", 0, false},  // channel slices (workgroups) per RoI, default 8
-    {"roi_align_fwd_band", 0, false},    // 1 band-resident forward: planes streamed through LDS, no gathers (default), 0 tiled kernels
-    {"roi_align_fwd_steps", 0, false},   // channels per band workgroup (fills x planes per fill), default 8
-    {"roi_align_fwd_gbias", 0, false},   // per cent added to the cost estimate of multi-plane units (default 0: 15 and 30 measured, no effect)
-    {"roi_align_fwd_tail_planes", 0, false},  // planes of a tail piece (default 8 = a whole fill)
-    {"roi_align_fwd_tail", 0, false},    // last per cent of a unit's channels reserved one fill at a time (default 0)
-    {"roi_align_fwd_grab", 0, false},    // channels a band workgroup reserves at a time (default 4)
-    {"roi_align_fwd_fb_slices", 0, false},  // band kernel: workgroups that share a flagged RoI's channels on the exact path (default 32)
-    {"roi_align_fwd_wgs", 0, false},     // persistent band workgroups (default 256 = one per CU)
-    {"roi_align_fwd_split", 0, false},   // 1 more bands than LDS needs when a unit's expected items exceed a round (default)
-    {"roi_align_fwd_g", 0, false},       // most planes per fill of the band-resident forward (1, 2, 4 or 8; default 8)
-    {"roi_align_bwd", 0, false},         // 0 global atomics, 1 per-level LDS planes, 2 fused (default)
-    {"roi_align_bwd_lds_kb", 0, false},  // LDS budget per workgroup (band size), default 36
-    {"roi_align_bwd_accum", 0, false},   // per-level plane path only: 1 int64 fixed point, 0 float CAS
-    {"roi_align_bwd_order", 0, false},   // 0 longest workgroups first (default), 1 most workgroups first
-    {"roi_align_bwd_threads", 0, false}, // 256 or 512 (default)
-    {"roi_align_bwd_packed", 0, false},  // packed arg-max backward: 1 wide-load kernel (default), 0 per-item loads
+    // ---- product: every key selects a kernel that some shape or entry point reaches without it (the
+    // workspace-free entry points, C % 4 != 0, planes over the LDS budget, ...); tests force them here ----
+    {"roi_align_fwd", 0, false},         // 1 (default): band-resident kernel / tiled kernels where it does not apply; 0: naive per-element kernel
+    {"roi_align_fwd_band", 0, false},    // 1 (default) band-resident forward: planes streamed through LDS, no gathers; 0: the tiled fallback kernels
+    {"roi_align_bwd", 0, false},         // 2 (default) fused all-level kernel; 1 per-level LDS planes; 0 global atomics
     {"roi_align_bwd_flt4", 0, false},    // 1 (default): single-level float arg-max backward with four channel planes per workgroup when they fit
-    {"roi_align_bwd_tch", 0, false},     // RoIs per staged coordinate-table chunk (7x7: 16/32/64, 14x14: 8/16/32)
+    {"roi_align_bwd_fx", 0, false},      // 1 (default): band sums in 32-bit fixed point (bit-reproducible); 0: fp32 compare-and-swap adds, hardware order
     {"roi_align_bwd_lists", 0, false},   // workspace pre-pass: 1 RoI lists + tap tables per band unit (default), 2 lists only, 0 none
-    {"roi_pool_fwd", 0, false},          // 0 wave per (roi, channel), 1 four planes in LDS per workgroup (default), 2 one plane
-    {"roi_pool_bwd", 0, false},          // 0 global atomics, 1 LDS planes, four channels per workgroup (default), 2 one channel
+    {"roi_pool_fwd", 0, false},          // 1 (default) four planes in LDS per workgroup, 2 one plane, 0 wave per (roi, channel)
+    {"roi_pool_bwd", 0, false},          // 1 (default) LDS planes, four channels per workgroup, 2 one channel, 0 global atomics
     {"proposal_topk", 0, false},         // 0 by level size (default), 1 single workgroup, 2 multi-workgroup
-    {"top_proposal_select", 0, false},   // 1 radix select before the sort when top_n < N (default)
     {"soft_nms_threads", 0, false},      // threads per problem: 64, 128 or 256 (default)
-    {"deform_gemm_split", 0, false}, // 2 (default): scaled fp16 hi/lo split (needs operand maxima); 1: bf16 hi/lo split; 0: fp32 MFMA
-    {"deform_gemm_ksplit", 0, false},// 1 (default): tiles of a mostly empty last round are cut into k slices (atomic adds)
-    {"deform_gemm_bk", 0, false},    // K extent of a GEMM tile: 16 (default) or 32
-    {"deform_gemm_j", 0, false},     // GEMM tile width 64*J (1..3), 0 = by wave quantisation (default)
-    {"dcn_im2col", 0, false},        // 1 LDS-plane im2col (default), 0 per-lane global gathers
-    {"dcn_im2col_split", 0, false},  // channel splits per (image, group, pixel tile), default 1
-    {"dcn_im2col_nt", 0, false},     // bit 0: non-temporal col stores (default 1); bits 1-2 exist in the profiling build only
-    {"dcn_window", 0, false},        // 1 stage only the touched range of each plane (default)
-    {"dcn_col2im", 0, false},        // 1 four channels per workgroup, shared sample geometry (default), 0 one channel
-    {"dcn_col2im_fx", 0, false},     // 1 (default): the layer's backward sums dX in fixed point (integer LDS adds), 0 fp32 compare-and-swap
-    {"dcn_coord", 0, false},         // 1 LDS-plane offset gradient (default), 0 per-lane gathers
-    {"dcn_fused", 0, false},         // 1 (default): the col-free entry points sample inside the GEMM; 0: im2col + GEMM
-    {"dcn_fused_ablate", 0, false},  // profiling build only: parts of the fused kernels switched off
-    {"dcn_fused_tile", 0, false},    // pixels per tile of the fused kernels (1..96), 0 = balanced over the CUs (default)
+    {"deform_gemm_split", 0, false},     // 2 (default): scaled fp16 hi/lo split (needs operand maxima); 1: bf16 hi/lo split; 0: fp32 MFMA
+    {"deform_gemm_ksplit", 0, false},    // 1 (default): tiles of a mostly empty last round are cut into k slices (atomic adds)
+    {"dcn_im2col", 0, false},            // 1 LDS-plane im2col (default), 0 per-lane global gathers
+    {"dcn_window", 0, false},            // 1 stage only the touched range of each plane (default)
+    {"dcn_col2im", 0, false},            // 1 four channels per workgroup, shared sample geometry (default), 0 one channel
+    {"dcn_col2im_fx", 0, false},         // 1 (default): the layer's backward sums dX in fixed point (integer LDS adds), 0 fp32 compare-and-swap
+    {"dcn_coord", 0, false},             // 1 LDS-plane offset gradient (default), 0 per-lane gathers
+    {"dcn_fused", 0, false},             // 1 (default): the col-free entry points sample inside the GEMM; 0: im2col + GEMM
+    {"dcn_fused_tile", 0, false},        // pixels per tile of the fused kernels (1..96), 0 = balanced over the CUs (default): partial-tile tests
+#ifdef SD_PROFILING
+    // ---- profiling build only (tools/libsimpledet_ops_hip_prof.so): results are WRONG when != 0 ----
+    {"roi_align_fwd_ablate", 0, false},
+    {"roi_align_bwd_ablate", 0, false},
+    {"roi_align_dbg_lo", 0, false},      // device buffer for per-wave phase clocks
+    {"roi_align_dbg_hi", 0, false},
+    {"gemm_ablate", 0, false},           // skip the A (1) / B (2) prefetch of the split GEMM
+    {"gemm_dbg_cap", 0, false},          // waves the buffer above has room for (split GEMM)
+    {"dcn_im2col_nt", 0, false},         // bits 1-2: parts of the LDS im2col switched off
+    {"dcn_fused_ablate", 0, false},      // parts of the fused forward switched off
+#endif
 };
 }  // namespace
 

@@ -131,12 +131,21 @@ def _assert_bwd_close(got, want, tol=1e-4):
     assert err <= tol, "max abs err %g" % err
 
 
+def _fwd_path(path):
+    """the forward's three kernel families: "band" (default: band-resident kernel where the call has a
+    workspace and the shape fits), "tiled" (what workspace-free calls and other shapes get), "naive"
+    (per-element kernel: any pooled size)"""
+    from simpledet_amd._lib import lib
+    lib().set_tuning("roi_align_fwd", 0 if path == "naive" else 1)
+    lib().set_tuning("roi_align_fwd_band", 0 if path == "tiled" else 1)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 0, 3])  # tiled (default), naive, tiled at 3 WG/CU
+@pytest.mark.parametrize("variant", ["band", "naive", "tiled"])
 @pytest.mark.parametrize("case", ["small", "c4", "p2", "mask14", "odd_pool"])
 def test_single_level_forward_bit_exact(ops, oracle, case, variant):
     from simpledet_amd._lib import lib
-    lib().set_tuning("roi_align_fwd", variant)
+    _fwd_path(variant)
     try:
         if case == "small":
             data, rois = small_case(0, C=8)
@@ -162,7 +171,7 @@ def test_single_level_forward_bit_exact(ops, oracle, case, variant):
         for g, w, name in zip(got, want, ("output", "maxidx_x", "maxidx_y")):
             np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=name)
     finally:
-        lib().set_tuning("roi_align_fwd", 1)
+        _fwd_path("band")
 
 
 @pytest.mark.gpu
@@ -386,7 +395,7 @@ def _decode_packed(am, rois, feats_shapes, strides, level):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 0, 3])
+@pytest.mark.parametrize("variant", ["band", "naive", "tiled"])
 def test_fpn_packed_argmax_forward_backward(ops, oracle, variant):
     import torch
     from simpledet_amd._lib import lib
@@ -395,11 +404,11 @@ def test_fpn_packed_argmax_forward_backward(ops, oracle, variant):
     want = oracle.fpn_roi_align_fwd(feats, rois, STRIDES, (7, 7))
     _, level = oracle.fpn_roi_assign(rois, STRIDES)
     tf = [_t(f) for f in feats]
-    lib().set_tuning("roi_align_fwd", variant)
+    _fwd_path(variant)
     try:
         out, am = ops.fpn_roi_align_forward_packed(tf, _t(rois), STRIDES, (7, 7))
     finally:
-        lib().set_tuning("roi_align_fwd", 1)
+        _fwd_path("band")
     np.testing.assert_array_equal(out.cpu().numpy(), want[0])
     amn, con = ops.argmax_codes(am[0], (7, 7)).cpu().numpy(), am[1].cpu().numpy()
     np.testing.assert_array_equal(amn == 255, want[1] == -1)
@@ -450,23 +459,23 @@ def test_fpn_packed_equals_float_argmax_path_full_size(ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [3, 0])
+@pytest.mark.parametrize("variant", ["tiled", "naive"])
 def test_forward_variants_agree_at_full_size(ops, variant):
-    """Baseline shapes (2 x 512 RoIs x 256 channels, degenerate RoIs included): the tiled kernel at
-    3 workgroups per CU and the naive kernel give the default kernel's bits, in both the packed
-    and the float arg-max form."""
+    """Baseline shapes (2 x 512 RoIs x 256 channels, degenerate RoIs included): the tiled fallback kernel
+    and the naive kernel give the default kernel's bits, in both the packed and the float arg-max
+    form."""
     import torch
     from simpledet_amd._lib import lib
     feats = [_t(f) for f in synth.feature_maps(2, batch=2, channels=256)]
     rois = _t(synth.random_rois(2, 2, 512))
     o1, am1 = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, (7, 7))
     f1 = ops.fpn_roi_align_forward(feats, rois, STRIDES, (7, 7))
-    lib().set_tuning("roi_align_fwd", variant)
+    _fwd_path(variant)
     try:
         o2, am2 = ops.fpn_roi_align_forward_packed(feats, rois, STRIDES, (7, 7))
         f2 = ops.fpn_roi_align_forward(feats, rois, STRIDES, (7, 7))
     finally:
-        lib().set_tuning("roi_align_fwd", 1)
+        _fwd_path("band")
     assert torch.equal(o1, o2)
     assert torch.equal(ops.argmax_codes(am1[0], (7, 7)), ops.argmax_codes(am2[0], (7, 7)))
     # the coordinate table has entries only for RoIs assigned to a level (the rest is never read)

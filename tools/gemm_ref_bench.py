@@ -29,8 +29,6 @@ for name, f_t, f_s in [
 # tile-width A/B (sd_gemm_f32 only)
 from simpledet_amd._lib import lib
 for J, bk in ((1, 16), (2, 16), (3, 16), (0, 16), (1, 32), (2, 32)):
-    lib().set_tuning("deform_gemm_j", J)
-    lib().set_tuning("deform_gemm_bk", bk)
     r = []
     for f_s in (lambda: ops.gemm_f32(w, col), lambda: ops.gemm_f32(w, dy, trans_a=True),
                 lambda: ops.gemm_f32(dy, col, trans_b=True)):
