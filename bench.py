@@ -89,7 +89,8 @@ def kernel_source_sha():
     """sha256 over the sources of the kernels the roofline is about: a PMC profile is only quoted for them"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("roi_align.hip", "common.h", "runtime.hip"):
+    for f in ("roi_align_common.h", "roi_align_lists.h", "roi_align_fwd.hip", "roi_align_bwd.hip", "roi_align_prep.hip",
+              "common.h", "runtime.hip"):
         h.update(open(os.path.join(ROOT, "simpledet_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -408,7 +409,7 @@ def main():
         try:
             prof = json.load(open(pmc_path))
             # a profile is quoted only if it was taken with THESE kernel sources (tools/summarize_profile.py
-            # records the hash of simpledet_amd/csrc/{roi_align.hip,common.h,runtime.hip} next to the counters)
+            # records the hash of simpledet_amd/csrc/{roi_align_*.{h,hip},common.h,runtime.hip} next to the counters)
             if prof.get("kernel_source_sha256") != src_sha:
                 stale.append(os.path.basename(pmc_path))
                 continue

@@ -59,7 +59,8 @@ def main(out):
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("roi_align.hip", "common.h", "runtime.hip"):
+    for f in ("roi_align_common.h", "roi_align_lists.h", "roi_align_fwd.hip", "roi_align_bwd.hip", "roi_align_prep.hip",
+              "common.h", "runtime.hip"):
         h.update(open(os.path.join(root, "simpledet_amd", "csrc", f), "rb").read())
     res["kernel_source_sha256"] = h.hexdigest()
     # ... and per file, for the quotes that concern other kernels (bench.py: NMS L2 hit rates need nms.hip /
