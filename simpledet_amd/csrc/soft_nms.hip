@@ -35,27 +35,34 @@ struct SoftArgs {
 __device__ __forceinline__ float pmin(float a, float b) { return a <= b ? a : b; }  // cpu_nms.pyx:27
 __device__ __forceinline__ float pmax(float a, float b) { return a >= b ? a : b; }  // cpu_nms.pyx:30
 
-struct Cand {
-  float s;
-  int pos;  // -1: none
-};
-// "maxscore < boxes[pos, 4]" scanning upward from i: the first maximum wins, NaN never wins
-__device__ __forceinline__ Cand better(Cand a, Cand b) {
-  if (b.pos < 0) return a;
-  if (a.pos < 0) return b;
-  if (b.s > a.s || (b.s == a.s && b.pos < a.pos)) return b;
-  return a;
+// A candidate of the arg-max "maxscore < boxes[pos, 4]" scanning upward from i (the first maximum wins, NaN
+// never wins) as ONE 64-bit key: the score as an order-preserving 32-bit integer in the high word, the
+// complemented position in the low word; the larger key is the better candidate (higher score, then lower
+// position), 0 is "none".  One 64-bit compare + two selects per reduction step instead of the five compares
+// of a (score, position) pair -- the kernel is bound by its VALU instruction count (round 5: SQ_ACTIVE_INST_VALU
+// 76 % of the SIMD cycles with five problems per CU, profiles/r05g_ops_pmc_summary.json).
+//   -0.0 and +0.0 compare equal as floats, so -0.0 enters as +0.0; NaN scores never become candidates.
+typedef unsigned long long Cand;
+__device__ __forceinline__ Cand cand_of(float s, int pos) {
+  const unsigned b = __float_as_uint(s + 0.0f);
+  const unsigned ord = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);   // monotone in s over the non-NaN floats, > 0
+  return ((Cand)ord << 32) | (unsigned)(0x7fffffff - pos);
 }
+__device__ __forceinline__ int cand_pos(Cand c) { return c ? 0x7fffffff - (int)(unsigned)c : -1; }
+__device__ __forceinline__ float cand_score(Cand c) {
+  const unsigned ord = (unsigned)(c >> 32);
+  return __uint_as_float(ord ^ ((ord >> 31) ? 0x80000000u : 0xffffffffu));
+}
+__device__ __forceinline__ Cand better(Cand a, Cand b) { return b > a ? b : a; }
 // Wave arg-max on the DPP network (row shifts inside 16-lane rows, then two row broadcasts; the
 // result lands in lane 63): VALU latency per step instead of a ds_bpermute round trip per shuffle.
-// Returns wave-uniform values.
+// Returns a wave-uniform value.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ Cand dpp_step(Cand c) {
-  Cand d;
-  // lanes without a source keep "none" (pos = -1), which better() ignores
-  d.s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c.s), CTRL, ROW_MASK, 0xf, false));
-  d.pos = __builtin_amdgcn_update_dpp(-1, c.pos, CTRL, ROW_MASK, 0xf, false);
-  return better(c, d);
+  // lanes without a source keep "none" (0), which never wins
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)c, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(c >> 32), CTRL, ROW_MASK, 0xf, false);
+  return better(c, ((Cand)hi << 32) | lo);
 }
 __device__ __forceinline__ Cand wave_best_dpp(Cand c) {
   c = dpp_step<0x111, 0xf>(c);  // row_shr:1
@@ -64,10 +71,9 @@ __device__ __forceinline__ Cand wave_best_dpp(Cand c) {
   c = dpp_step<0x118, 0xf>(c);  // row_shr:8
   c = dpp_step<0x142, 0xa>(c);  // row_bcast:15 into rows 1 and 3
   c = dpp_step<0x143, 0xc>(c);  // row_bcast:31 into rows 2 and 3
-  Cand r;
-  r.s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.s), 63));
-  r.pos = __builtin_amdgcn_readlane(c.pos, 63);
-  return r;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)c, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(c >> 32), 63);
+  return ((Cand)hi << 32) | lo;
 }
 
 template <int THREADS>
@@ -87,9 +93,8 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
   // after the six planes: flag words, per-wave partial arg-max, control words
   unsigned long long* FW = reinterpret_cast<unsigned long long*>(smem + (((size_t)6 * Nmax + 1) & ~(size_t)1));
   const int nwords = (Nmax + 63) / 64 + 1;
-  float* PS = reinterpret_cast<float*>(FW + nwords);
-  int* PP = reinterpret_cast<int*>(PS + NW);
-  int* CTRL = PP + NW;  // [0] = N, [1] = step stamp of the last removal
+  Cand* PK = reinterpret_cast<Cand*>(FW + nwords);   // per-wave partial arg-max (keys)
+  int* CTRL = reinterpret_cast<int*>(PK + NW);  // [0] = N, [1] = step stamp of the last removal
   int* LIST = CTRL + 4;
   const int qcap = (((Nmax + kWave - 1) / kWave + NW - 1) / NW) * kWave;  // queue words per wave
 
@@ -112,25 +117,22 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
   for (int i = 0; i < n; ++i) {  // range(N) is evaluated once (cpu_nms.pyx:115)
     if (i >= N) break;
     if (!have_best) {
-      Cand c{0.f, -1};
+      Cand c = 0;
       for (int pos = i + wave * kWave + lane; pos < N; pos += THREADS) {
         const float sc = S[pos];
-        if (sc == sc) c = better(c, Cand{sc, pos});
+        if (sc == sc) c = better(c, cand_of(sc, pos));
       }
       c = wave_best_dpp(c);
-      if (lane == 0) {
-        PS[wave] = c.s;
-        PP[wave] = c.pos;
-      }
+      if (lane == 0) PK[wave] = c;
       __syncthreads();
     }
     // ---- selected box: arg-max over [i, N), box i wins ties and is immune to NaN comparisons ----
-    Cand best{0.f, -1};
+    Cand best = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) best = better(best, Cand{PS[w], PP[w]});
+    for (int w = 0; w < NW; ++w) best = better(best, PK[w]);
     const float si = S[i];
-    int maxpos = best.pos;
-    if (maxpos < 0 || !(si == si) || !(si < best.s)) maxpos = i;
+    // `si < best score`: box i sits at the lowest position, so its key beats every candidate of an equal score
+    const int maxpos = (!(si == si) || best <= cand_of(si, i)) ? i : cand_pos(best);
     // registers: the selected box (t*) and the old box i, which goes to position maxpos
     const float tx1 = X1[maxpos], ty1 = Y1[maxpos], tx2 = X2[maxpos], ty2 = Y2[maxpos];
     const float ts = S[maxpos];
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
     // exactly d > -1 for a float d.  Typically ~1% of the boxes overlap, so they are queued and the
     // expensive IoU / decay arithmetic (double adds, IEEE divide) runs once per step on a dense set
     // of lanes instead of in every 64-box chunk.  Untouched boxes enter the next arg-max here.
-    Cand c{0.f, -1};
+    Cand c = 0;
     const int M = N - (i + 1);
     // every wave queues the overlapping boxes of ITS chunks in its own segment (length in a
     // register: no LDS atomic, and no barrier between the two passes -- pass 2 of a wave only
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
         }
         const float dw = pmin(tx2, x2) - pmax(tx1, x1), dh = pmin(ty2, y2) - pmax(ty1, y1);
         ovl = dw > -1.f && dh > -1.f;
-        if (!ovl && s == s) c = better(c, Cand{s, pos});
+        if (!ovl && s == s) c = better(c, cand_of(s, pos));
       }
       const unsigned long long bal = __ballot(ovl);
       if (ovl) QL[nq + __popcll(bal & ((1ull << lane) - 1))] = pos;
@@ -197,14 +199,11 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
         any_removed = true;
         atomicOr(&FW[rel >> 6], 1ull << (rel & 63));
       } else if (ns == ns) {
-        c = better(c, Cand{ns, pos});
+        c = better(c, cand_of(ns, pos));
       }
     }
     c = wave_best_dpp(c);
-    if (lane == 0) {
-      PS[wave] = c.s;
-      PP[wave] = c.pos;
-    }
+    if (lane == 0) PK[wave] = c;
     if (any_removed) CTRL[1] = i;
     __syncthreads();
     have_best = true;
@@ -240,10 +239,11 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
             }
             return (w << 6) + __ffsll((long long)m) - 1;
           };
-          Cand gb{0.f, -1};  // arg-max of the remaining boxes, positions before the moves
+          Cand gb = 0;  // arg-max of the remaining boxes, positions before the moves
 #pragma unroll
-          for (int w = 0; w < NW; ++w) gb = better(gb, Cand{PS[w], PP[w]});
-          int bpos = gb.pos;
+          for (int w = 0; w < NW; ++w) gb = better(gb, PK[w]);
+          int bpos = cand_pos(gb);
+          const float gbs = cand_score(gb);
           int mv_h = 0, mv_s = 0;  // this lane's move: absolute positions hole <- source
           auto flush = [&](int cnt) {
             if (cnt == 0) return;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
 #pragma unroll
               for (int f = 0; f < 6; ++f) smem[f * Nmax + mv_h] = v[f];
               is_best = mv_s == bpos;
-              if (gb.pos >= 0 && v[4] == gb.s) cand = mv_h;  // carries the best score (never NaN)
+              if (gb && v[4] == gbs) cand = mv_h;  // carries the best score (never NaN)
             }
             if (__any(cand != 0x7fffffff)) {  // rare: a moved box carries the best score
               if (__any(is_best)) bpos = 0x7fffffff;  // the recorded best itself moved: it is in `cand`
@@ -281,10 +281,9 @@ __global__ __launch_bounds__(THREADS) void soft_nms_kernel(SoftArgs a) {
           flush(nmv & (kWave - 1));
           if (lane == 0) {
             CTRL[0] = i + 1 + Mc;
-            PS[0] = gb.s;
-            PP[0] = gb.pos >= 0 ? bpos : -1;
+            PK[0] = gb ? ((gb & 0xffffffff00000000ull) | (unsigned)(0x7fffffff - bpos)) : 0;
           }
-          if (lane > 0 && lane < NW) PP[lane] = -1;
+          if (lane > 0 && lane < NW) PK[lane] = 0;
         }
       } else if (wave == 0) {
         int Mc = M;
