@@ -333,6 +333,20 @@ def main():
 
     fwd_samples = [events[i][0].elapsed_time(events[i][1]) for i in event_steps]
     bwd_samples = [events[i][1].elapsed_time(events[i][2]) for i in event_steps]
+    # beside the line's value (not part of it): the same K steps with NO event in them, and with events in
+    # EVERY step (round 4's timed region), so that what the instrumentation costs is measured in this very run
+    instr = {}
+    if world == 1:
+        def leg(evs):
+            barrier()
+            t = time.perf_counter()
+            for i in range(args.steps):
+                step(evs[i] if evs else None)
+            barrier()
+            return (time.perf_counter() - t) * 1e3 / args.steps
+        every = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        instr = {"ms_per_step_no_events": leg(None), "ms_per_step_events_in_every_step": leg(every),
+                 "ms_per_step_no_events_again": leg(None)}
     fwd_ms = float(np.mean(fwd_samples))
     bwd_ms = float(np.mean(bwd_samples))
     ms_per_step = elapsed * 1e3 / args.steps
@@ -455,6 +469,7 @@ def main():
         "kernel_note": "names reported by the library for the dispatch it took (sd_last_dispatch); avg_launch_ms "
                        "spans every launch of the forward op incl. its rois-only pre-pass",
         "event_steps": event_steps,
+        "instrumentation": instr,
         "event_note": "HIP events on the torch stream the kernels are launched on, inside the timed region, on "
                       "every %d-th step (a record between launches costs 3-4 us of the step it times)" % stride,
         "fwd_ms_min_max": [float(min(fwd_samples)), float(max(fwd_samples))],
