@@ -132,32 +132,44 @@ def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
 
 
 @pytest.mark.gpu
-def test_lds_plane_kernels_equal_per_lane_kernels(ops):
-    """The LDS-plane im2col / offset-gradient kernels against the per-lane (reference-structure)
-    kernels they replace, at a size with several pixel tiles and the layer's 3x3 / 4-group setup."""
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, C=32, H=28, W=36, F=8, dg=4, off_scale=2.5),      # several pixel tiles, the layer's 3x3 / 4-group setup
+    dict(N=1, C=256, H=50, W=84, F=8, dg=4, off_scale=2.0),     # the BASELINE plane: 64 channels per group
+    dict(N=2, C=64, H=50, W=84, F=8, dg=4, off_scale=40.0),     # wild offsets: every window is the whole plane
+    dict(N=2, C=32, H=28, W=36, F=8, dg=4, off_scale=2.5, stride=2),
+    dict(N=1, C=12, H=20, W=24, F=8, dg=2, off_scale=1.0),      # 6 channels per group
+    dict(N=1, C=32, H=25, W=42, F=8, dg=4, off_scale=1.0),      # H*W % 4 != 0: scalar window copies
+])
+def test_sampling_kernel_families_give_the_same_bits(ops, cfg):
+    """deformable im2col and the offset gradient in their two forms -- LDS windows (`dcn_im2col` / `dcn_coord` = 1,
+    the default) and per-lane global gathers (= 0, the reference's structure): same expressions in the same
+    channel order, so the same bits; also with whole planes staged instead of windows (`dcn_window` = 0)."""
     import torch
     from simpledet_amd._lib import lib
-    x, off, w, kw = _case(11, N=2, C=32, H=28, W=36, F=8, dg=4, off_scale=2.5)
-    a = dict(pad=1, stride=1, dilate=1, num_deformable_group=4)
+    x, off, w, kw = _case(11, **cfg)
+    a = dict(pad=kw["pad"], stride=kw["stride"], dilate=kw["dil"], num_deformable_group=kw["dgroup"])
     tx, to = _t(x), _t(off)
-    col1 = ops.deform_im2col(tx, to, **a)
-    g = torch.randn_like(col1)
-    do1 = ops.deform_col2im_coord(g, tx, to, **a)
-    for k in ("dcn_im2col", "dcn_coord"):
-        lib().set_tuning(k, 0)
+    res = {}
+    g = None
     try:
-        col0 = ops.deform_im2col(tx, to, **a)
-        do0 = ops.deform_col2im_coord(g, tx, to, **a)
-    finally:
+        for mode in (1, 0):
+            for k in ("dcn_im2col", "dcn_coord"):
+                lib().set_tuning(k, mode)
+            col = ops.deform_im2col(tx, to, **a)
+            if g is None:
+                g = torch.randn_like(col)
+            res[mode] = (col, ops.deform_col2im_coord(g, tx, to, **a))
         for k in ("dcn_im2col", "dcn_coord"):
             lib().set_tuning(k, 1)
-    lib().set_tuning("dcn_window", 0)
-    try:
-        col2 = ops.deform_im2col(tx, to, **a)
+        lib().set_tuning("dcn_window", 0)
+        res["whole"] = (ops.deform_im2col(tx, to, **a), ops.deform_col2im_coord(g, tx, to, **a))
     finally:
         lib().set_tuning("dcn_window", 1)
-    assert torch.equal(col1, col0) and torch.equal(col1, col2)
-    assert torch.equal(do1, do0)  # same products, same channel order
+        for k in ("dcn_im2col", "dcn_coord"):
+            lib().set_tuning(k, 1)
+    for key in (0, "whole"):
+        assert torch.equal(res[1][0], res[key][0]), ("im2col", key)
+        assert torch.equal(res[1][1], res[key][1]), ("col2im_coord", key)   # same products, same channel order
 
 
 @pytest.mark.gpu
