@@ -671,9 +671,19 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
 // reads 196-byte fragments.  Here a workgroup owns FOUR consecutive channels of one image: the rows
 // of (RoI, c..c+3) are 784 contiguous, 16-byte aligned bytes of each of the three inputs, read as
 // dwordx4, and the four dX planes leave as one contiguous run.  The scatter is the reference's
-// (roi_align_v2.cu:35-84: every bin with an arg-max adds its four bilinear terms; the RoI geometry
-// is not read) with fp32 compare-and-swap adds in LDS.
-//   grid: x = channel quad, y = image; LDS = 4 * H * W floats
+// (roi_align_v2.cu:35-84: every bin with an arg-max adds its four bilinear terms).
+// Round 5: the sums are 32-bit fixed point (integer LDS adds: 4-9 lane adds per clock and CU against ~2
+// for the fp32 compare-and-swap loop, which was half of this kernel's time).  One unit is
+// 2^-30 of (max|dY| x the plane's weight bound).  The weight bound is per PIXEL here: a RoI can put at
+// most nx * ny bins' worth of weight on one pixel (the bins whose samples come within a pixel of it, as
+// in bwd_band_list), and only on the pixels of its own extent -- so every RoI adds nx * ny to its
+// rectangle of a 2-D difference array (four integer adds), two prefix passes turn that into the bound
+// of every pixel, and its maximum is the plane's.  (The band kernels sum nx * ny over ALL RoIs of a band:
+// 512 RoIs of 16 would always exceed their cap of 2048.)  max|dY| is taken optimistically from each
+// thread's first item with a factor two of headroom and verified behind the scatter, as in
+// roi_align_bwd_packed4; non-finite gradients, a weight bound above 2048 and `roi_align_bwd_fx` = 0
+// take the fp32 compare-and-swap adds.  The result is a deterministic function of the inputs.
+//   grid: x = channel quad, y = image; LDS = 4 * H * W words + 8
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArgs a, int lvl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -684,44 +694,167 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
   const int img = blockIdx.y;
   const int H = a.L.H[lvl], W = a.L.W[lvl], HW = H * W, PP = a.PP;
   float* plane = smem;  // [CC][HW]
-  for (int i = tid; i < CC * HW; i += THREADS) plane[i] = 0.f;
-  __syncthreads();
+  int* plane_i = reinterpret_cast<int*>(smem);
+  int* ctl = plane_i + CC * HW;  // [0] weight bound, [1] max|dY| of the first items, [2] non-finite flag, [3] true max|dY|
+  bool use_fx = !a.float_adds;
+  if (tid < 8) ctl[tid] = 0;
+  if (use_fx) {
+    // per-pixel weight bound: difference array of (H + 1) x (W + 1) words in the (not yet used) planes
+    const int DW = W + 1;
+    for (int i = tid; i < (H + 1) * DW; i += THREADS) plane_i[i] = 0;
+    __syncthreads();
+    const int pw = PP == 49 ? 7 : 14;  // the launcher admits 7x7 and 14x14
+    const float scale = a.L.scale[lvl];
+    for (int r = tid; r < a.R; r += THREADS) {
+      const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + r) * 4);
+      // pixels the taps of this RoI can reach: the clipped box +-2 (bwd_band_list); anything else
+      // (NaN / inf coordinates) counts on the whole plane
+      const float xs = fminr(fmaxr(rb.x * scale, 0.f), (float)(W - 1)), xe = fminr(fmaxr(rb.z * scale, 0.f), (float)(W - 1));
+      const float ys = fminr(fmaxr(rb.y * scale, 0.f), (float)(H - 1)), ye = fminr(fmaxr(rb.w * scale, 0.f), (float)(H - 1));
+      const float xlo = fminr(xs, xe) - 2.f, xhi = fmaxr(xs, xe) + 2.f;
+      const float ylo = fminr(ys, ye) - 2.f, yhi = fmaxr(ys, ye) + 2.f;
+      int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
+      if (xlo >= -2.f && xhi <= (float)(W + 1)) { x0 = imaxr((int)floorf(xlo), 0); x1 = iminr((int)ceilf(xhi), W - 1); }
+      if (ylo >= -2.f && yhi <= (float)(H + 1)) { y0 = imaxr((int)floorf(ylo), 0); y1 = iminr((int)ceilf(yhi), H - 1); }
+      const float bwx = (rb.z - rb.x) * scale * (1.f / (float)pw), bwy = (rb.w - rb.y) * scale * (1.f / (float)pw);
+      const float fx = 2.00002f * __builtin_amdgcn_rcpf(bwx), fy = 2.00002f * __builtin_amdgcn_rcpf(bwy);
+      const int nx = (bwx > 0.f && fx < (float)pw) ? iminr((int)fx + 2, pw) : pw;
+      const int ny = (bwy > 0.f && fy < (float)pw) ? iminr((int)fy + 2, pw) : pw;
+      const int w = nx * ny;
+      atomicAdd(plane_i + y0 * DW + x0, w);
+      atomicAdd(plane_i + y0 * DW + x1 + 1, -w);
+      atomicAdd(plane_i + (y1 + 1) * DW + x0, -w);
+      atomicAdd(plane_i + (y1 + 1) * DW + x1 + 1, w);
+    }
+    __syncthreads();
+    for (int y = tid; y <= H; y += THREADS) {  // prefix along the rows (running sum in a register)
+      int run = 0;
+#pragma unroll 4
+      for (int x = 0; x <= W; ++x) {
+        run += plane_i[y * DW + x];
+        plane_i[y * DW + x] = run;
+      }
+    }
+    __syncthreads();
+    int m = 0;
+    for (int x = tid; x <= W; x += THREADS) {  // prefix down the columns: only its maximum is kept
+      int run = 0;
+#pragma unroll 4
+      for (int y = 0; y <= H; ++y) {
+        run += plane_i[y * DW + x];
+        m = imaxr(m, run);
+      }
+    }
+    if (m > 0) atomicMax(ctl, m);
+    __syncthreads();
+  }
+  for (int i = tid; i < CC * HW; i += THREADS) plane_i[i] = 0;
   const int per = CC * PP / 4;  // float4 units per RoI (CC * PP is a multiple of 4)
   const int nunits = a.R * per;
   const long base = ((long)img * a.R * a.C + c) * PP;
   const long roi_stride = (long)a.C * PP;
-  for (int u = tid; u < nunits; u += THREADS) {
-    const int r = u / per, L = u - r * per;
-    const long idx = base + r * roi_stride + 4 * L;
-    const float4 g4 = *reinterpret_cast<const float4*>(a.dy + idx);
-    const float4 x4 = *reinterpret_cast<const float4*>(a.ax + idx);
-    const float4 y4 = *reinterpret_cast<const float4*>(a.ay + idx);
-    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
-    const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float a_x = xx[k], a_y = yy[k];
-      if (a_x == -1.f || a_y == -1.f) continue;  // roi_align_v2.cu:53: nothing was pooled
-      const int e = 4 * L + k;
-      const int cc = (e >= PP) + (e >= 2 * PP) + (e >= 3 * PP);
-      const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
-      const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
-      const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
-      const int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
-      // (v - low) / (high - low) with high - low == 1
-      const float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow);
-      const float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft);
-      const float g = gg[k];
-      float* pl = plane + cc * HW;
-      lds_add_cas(pl + hlow * W + wleft, g * (1 - alpha) * (1 - beta));
-      lds_add_cas(pl + hlow * W + wright, g * (1 - alpha) * beta);
-      lds_add_cas(pl + hhigh * W + wleft, g * alpha * (1 - beta));
-      lds_add_cas(pl + hhigh * W + wright, g * alpha * beta);
+  struct Item { float4 g, x, y; int L; };
+  auto load_item = [&](int u, Item& it) {
+    it.L = -1;
+    if (u < nunits) {
+      const int r = u / per, L = u - r * per;
+      const long idx = base + r * roi_stride + 4 * L;
+      it.g = *reinterpret_cast<const float4*>(a.dy + idx);
+      it.x = *reinterpret_cast<const float4*>(a.ax + idx);
+      it.y = *reinterpret_cast<const float4*>(a.ay + idx);
+      it.L = L;
     }
+  };
+  auto abs4 = [](const float4& g) {
+    return fmaxr(fmaxr(fabsf(g.x), fabsf(g.y)), fmaxr(fabsf(g.z), fabsf(g.w)));
+  };
+  auto wave_max_to = [&](float m, int bad, int slot) {
+    m = wave_max_f32(m);
+    if ((tid & (kWave - 1)) == 0)  // non-negative floats order like their bit patterns
+      atomicMax(reinterpret_cast<unsigned*>(ctl + slot), __float_as_uint(m));
+    if (__any(bad) && (tid & (kWave - 1)) == 0) atomicOr(ctl + 2, 1);
+  };
+  float fx_scale = 1.f, fx_inv = 1.f;
+  auto set_scale = [&](float gmax) {
+    const float bound = gmax * (float)ctl[0];  // no pixel of a plane can exceed this
+    if (!(bound <= FLT_MAX) || ctl[0] > 2048) { use_fx = false; return; }
+    int e;
+    frexpf(bound > 0.f ? bound : 1.f, &e);  // bound < 2^e
+    const int S = iminr(30 - e, 126);
+    fx_scale = ldexpf(1.f, S);
+    fx_inv = ldexpf(1.f, -S);
+  };
+  Item cur;
+  load_item(tid, cur);
+  float m_all = cur.L >= 0 ? abs4(cur.g) : 0.f;
+  int bad = !(m_all <= FLT_MAX);
+  if (use_fx) wave_max_to(m_all, bad, 1);
+  __syncthreads();  // the planes are zero, the first maxima are in
+  float gmax_used = 0.f;
+  if (use_fx) {
+    gmax_used = __uint_as_float((unsigned)ctl[1]);
+    if (ctl[2]) use_fx = false;
+    else set_scale(gmax_used > 0.f ? gmax_used : 1.f);
+  }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt > 0) load_item(tid, cur);
+    for (int u = tid; u < nunits; u += THREADS) {
+      Item nxt;
+      load_item(u + THREADS, nxt);
+      const float ag = abs4(cur.g);
+      bad |= !(ag <= FLT_MAX);
+      m_all = fmaxr(m_all, ag);
+      const float gg[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w}, xx[4] = {cur.x.x, cur.x.y, cur.x.z, cur.x.w};
+      const float yy[4] = {cur.y.x, cur.y.y, cur.y.z, cur.y.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a_x = xx[k], a_y = yy[k];
+        if (a_x == -1.f || a_y == -1.f) continue;  // roi_align_v2.cu:53: nothing was pooled
+        const int e = 4 * cur.L + k;
+        const int cc = (e >= PP) + (e >= 2 * PP) + (e >= 3 * PP);
+        const int hlow = iminr(imaxr((int)floorf(a_y), 0), H - 1);
+        const int hhigh = iminr(imaxr((int)ceilf(a_y), 0), H - 1);
+        const int wleft = iminr(imaxr((int)floorf(a_x), 0), W - 1);
+        const int wright = iminr(imaxr((int)ceilf(a_x), 0), W - 1);
+        // (v - low) / (high - low) with high - low == 1
+        const float alpha = (hlow == hhigh) ? 0.5f : (a_y - (float)hlow);
+        const float beta = (wleft == wright) ? 0.5f : (a_x - (float)wleft);
+        const float g = gg[k];
+        const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
+        const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
+        const int o0 = cc * HW + hlow * W, o1 = cc * HW + hhigh * W;
+        if (use_fx) {
+          lds_add_i32(plane_i + o0 + wleft, w00, fx_scale);
+          lds_add_i32(plane_i + o0 + wright, w01, fx_scale);
+          lds_add_i32(plane_i + o1 + wleft, w10, fx_scale);
+          lds_add_i32(plane_i + o1 + wright, w11, fx_scale);
+        } else {
+          lds_add_cas(plane + o0 + wleft, w00);
+          lds_add_cas(plane + o0 + wright, w01);
+          lds_add_cas(plane + o1 + wleft, w10);
+          lds_add_cas(plane + o1 + wright, w11);
+        }
+      }
+      cur = nxt;
+    }
+    if (!use_fx || attempt > 0) break;
+    // was the optimistic scale enough?
+    wave_max_to(m_all, bad, 3);
+    __syncthreads();
+    const float gmax_true = __uint_as_float((unsigned)ctl[3]);
+    if (!ctl[2] && gmax_true <= 2.f * gmax_used) break;  // also when all gradients are zero
+    __syncthreads();  // every thread has read the verdict before the planes are cleared
+    for (int i = tid; i < CC * HW; i += THREADS) plane_i[i] = 0;  // rare: again, with the exact maximum (or float adds)
+    if (ctl[2]) use_fx = false;
+    else set_scale(gmax_true);
+    __syncthreads();
   }
   __syncthreads();
   float* dst = a.dx[lvl] + ((long)img * a.C + c) * HW;  // the four planes are contiguous
-  for (int i = tid; i < CC * HW; i += THREADS) dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + plane[i] : plane[i];
+  for (int i = tid; i < CC * HW; i += THREADS) {
+    const float v = use_fx ? (float)plane_i[i] * fx_inv : plane[i];
+    dst[i] = (a.req == SD_REQ_ADD) ? dst[i] + v : v;
+  }
 }
 
 // levels: dx[l] / H / W / scale from a.L; returns SD_ERR_UNSUPPORTED when a level does not fit
@@ -745,7 +878,7 @@ int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace,
   if (prepass == 0 && flt && !a.filter && nlvl == 1 && a.dx[0] && a.C % 4 == 0 && a.B <= 65535 &&
       (long)a.L.H[0] * a.L.W[0] * 16 <= 72 * 1024 && tuning("roi_align_bwd_flt4", 1) == 1 &&
       (((uintptr_t)a.dy | (uintptr_t)a.ax | (uintptr_t)a.ay) & 15) == 0) {
-    const size_t lds4 = (size_t)a.L.H[0] * a.L.W[0] * 16;
+    const size_t lds4 = (size_t)a.L.H[0] * a.L.W[0] * 16 + 32;
     if (lds4 > 64 * 1024)
       SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_align_bwd_flt4_kernel<512>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));

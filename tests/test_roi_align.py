@@ -219,6 +219,57 @@ def test_single_level_backward(ops, oracle, case, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c4", "mask14", "late_outlier", "inf", "piled", "nan_roi"])
+def test_c4_backward_fixed_point_planes(ops, oracle, case):
+    """roi_align_bwd_flt4_kernel (the drop-in backward of the C4 family: four channel planes of one image per
+    workgroup) sums in 32-bit fixed point since round 5: against the oracle, against its own fp32
+    compare-and-swap adds (`roi_align_bwd_fx` = 0), and bit-reproducible from run to run.
+      late_outlier: one gradient 1000 x the rest that no thread sees in its first item -> the optimistic
+                    scale fails its check and the planes are summed again with the exact maximum
+      inf:          a non-finite gradient must reach its four pixels as the reference's float adds deliver it
+      piled:        512 copies of one tiny RoI: per-pixel weight bound 25,088 > 2048 -> float adds
+      nan_roi:      a RoI of NaNs (its arg-max planes are -1: nothing pooled) counts on the whole plane"""
+    import torch
+    from simpledet_amd._lib import lib
+    pooled = (14, 14) if case == "mask14" else (7, 7)
+    R = 96 if case == "mask14" else 512
+    data = synth.feature_maps(11, 2, 8, ((50, 84),))[0]
+    rois = synth.random_rois(12, 2, R)
+    if case == "piled":
+        rois[:] = np.array([400.0, 300.0, 415.0, 316.0], np.float32)
+    if case == "nan_roi":
+        rois[0, 5] = np.nan
+    o, ax, ay = oracle.roi_align_v2_fwd(data, rois, pooled, 1 / 16.0, nthreads=8)
+    dy = np.random.RandomState(13).standard_normal(o.shape).astype(np.float32)
+    if case == "late_outlier":
+        dy[1, R - 3, 5, 3, 3] = 4000.0
+    if case == "inf":
+        dy[0, 17, 2, 4, 4] = np.inf
+    want = oracle.roi_align_v2_bwd(dy, ax, ay, data.shape)
+    args = (_t(dy), _t(rois), _t(ax), _t(ay), data.shape, 1 / 16.0)
+    got = ops.roi_align_v2_backward(*args)[0]
+    again = ops.roi_align_v2_backward(*args)[0]
+    lib().set_tuning("roi_align_bwd_fx", 0)
+    try:
+        flt = ops.roi_align_v2_backward(*args)[0]
+    finally:
+        lib().set_tuning("roi_align_bwd_fx", 1)
+    g, f = got.cpu().numpy(), flt.cpu().numpy()
+    if case not in ("piled", "inf"):   # integer sums do not depend on the order of the adds (float adds do)
+        assert torch.equal(got, again)
+    fin = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(g), fin)
+    np.testing.assert_array_equal(g[~fin], want[~fin])
+    # one unit is <= 2 max|dY| * 2048 * 2^-30: the elementwise bar scales with the largest gradient
+    gmax = float(np.abs(dy[np.isfinite(dy)]).max())
+    # (and with the sums themselves -- gradient sums reach ~30 in the other cases, hundreds when 512 RoIs coincide:
+    # there the float adds in another order than the oracle's differ by more)
+    tol = 1e-4 * max(1.0, gmax / 5.0, float(np.abs(want[fin]).max()) / 30.0)
+    assert float(np.abs(g[fin] - want[fin]).max()) <= tol
+    assert float(np.abs(f[fin] - want[fin]).max()) <= tol
+
+
+@pytest.mark.gpu
 def test_backward_rejects_write_inplace(ops):
     import torch
     from simpledet_amd._lib import SimpleDetOpsError
