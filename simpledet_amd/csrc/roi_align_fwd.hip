@@ -989,7 +989,8 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
               if constexpr (HALF) reinterpret_cast<__half*>(a.out)[oo] = __float2half(maxval);
               else a.out[oo] = maxval;
             }
-            if (PK) {
+            if (SD_ABLATE(a, 256)) {   // (profiling build: no arg-max stores)
+            } else if (PK) {
               a.amax8[ao] = (unsigned char)bk;
             } else {
               a.ax[oo] = bx_;
