@@ -1079,6 +1079,143 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Whole-plane forward of the drop-in ROIAlign_v2 (round 5): the C4 family -- a single level whose four
+// channel planes fit in LDS together ((2,1024,50,84): 67 KB), 7x7 bins, float arg-max outputs.  The dual of
+// roi_align_bwd_flt4_kernel: workgroup = (channel quad, image), two per CU.
+//   planes   staged CHANNEL-LAST ([position][4 channels]: a 4 x 4 register block per lane, four 16-byte LDS
+//            stores); a tap of four channels is one ds_read_b128, and the sample positions / fractions of a
+//            (RoI, bin) -- the pre-pass's row / column entries, the ones the band kernel keeps in registers --
+//            are shared by the four channels (the arithmetic runs on channel PAIRS: v_pk_mul / v_pk_add).
+//   stores   92 % of this op's traffic is its three fp32 outputs.  Written per lane as 4-byte elements they
+//            reach 2.9 TB/s (twelve 256-byte pieces per wave and trip; `profiles/r05r_*`: the stores ALONE
+//            take 0.21 ms, a plain fill of the same 617 MB 0.09).  So a wave owns one RoI per trip (lane =
+//            bin, 49 of 64 lanes), transposes each output through 784 bytes of wave-private LDS and writes the
+//            784-byte run of (RoI, four channels) as 49 x 16 bytes: three stores per trip instead of twelve,
+//            whole aligned runs.  (LDS operations of one wave complete in order: no barrier.)
+// Same float expressions in the same order as roi_align_fwd_band (and roi_align_fwd_elem): bit-equal.
+// RoIs the pre-pass flags (three-sample bins, nothing pooled) take roi_align_fwd_elem / the constant.
+//   grid: x = channel quad, y = image; LDS = (H * W + 1) * 16 bytes + 8 x 784
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void roi_align_fwd_quad(BandArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float band_smem[];
+  const FwdArgs& a = A.f;
+  const BandPlan& P = A.p;
+  constexpr int T = 512, POOL = 7, PPG = POOL * POOL, NW = T / kWave;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int G = a.C / 4;
+  const int c = 4 * ((G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+  const int img = blockIdx.y;
+  const int H = a.L.H[0], W = a.L.W[0], HW = H * W;
+  float4* pl = reinterpret_cast<float4*>(band_smem);
+  float* st = band_smem + 4 * (HW + 1) + wave * (4 * PPG);   // this wave's 784 bytes
+  const float* src = reinterpret_cast<const float*>(a.L.data[0]) + ((long)img * a.C + c) * HW;
+  for (int i4 = tid; i4 < (HW >> 2); i4 += T) {
+    const float4 v0 = *reinterpret_cast<const float4*>(src + 4 * i4);
+    const float4 v1 = *reinterpret_cast<const float4*>(src + (long)HW + 4 * i4);
+    const float4 v2 = *reinterpret_cast<const float4*>(src + 2L * HW + 4 * i4);
+    const float4 v3 = *reinterpret_cast<const float4*>(src + 3L * HW + 4 * i4);
+    pl[4 * i4 + 0] = make_float4(v0.x, v1.x, v2.x, v3.x);
+    pl[4 * i4 + 1] = make_float4(v0.y, v1.y, v2.y, v3.y);
+    pl[4 * i4 + 2] = make_float4(v0.z, v1.z, v2.z, v3.z);
+    pl[4 * i4 + 3] = make_float4(v0.w, v1.w, v2.w, v3.w);
+  }
+  if (tid == 0) pl[HW] = make_float4(0.f, 0.f, 0.f, 0.f);   // the "right" tap read beside the last pixel (weight 0 or replaced)
+  __syncthreads();
+  const bool act = lane < PPG;
+  const int bin = act ? lane : 0, pp = bin / POOL, q = bin - pp * POOL;
+  // the table entries of a RoI are fetched one trip ahead (the output pointers may alias anything as far as
+  // the compiler knows: behind the stores of a trip the loads of the next would start only then)
+  struct Ent { uint4 re, ce; float2 rv, cv; int flag; };
+  auto load_ent = [&](int n, Ent& e) {
+    e.flag = 2;
+    e.re = e.ce = make_uint4(0, 0, 0, 0);
+    e.rv = e.cv = make_float2(0.f, 0.f);
+    if (n < a.R) {
+      const long roi = (long)img * a.R + n;
+      e.flag = P.fbflag[roi];
+      e.re = P.rowent[roi * POOL + pp];
+      e.ce = P.colent[roi * POOL + q];
+      e.rv = P.rowval[roi * POOL + pp];
+      e.cv = P.colval[roi * POOL + q];
+    }
+  };
+  Ent cur;
+  load_ent(wave, cur);
+  for (int n = wave; n < a.R; n += NW) {
+    const long roi = (long)img * a.R + n;
+    const int flag = __builtin_amdgcn_readfirstlane(cur.flag);
+    const uint4 re = cur.re, ce = cur.ce;
+    const float2 rv = cur.rv, cv = cur.cv;
+    load_ent(n + NW, cur);
+    const long ob = (roi * a.C + c) * PPG;
+    if (flag) {
+      // exact per-element path (a handful of RoIs) / constant output: element stores
+      const float4 bx = *reinterpret_cast<const float4*>(a.rois + roi * 4);
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        FwdOut o{0.f, -1.f, -1.f, 255};
+        if (flag == 1 && act) o = roi_align_fwd_elem(src + (long)k * HW, H, W, bx.x, bx.y, bx.z, bx.w, a.L.scale[0], pp, q, POOL, POOL);
+        if (act) {
+          a.out[ob + k * PPG + bin] = o.val;
+          a.ax[ob + k * PPG + bin] = o.ax;
+          a.ay[ob + k * PPG + bin] = o.ay;
+        }
+      }
+      continue;
+    }
+    float maxval[4], bx_[4], by_[4];
+    {
+      const int lo0 = (int)(re.x & 0xfffff), lo1 = (int)(re.y & 0xfffff);
+      const int hi0 = lo0 + ((re.x >> 20) & 1 ? W : 0), hi1 = lo1 + ((re.y >> 20) & 1 ? W : 0);
+      const int left0 = ce.x & 0xfff, left1 = (ce.x >> 13) & 0xfff;
+      // coincident (left, right) columns: both taps are the left pixel
+      const int right0 = left0 + ((ce.x >> 12) & 1 ? 0 : 1), right1 = left1 + ((ce.x >> 25) & 1 ? 0 : 1);
+      const bool empty = (re.x >> 31) | ((ce.x >> 26) & 1);
+      const float fa0 = __uint_as_float(re.z), fa1 = __uint_as_float(re.w);
+      const float fb0 = __uint_as_float(ce.z), fb1 = __uint_as_float(ce.w);
+      // weight products, the reference's expressions (roi_align_v2-inl.h:131-134), paired (left, right)
+      const v2f b0 = {1 - fb0, fb0}, b1 = {1 - fb1, fb1};
+      const v2f wl00 = (1 - fa0) * b0, wh00 = fa0 * b0, wl01 = (1 - fa0) * b1, wh01 = fa0 * b1;
+      const v2f wl10 = (1 - fa1) * b0, wh10 = fa1 * b0, wl11 = (1 - fa1) * b1, wh11 = fa1 * b1;
+      const float init = empty ? 0.f : -FLT_MAX;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { maxval[k] = init; bx_[k] = -1.f; by_[k] = -1.f; }
+      // one sample: rows (lo, hi), columns (left, right), four channels at a time as two channel pairs;
+      // value = w1*TL + w2*BL + w3*TR + w4*BR, summed left to right (roi_align_v2-inl.h:135-138)
+      auto sample = [&](int lo, int hi, int left, int right, v2f wl, v2f wh, float cx, float cy) {
+        const float4 tl = pl[lo + left], bl = pl[hi + left], tr = pl[lo + right], br = pl[hi + right];
+        const v2f w1 = {wl.x, wl.x}, w2 = {wh.x, wh.x}, w3 = {wl.y, wl.y}, w4 = {wh.y, wh.y};
+        const v2f va = ((w1 * v2f{tl.x, tl.y} + w2 * v2f{bl.x, bl.y}) + w3 * v2f{tr.x, tr.y}) + w4 * v2f{br.x, br.y};
+        const v2f vb = ((w1 * v2f{tl.z, tl.w} + w2 * v2f{bl.z, bl.w}) + w3 * v2f{tr.z, tr.w}) + w4 * v2f{br.z, br.w};
+        const float value[4] = {va.x, va.y, vb.x, vb.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (value[k] > maxval[k]) { maxval[k] = value[k]; bx_[k] = cx; by_[k] = cy; }
+      };
+      sample(lo0, hi0, left0, right0, wl00, wh00, cv.x, rv.x);
+      sample(lo0, hi0, left1, right1, wl01, wh01, cv.y, rv.x);
+      sample(lo1, hi1, left0, right0, wl10, wh10, cv.x, rv.y);
+      sample(lo1, hi1, left1, right1, wl11, wh11, cv.y, rv.y);
+    }
+    // [channel][bin] through the wave's LDS row, then 49 lanes x 16 bytes = the 784-byte run of (RoI, c .. c + 3)
+    auto put = [&](const float (&v)[4], float* dst) {
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k * PPG + bin] = v[k];
+        *reinterpret_cast<float4*>(dst + ob + 4 * lane) = *reinterpret_cast<const float4*>(st + 4 * lane);
+      }
+    };
+    if (!(SD_ABLATE(a, 128))) put(maxval, a.out);   // (profiling build: 128 no value stores, 256 no arg-max stores)
+    if (!(SD_ABLATE(a, 256))) {
+      put(bx_, a.ax);
+      put(by_, a.ay);
+    }
+  }
+}
+
+
 __global__ __launch_bounds__(256) void fpn_assign_kernel(const float* rois, int n_rois,
                                                          RoiLevels L, float* rois_per_level,
                                                          int32_t* level) {
@@ -1256,6 +1393,22 @@ int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace, size_t workspace_byt
       const bool merged = bplan && bplan->lists_units > 0 && bplan->PP == POOL * POOL;
       if (bplan_done) *bplan_done = merged;
       if (int e = launch_fwd_prep(A, POOL, nlist + nent + ncoord, merged ? bplan : nullptr, st)) return e;
+      // single level, 7x7, float arg-max, four whole planes fit in LDS together (the C4 family): one workgroup
+      // per (channel quad, image) with channel-last planes and 784-byte stores (`roi_align_fwd_quad` = 0: the band kernel)
+      {
+        const long HW0 = (long)a.L.H[0] * a.L.W[0];
+        const size_t lds = (size_t)(HW0 + 1) * 16 + 8 * 4 * 49 * sizeof(float);
+        if (!a.amax8 && !a.half_io && POOL == 7 && a.L.nlvl == 1 && a.L.stride[0] >= 0 && P.nbands[0] == 1 &&
+            a.C % 4 == 0 && HW0 % 4 == 0 && lds <= 78 * 1024 && a.B <= 65535 &&
+            (((uintptr_t)a.L.data[0] | (uintptr_t)a.out | (uintptr_t)a.ax | (uintptr_t)a.ay) & 15) == 0 &&
+            tuning("roi_align_fwd_quad", 1) == 1) {
+          SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_align_fwd_quad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(roi_align_fwd_quad, dim3(a.C / 4, a.B), dim3(512), lds, st, A);
+          note_dispatch("sd::roi_fwd_prep_kernel<7> + sd::roi_align_fwd_quad");
+          SD_LAUNCH_CHECK();
+          return SD_OK;
+        }
+      }
 #define SD_FWD_BAND(POOLV, PK)                                                                    \
   do {                                                                                            \
     auto k = roi_align_fwd_band<POOLV, PK>;                                                       \

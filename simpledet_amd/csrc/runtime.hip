@@ -34,6 +34,7 @@ Knob g_knobs[] = {
     // workspace-free entry points, C % 4 != 0, planes over the LDS budget, ...); tests force them here ----
     {"roi_align_fwd", 0, false},         // 1 (default): band-resident kernel / tiled kernels where it does not apply; 0: naive per-element kernel
     {"roi_align_fwd_band", 0, false},    // 1 (default) band-resident forward: planes streamed through LDS, no gathers; 0: the tiled fallback kernels
+    {"roi_align_fwd_quad", 0, false},    // 1 (default): single-level float arg-max forward with four channel-last planes per workgroup when they fit (the C4 family); 0: the band kernel
     {"roi_align_bwd", 0, false},         // 2 (default) fused all-level kernel; 1 per-level LDS planes; 0 global atomics
     {"roi_align_bwd_flt4", 0, false},    // 1 (default): single-level float arg-max backward with four channel planes per workgroup when they fit
     {"roi_align_bwd_fx", 0, false},      // 1 (default): band sums in 32-bit fixed point (bit-reproducible); 0: fp32 compare-and-swap adds, hardware order

@@ -175,6 +175,31 @@ def test_single_level_forward_bit_exact(ops, oracle, case, variant):
 
 
 @pytest.mark.gpu
+def test_c4_whole_plane_forward_equals_band_kernel_at_full_size(ops):
+    """roi_align_fwd_quad (round 5: the drop-in forward of the C4 family -- four channel-last planes per workgroup,
+    a wave per RoI, 784-byte stores through wave-private LDS) against the band kernel (`roi_align_fwd_quad` = 0) at
+    BASELINE's C4 size, degenerate RoIs included (three-sample bins and empty RoIs take the exact path inside
+    either kernel): the same bits in all three outputs, run after run (the staging has no barrier: it relies on
+    the in-order LDS of a wave)."""
+    import torch
+    from simpledet_amd._lib import lib
+    data = torch.randn((2, 1024, 50, 84), device="cuda")
+    rois = _t(synth.random_rois(21, 2, 512))
+    lib().set_tuning("roi_align_fwd_quad", 0)
+    try:
+        want = [t.clone() for t in ops.roi_align_v2_forward(data, rois, (7, 7), 1 / 16.0)]
+        assert "fwd_band" in (lib().cdll.sd_last_dispatch() or b"").decode()
+    finally:
+        lib().set_tuning("roi_align_fwd_quad", 1)
+    for _ in range(3):
+        got = ops.roi_align_v2_forward(data, rois, (7, 7), 1 / 16.0)
+        assert "fwd_quad" in (lib().cdll.sd_last_dispatch() or b"").decode()
+        for g, w, name in zip(got, want, ("output", "maxidx_x", "maxidx_y")):
+            assert torch.equal(g, w), name
+        del got
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [2, 1, 0])
 @pytest.mark.parametrize("case", ["small", "p2_bands", "c4", "mask14", "odd_pool"])
 def test_single_level_backward(ops, oracle, case, variant):
