@@ -185,10 +185,13 @@ int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const 
  *     sd_set_tuning("roi_align_bwd_fx", 0)
  * (packed arg-max and float arg-max planes alike) at ~1.2-1.5 x the time; the sums then depend on the order
  * in which the hardware serves the adds, like the reference's.
- *   EXCEPTION: sd_roi_align_v2_bwd on a single map with C % 4 == 0 whose four planes fit 72 KB of LDS
- * (the C4 family) runs roi_align_bwd_flt4_kernel by default, which already sums with fp32
- * compare-and-swap adds in hardware order: fp32-relative accuracy, NOT bit-reproducible run to run.
- * sd_set_tuning("roi_align_bwd_flt4", 0) selects the banded fixed-point kernel there too. */
+ *   sd_roi_align_v2_bwd on a single map with C % 4 == 0 whose four planes fit 72 KB of LDS (the C4
+ * family) runs roi_align_bwd_flt4_kernel (four whole planes per workgroup).  Since round 5 it sums in
+ * the same 32-bit fixed point, scaled by max|dY| of the workgroup x a per-PIXEL weight bound taken from
+ * the RoIs' footprints (so `rois` must be the boxes the arg-max planes were produced with, as they are
+ * in the operator): bit-reproducible, 4.5e-5 from the exact sums for dY ~ N(0,1) at the C4 shape; the
+ * same fall-backs and the same sd_set_tuning("roi_align_bwd_fx", 0) as above.
+ * sd_set_tuning("roi_align_bwd_flt4", 0) selects the banded kernel there. */
 /* The same with a device workspace of sd_fpn_roi_align_bwd_workspace_bytes(): the per-band RoI
  * lists are then built by one small pre-pass instead of by every channel's workgroup (same
  * results bit for bit).  workspace may be NULL (= the call above). */
