@@ -27,6 +27,7 @@ struct PoolArgs {
   float* maxidx;
   int B, C, H, W, K, PH, PW;
   float scale;
+  int ablate;  // (profiling build: 1 no scan, 2 no output stores)
 };
 
 __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(PoolArgs a) {
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(T) void roi_pool_fwd_plane_kernel(PoolArgs a) {
       const int* e = tab + ES * ri;
       const long obase = ((long)__builtin_amdgcn_readfirstlane(e[0]) * a.C + c) * PP;
       const bool valid = __builtin_amdgcn_readfirstlane(e[1]) != 0;
-      const int hext = __builtin_amdgcn_readfirstlane(e[2]), wext = __builtin_amdgcn_readfirstlane(e[3]);
+      const int hext = SD_ABLATE(a, 1) ? 0 : __builtin_amdgcn_readfirstlane(e[2]), wext = __builtin_amdgcn_readfirstlane(e[3]);
       for (int bin0 = 0; bin0 < PP; bin0 += kWave) {
         const int bin = bin0 + lane;
         const bool active = bin < PP;
@@ -240,8 +241,12 @@ __global__ __launch_bounds__(T) void roi_pool_fwd_plane_kernel(PoolArgs a) {
           if (lane * 4 < CC * PP) {
             const float4 o = *reinterpret_cast<const float4*>(stage + lane * 4);
             const float4 m = *reinterpret_cast<const float4*>(stage + RUN + lane * 4);
-            *reinterpret_cast<float4*>(a.out + obase + lane * 4) = o;
-            *reinterpret_cast<float4*>(a.maxidx + obase + lane * 4) = m;
+            if (!(SD_ABLATE(a, 2))) {
+              *reinterpret_cast<float4*>(a.out + obase + lane * 4) = o;
+              *reinterpret_cast<float4*>(a.maxidx + obase + lane * 4) = m;
+            } else if (o.x == 12345.678f && m.x == 4.5f) {
+              a.out[0] = 0.f;
+            }
           }
         } else if (active) {
 #pragma unroll
@@ -371,7 +376,7 @@ extern "C" int sd_roi_pool_v1_fwd(const float* data, const float* rois, float* o
   SD_REQUIRE((long)H * W < (1L << 24), "plane too large for a float argmax index");
   if ((long)K * C == 0) return SD_OK;
   SD_REQUIRE(data && rois && out && maxidx, "null tensor pointer");
-  PoolArgs a{data, rois, out, maxidx, B, C, H, W, K, pooled_h, pooled_w, spatial_scale};
+  PoolArgs a{data, rois, out, maxidx, B, C, H, W, K, pooled_h, pooled_w, spatial_scale, SD_PROF_TUNING("roi_pool_fwd_ablate", 0)};
   const size_t lds = (size_t)((((long)H * W + 3) & ~3L) + kPoolChunk * (4 + pooled_h + pooled_w)) * 4;
   // four planes + tables + per-wave staging rows (7x7 only), one workgroup of 1024 lanes per CU
   const size_t lds4 = (size_t)((long)H * W * 4 + ((kPoolChunk * (4 + 7 + 7) + 3) & ~3) + 16 * 2 * 196) * 4;

@@ -55,6 +55,7 @@ Knob g_knobs[] = {
 #ifdef SD_PROFILING
     // ---- profiling build only (tools/libsimpledet_ops_hip_prof.so): results are WRONG when != 0 ----
     {"roi_align_fwd_ablate", 0, false},
+    {"roi_pool_fwd_ablate", 0, false},
     {"roi_align_bwd_ablate", 0, false},
     {"roi_align_dbg_lo", 0, false},      // device buffer for per-wave phase clocks
     {"roi_align_dbg_hi", 0, false},
