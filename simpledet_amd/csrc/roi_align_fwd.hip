@@ -1123,50 +1123,60 @@ __global__ __launch_bounds__(512) void roi_align_fwd_quad(BandArgs A) {
   }
   if (tid == 0) pl[HW] = make_float4(0.f, 0.f, 0.f, 0.f);   // the "right" tap read beside the last pixel (weight 0 or replaced)
   __syncthreads();
+  // lanes 49..63 repeat lane 48's work (same entries, same values, same addresses): every LDS and global store below is
+  // issued by all 64 lanes, no branch around any of them
   const bool act = lane < PPG;
-  const int bin = act ? lane : 0, pp = bin / POOL, q = bin - pp * POOL;
-  // the table entries of a RoI are fetched one trip ahead (the output pointers may alias anything as far as
-  // the compiler knows: behind the stores of a trip the loads of the next would start only then)
+  const int bin = act ? lane : PPG - 1, pp = bin / POOL, q = bin - pp * POOL;
+  // A software pipeline over the wave's RoIs, built around vmcnt: it counts loads and stores in order, so a wait for
+  // table entries is also a wait for every store issued before their loads.  Per trip: (1) the loads of the NEXT
+  // RoI's entries go out, (2) the three 784-byte stores of the PREVIOUS RoI's outputs go out behind them, (3) this
+  // RoI is computed, (4) `touch` waits for the entries with exactly those three stores still in flight --
+  // s_waitcnt vmcnt(3), which the compiler can only emit because every trip issues the same memory operations: the
+  // loads are unconditional (clamped RoI index), flagged RoIs store constants and the few that need
+  // roi_align_fwd_elem are redone by a second walk, the first trip "stores" its own RoI's rows (overwritten by the
+  // real values a trip later: same wave, same addresses, in order).  With the stores of a trip waited for at the next
+  // loop head (vmcnt(0)) compute and stores added up: 0.07 + 0.095 ms (`profiles/r05r_*`).
   struct Ent { uint4 re, ce; float2 rv, cv; int flag; };
   auto load_ent = [&](int n, Ent& e) {
-    e.flag = 2;
-    e.re = e.ce = make_uint4(0, 0, 0, 0);
-    e.rv = e.cv = make_float2(0.f, 0.f);
-    if (n < a.R) {
-      const long roi = (long)img * a.R + n;
-      e.flag = P.fbflag[roi];
-      e.re = P.rowent[roi * POOL + pp];
-      e.ce = P.colent[roi * POOL + q];
-      e.rv = P.rowval[roi * POOL + pp];
-      e.cv = P.colval[roi * POOL + q];
-    }
+    const long roi = (long)img * a.R + (n < a.R ? n : a.R - 1);
+    e.flag = P.fbflag[roi];
+    e.re = P.rowent[roi * POOL + pp];
+    e.ce = P.colent[roi * POOL + q];
+    e.rv = P.rowval[roi * POOL + pp];
+    e.cv = P.colval[roi * POOL + q];
+  };
+  auto touch = [](Ent& e) {
+    asm volatile("" : "+v"(e.re.x), "+v"(e.re.y), "+v"(e.re.z), "+v"(e.re.w), "+v"(e.ce.x), "+v"(e.ce.y), "+v"(e.ce.z),
+                 "+v"(e.ce.w), "+v"(e.rv.x), "+v"(e.rv.y), "+v"(e.cv.x), "+v"(e.cv.y), "+v"(e.flag));
+  };
+  // [channel][bin] through the wave's LDS row, then 16 bytes per lane = the 784-byte run of (RoI, c .. c + 3)
+  const int lane_c = act ? lane : PPG - 1;
+  auto put = [&](const float (&v)[4], float* dst, long ob) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st[k * PPG + bin] = v[k];
+    *reinterpret_cast<float4*>(dst + ob + 4 * lane_c) = *reinterpret_cast<const float4*>(st + 4 * lane_c);
   };
   Ent cur;
   load_ent(wave, cur);
+  float pv[4] = {0.f, 0.f, 0.f, 0.f}, px[4] = {-1.f, -1.f, -1.f, -1.f}, py[4] = {-1.f, -1.f, -1.f, -1.f};
+  long pob = (((long)img * a.R + (wave < a.R ? wave : 0)) * a.C + c) * PPG;   // (first trip: this wave's own first RoI)
   for (int n = wave; n < a.R; n += NW) {
     const long roi = (long)img * a.R + n;
     const int flag = __builtin_amdgcn_readfirstlane(cur.flag);
     const uint4 re = cur.re, ce = cur.ce;
     const float2 rv = cur.rv, cv = cur.cv;
-    load_ent(n + NW, cur);
-    const long ob = (roi * a.C + c) * PPG;
-    if (flag) {
-      // exact per-element path (a handful of RoIs) / constant output: element stores
-      const float4 bx = *reinterpret_cast<const float4*>(a.rois + roi * 4);
-#pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        FwdOut o{0.f, -1.f, -1.f, 255};
-        if (flag == 1 && act) o = roi_align_fwd_elem(src + (long)k * HW, H, W, bx.x, bx.y, bx.z, bx.w, a.L.scale[0], pp, q, POOL, POOL);
-        if (act) {
-          a.out[ob + k * PPG + bin] = o.val;
-          a.ax[ob + k * PPG + bin] = o.ax;
-          a.ay[ob + k * PPG + bin] = o.ay;
-        }
-      }
-      continue;
+    Ent nxt;
+    load_ent(n + NW, nxt);
+    if (!(SD_ABLATE(a, 128))) put(pv, a.out, pob);   // (profiling build: 128 no value stores, 256 no arg-max stores)
+    if (!(SD_ABLATE(a, 256))) {
+      put(px, a.ax, pob);
+      put(py, a.ay, pob);
     }
     float maxval[4], bx_[4], by_[4];
-    {
+    if (flag) {   // nothing pooled (flag 2): the constant; flag 1 is redone below
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { maxval[k] = 0.f; bx_[k] = -1.f; by_[k] = -1.f; }
+    } else {
       const int lo0 = (int)(re.x & 0xfffff), lo1 = (int)(re.y & 0xfffff);
       const int hi0 = lo0 + ((re.x >> 20) & 1 ? W : 0), hi1 = lo1 + ((re.y >> 20) & 1 ? W : 0);
       const int left0 = ce.x & 0xfff, left1 = (ce.x >> 13) & 0xfff;
@@ -1199,18 +1209,33 @@ __global__ __launch_bounds__(512) void roi_align_fwd_quad(BandArgs A) {
       sample(lo1, hi1, left0, right0, wl10, wh10, cv.x, rv.y);
       sample(lo1, hi1, left1, right1, wl11, wh11, cv.y, rv.y);
     }
-    // [channel][bin] through the wave's LDS row, then 49 lanes x 16 bytes = the 784-byte run of (RoI, c .. c + 3)
-    auto put = [&](const float (&v)[4], float* dst) {
-      if (act) {
+    touch(nxt);
+    cur = nxt;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) st[k * PPG + bin] = v[k];
-        *reinterpret_cast<float4*>(dst + ob + 4 * lane) = *reinterpret_cast<const float4*>(st + 4 * lane);
-      }
-    };
-    if (!(SD_ABLATE(a, 128))) put(maxval, a.out);   // (profiling build: 128 no value stores, 256 no arg-max stores)
+    for (int k = 0; k < 4; ++k) { pv[k] = maxval[k]; px[k] = bx_[k]; py[k] = by_[k]; }
+    pob = (roi * a.C + c) * PPG;
+  }
+  if (wave < a.R) {   // the last RoI's outputs
+    if (!(SD_ABLATE(a, 128))) put(pv, a.out, pob);
     if (!(SD_ABLATE(a, 256))) {
-      put(bx_, a.ax);
-      put(by_, a.ay);
+      put(px, a.ax, pob);
+      put(py, a.ay, pob);
+    }
+  }
+  // the RoIs of the exact per-element path (three-sample bins: a handful per launch): element stores over the
+  // constants written above (same wave, same addresses, in order)
+  for (int n = wave; n < a.R; n += NW) {
+    const long roi = (long)img * a.R + n;
+    if (P.fbflag[roi] != 1) continue;
+    const float4 bx = *reinterpret_cast<const float4*>(a.rois + roi * 4);
+    const long ob = (roi * a.C + c) * PPG;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      if (!act) continue;
+      const FwdOut o = roi_align_fwd_elem(src + (long)k * HW, H, W, bx.x, bx.y, bx.z, bx.w, a.L.scale[0], pp, q, POOL, POOL);
+      a.out[ob + k * PPG + bin] = o.val;
+      a.ax[ob + k * PPG + bin] = o.ax;
+      a.ay[ob + k * PPG + bin] = o.ay;
     }
   }
 }
