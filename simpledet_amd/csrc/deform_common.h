@@ -21,6 +21,7 @@ struct Sample {
   bool ok;
   int h_low, w_low, h_high, w_high;
   float w1, w2, w3, w4;
+  float lh, lw;   // the fractions the four weights are products of: w1 = (1 - lh)(1 - lw), w2 = (1 - lh) lw, w3 = lh (1 - lw), w4 = lh lw
 };
 
 __device__ __forceinline__ Sample im2col_sample(const DcnGeom& g, int h_in, int w_in, int i, int j,
@@ -47,6 +48,7 @@ __device__ __forceinline__ Sample im2col_sample(const DcnGeom& g, int h_in, int 
   }
   const float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
   s.w1 = hh * hw; s.w2 = hh * lw; s.w3 = lh * hw; s.w4 = lh * lw;
+  s.lh = lh; s.lw = lw;
   s.h_low = h_low + h_in; s.h_high = h_high + h_in;  // absolute rows / columns
   s.w_low = w_low + w_in; s.w_high = w_high + w_in;
   return s;

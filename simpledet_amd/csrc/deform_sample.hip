@@ -615,6 +615,88 @@ void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restri
   }
 }
 
+// The same kernel as a software pipeline around vmcnt (round 5; 3x3 taps, 16-byte windows).  vmcnt counts loads
+// and stores in order: in the loop above the wait for a channel's window loads is also a wait for the previous
+// channel's nine col stores per lane (2.3 KB per wave on their way to HBM), on every one of the 64 channels.
+// Here the col values of a channel stay in registers for one trip: per channel (1) the window loads go out,
+// (2) the PREVIOUS channel's nine stores go out behind them, (3) the loads are waited for with exactly those nine
+// in flight (s_waitcnt vmcnt(9): every trip issues the same memory operations -- lanes past the last pixel repeat
+// the last pixel's work, the first trip stores zeros to the rows the second overwrites), (4) window -> LDS,
+// barrier, the nine values of this channel.  To make room for the nine pending values and two window words the
+// four bilinear weights of a tap are kept as their two fractions and multiplied out per channel (the same
+// products in the same order: the same bits).
+template <int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                               float* __restrict__ col, DcnGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  constexpr int K2 = 9;
+  const int P = g.Ho * g.Wo, plane = g.H * g.W;
+  const int tid = threadIdx.x;
+  const int p = iminr(blockIdx.x * T + tid, P - 1);   // (lanes past the last pixel: the last pixel again)
+  const int grp = blockIdx.y, n = blockIdx.z;
+  const int cpg = g.C / g.dgroup;
+  int info[kDcnMaxTaps];
+  float lh[K2], lw[K2];
+  {
+    const int h_col = p / g.Wo, w_col = p % g.Wo;
+    const int h_in = h_col * g.stride_h - g.pad_h, w_in = w_col * g.stride_w - g.pad_w;
+    const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P + p;
+    float oh[K2], ow[K2];
+#pragma unroll
+    for (int tap = 0; tap < K2; ++tap) {  // all offset loads in flight together
+      oh[tap] = off[(long)(2 * tap) * P];
+      ow[tap] = off[(long)(2 * tap + 1) * P];
+    }
+#pragma unroll
+    for (int tap = 0; tap < K2; ++tap) {
+      const Sample s = im2col_sample(g, h_in, w_in, tap / 3, tap % 3, oh[tap], ow[tap]);
+      info[tap] = dcn_pack(s.ok, s.h_low, s.w_low, s.h_high, s.w_high, g.W);
+      lh[tap] = s.lh; lw[tap] = s.lw;
+      __builtin_amdgcn_sched_barrier(0);  // one tap's temporaries at a time (register pressure)
+    }
+  }
+  int wstart, wcount;
+  dcn_window(info, g.W, plane, 1, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart, wcount);
+  const int n4 = wcount >> 2, last4 = n4 > 0 ? n4 - 1 : 0;
+  float val[K2];
+#pragma unroll
+  for (int tap = 0; tap < K2; ++tap) val[tap] = 0.f;
+  const long ch0 = (long)n * g.C + (long)grp * cpg;
+  for (int c = 0; c < cpg; ++c) {
+    const long ch = ch0 + c;
+    // rows of the channel whose values are pending (wave-uniform base + 32-bit lane offset); first trip: its own
+    float* out = col + (ch0 + (c > 0 ? c - 1 : 0)) * K2 * P;
+    __syncthreads();  // the previous channel's readers are done
+    const float4* s4 = reinterpret_cast<const float4*>(x + ch * plane + wstart);
+    float4 r0 = s4[iminr(tid, last4)], r1 = s4[iminr(tid + T, last4)];
+#pragma unroll
+    for (int tap = 0; tap < K2; ++tap) __builtin_nontemporal_store(val[tap], out + (tap * P + p));
+    asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+    float4* d4 = reinterpret_cast<float4*>(xs);
+    if (tid < n4) d4[tid] = r0;
+    if (tid + T < n4) d4[tid + T] = r1;
+    for (int i = tid + 2 * T; i < n4; i += T) d4[i] = s4[i];   // windows beyond 2 T x 16 bytes (wide offsets)
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < K2; ++tap) {
+      asm volatile("" : "+v"(info[tap]), "+v"(lh[tap]), "+v"(lw[tap]));  // keep the unpacking and the products inside the loop (registers)
+      const int in = info[tap];
+      const Corners q = dcn_corners(xs, in, g.W);
+      const float hh = 1 - lh[tap], hw = 1 - lw[tap];
+      const float w1 = hh * hw, w2 = hh * lw[tap], w3 = lh[tap] * hw, w4 = lh[tap] * lw[tap];
+      float v = (w1 * q.x1 + w2 * q.x2 + w3 * q.x3 + w4 * q.x4);
+      if (!(in & kDcnInside)) v = 0.f;
+      val[tap] = v;
+    }
+  }
+  {
+    float* out = col + (ch0 + cpg - 1) * K2 * P;
+#pragma unroll
+    for (int tap = 0; tap < K2; ++tap) __builtin_nontemporal_store(val[tap], out + (tap * P + p));
+  }
+}
+
 // Offset gradient with the same ownership: both directions of a tap share the four corner values,
 // the sum over the group's channels runs in registers in ascending channel order (as the per-lane
 // kernel and the reference do).  grid: x = pixel tiles, y = group, z = image
@@ -776,7 +858,11 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
     const int nt = 1 | (SD_PROF_TUNING("dcn_im2col_nt", 1) & 6);
     // (channel splits per (image, group, pixel tile): 2-8 measured in round 3, no gain -- one)
     const int nsplit = 1;
-    if (kh * kw == 9)
+    if (kh * kw == 9 && kw == 3 && vec == 1 && nt == 1 && C / dgroup >= 2 && tuning("dcn_im2col", 1) == 1 &&
+        tuning("dcn_im2col_pipe", 1) == 1)
+      hipLaunchKernelGGL((deform_im2col_pipe_kernel<T>), dim3(cdiv(P, T), dgroup, N), dim3(T), lds,
+                         (hipStream_t)stream, x, offset, col, g);
+    else if (kh * kw == 9)
       hipLaunchKernelGGL((deform_im2col_lds_kernel<T, 9>), dim3(cdiv(P, T), dgroup * nsplit, N),
                          dim3(T), lds, (hipStream_t)stream, x, offset, col, g, nsplit, vec, nt);
     else

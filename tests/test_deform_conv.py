@@ -143,7 +143,8 @@ def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
 def test_sampling_kernel_families_give_the_same_bits(ops, cfg):
     """deformable im2col and the offset gradient in their two forms -- LDS windows (`dcn_im2col` / `dcn_coord` = 1,
     the default) and per-lane global gathers (= 0, the reference's structure): same expressions in the same
-    channel order, so the same bits; also with whole planes staged instead of windows (`dcn_window` = 0)."""
+    channel order, so the same bits; also with whole planes staged instead of windows (`dcn_window` = 0) and with
+    im2col's stores in place (`dcn_im2col_pipe` = 0: the default stores a channel's values one trip later)."""
     import torch
     from simpledet_amd._lib import lib
     x, off, w, kw = _case(11, **cfg)
@@ -163,11 +164,15 @@ def test_sampling_kernel_families_give_the_same_bits(ops, cfg):
             lib().set_tuning(k, 1)
         lib().set_tuning("dcn_window", 0)
         res["whole"] = (ops.deform_im2col(tx, to, **a), ops.deform_col2im_coord(g, tx, to, **a))
+        lib().set_tuning("dcn_window", 1)
+        lib().set_tuning("dcn_im2col_pipe", 0)   # col stores in place instead of one channel behind the window loads
+        res["inplace"] = (ops.deform_im2col(tx, to, **a), res[1][1])
     finally:
         lib().set_tuning("dcn_window", 1)
+        lib().set_tuning("dcn_im2col_pipe", 1)
         for k in ("dcn_im2col", "dcn_coord"):
             lib().set_tuning(k, 1)
-    for key in (0, "whole"):
+    for key in (0, "whole", "inplace"):
         assert torch.equal(res[1][0], res[key][0]), ("im2col", key)
         assert torch.equal(res[1][1], res[key][1]), ("col2im_coord", key)   # same products, same channel order
 
