@@ -617,14 +617,14 @@ void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restri
 
 // The same kernel as a software pipeline around vmcnt (round 5; 3x3 taps, 16-byte windows).  vmcnt counts loads
 // and stores in order: in the loop above the wait for a channel's window loads is also a wait for the previous
-// channel's nine col stores per lane (2.3 KB per wave on their way to HBM), on every one of the 64 channels.
-// Here the col values of a channel stay in registers for one trip: per channel (1) the window loads go out,
-// (2) the PREVIOUS channel's nine stores go out behind them, (3) the loads are waited for with exactly those nine
-// in flight (s_waitcnt vmcnt(9): every trip issues the same memory operations -- lanes past the last pixel repeat
-// the last pixel's work, the first trip stores zeros to the rows the second overwrites), (4) window -> LDS,
-// barrier, the nine values of this channel.  To make room for the nine pending values and two window words the
-// four bilinear weights of a tap are kept as their two fractions and multiplied out per channel (the same
-// products in the same order: the same bits).
+// channel's nine col stores per lane (2.3 KB per wave on their way to HBM), on every one of the 64 channels, and
+// the loads themselves sit between two barriers with nothing to hide them.  Here the NEXT channel's window loads
+// go out before this channel's values are computed and stored, and are waited for behind the nine stores with
+// exactly those nine in flight (s_waitcnt vmcnt(9): every trip issues the same memory operations -- lanes past
+// the last pixel repeat the last pixel's work, the last trip reloads its own window): the load latency hides
+// behind the sampling, the stores are never waited for.  To make room for the two window words per lane the four
+// bilinear weights of a tap are kept as their two fractions and multiplied out per channel (the same products in
+// the same order: the same bits).
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restrict__ offset,
@@ -659,25 +659,25 @@ void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restr
   int wstart, wcount;
   dcn_window(info, g.W, plane, 1, reinterpret_cast<int*>(xs + plane + g.W + 4), tid, wstart, wcount);
   const int n4 = wcount >> 2, last4 = n4 > 0 ? n4 - 1 : 0;
-  float val[K2];
-#pragma unroll
-  for (int tap = 0; tap < K2; ++tap) val[tap] = 0.f;
   const long ch0 = (long)n * g.C + (long)grp * cpg;
-  for (int c = 0; c < cpg; ++c) {
-    const long ch = ch0 + c;
-    // rows of the channel whose values are pending (wave-uniform base + 32-bit lane offset); first trip: its own
-    float* out = col + (ch0 + (c > 0 ? c - 1 : 0)) * K2 * P;
-    __syncthreads();  // the previous channel's readers are done
-    const float4* s4 = reinterpret_cast<const float4*>(x + ch * plane + wstart);
-    float4 r0 = s4[iminr(tid, last4)], r1 = s4[iminr(tid + T, last4)];
-#pragma unroll
-    for (int tap = 0; tap < K2; ++tap) __builtin_nontemporal_store(val[tap], out + (tap * P + p));
-    asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
-    float4* d4 = reinterpret_cast<float4*>(xs);
+  float4* d4 = reinterpret_cast<float4*>(xs);
+  auto window_to_lds = [&](const float4& r0, const float4& r1, const float4* s4) {
     if (tid < n4) d4[tid] = r0;
     if (tid + T < n4) d4[tid + T] = r1;
     for (int i = tid + 2 * T; i < n4; i += T) d4[i] = s4[i];   // windows beyond 2 T x 16 bytes (wide offsets)
-    __syncthreads();
+  };
+  {
+    const float4* s4 = reinterpret_cast<const float4*>(x + ch0 * plane + wstart);
+    const float4 r0 = s4[iminr(tid, last4)], r1 = s4[iminr(tid + T, last4)];
+    window_to_lds(r0, r1, s4);
+  }
+  for (int c = 0; c < cpg; ++c) {
+    const long ch = ch0 + c;
+    __syncthreads();  // this channel's window is in LDS
+    // the NEXT channel's window loads go out first (the last trip reloads its own: same instruction count)
+    const float4* s4 = reinterpret_cast<const float4*>(x + (ch0 + (c + 1 < cpg ? c + 1 : c)) * plane + wstart);
+    float4 r0 = s4[iminr(tid, last4)], r1 = s4[iminr(tid + T, last4)];
+    float* out = col + ch * K2 * P;   // wave-uniform base + 32-bit lane offset
 #pragma unroll
     for (int tap = 0; tap < K2; ++tap) {
       asm volatile("" : "+v"(info[tap]), "+v"(lh[tap]), "+v"(lw[tap]));  // keep the unpacking and the products inside the loop (registers)
@@ -687,13 +687,12 @@ void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restr
       const float w1 = hh * hw, w2 = hh * lw[tap], w3 = lh[tap] * hw, w4 = lh[tap] * lw[tap];
       float v = (w1 * q.x1 + w2 * q.x2 + w3 * q.x3 + w4 * q.x4);
       if (!(in & kDcnInside)) v = 0.f;
-      val[tap] = v;
+      __builtin_nontemporal_store(v, out + (tap * P + p));
     }
-  }
-  {
-    float* out = col + (ch0 + cpg - 1) * K2 * P;
-#pragma unroll
-    for (int tap = 0; tap < K2; ++tap) __builtin_nontemporal_store(val[tap], out + (tap * P + p));
+    // the window loads, with this channel's nine stores still in flight: s_waitcnt vmcnt(9)
+    asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+    __syncthreads();  // everybody has read this channel's window
+    window_to_lds(r0, r1, s4);
   }
 }
 
