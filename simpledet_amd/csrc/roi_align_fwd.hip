@@ -1111,15 +1111,20 @@ __global__ __launch_bounds__(512) void roi_align_fwd_quad(BandArgs A) {
   float4* pl = reinterpret_cast<float4*>(band_smem);
   float* st = band_smem + 4 * (HW + 1) + wave * (4 * PPG);   // this wave's 784 bytes
   const float* src = reinterpret_cast<const float*>(a.L.data[0]) + ((long)img * a.C + c) * HW;
-  for (int i4 = tid; i4 < (HW >> 2); i4 += T) {
-    const float4 v0 = *reinterpret_cast<const float4*>(src + 4 * i4);
-    const float4 v1 = *reinterpret_cast<const float4*>(src + (long)HW + 4 * i4);
-    const float4 v2 = *reinterpret_cast<const float4*>(src + 2L * HW + 4 * i4);
-    const float4 v3 = *reinterpret_cast<const float4*>(src + 3L * HW + 4 * i4);
-    pl[4 * i4 + 0] = make_float4(v0.x, v1.x, v2.x, v3.x);
-    pl[4 * i4 + 1] = make_float4(v0.y, v1.y, v2.y, v3.y);
-    pl[4 * i4 + 2] = make_float4(v0.z, v1.z, v2.z, v3.z);
-    pl[4 * i4 + 3] = make_float4(v0.w, v1.w, v2.w, v3.w);
+  if ((HW & 3) == 0) {
+    for (int i4 = tid; i4 < (HW >> 2); i4 += T) {
+      const float4 v0 = *reinterpret_cast<const float4*>(src + 4 * i4);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + (long)HW + 4 * i4);
+      const float4 v2 = *reinterpret_cast<const float4*>(src + 2L * HW + 4 * i4);
+      const float4 v3 = *reinterpret_cast<const float4*>(src + 3L * HW + 4 * i4);
+      pl[4 * i4 + 0] = make_float4(v0.x, v1.x, v2.x, v3.x);
+      pl[4 * i4 + 1] = make_float4(v0.y, v1.y, v2.y, v3.y);
+      pl[4 * i4 + 2] = make_float4(v0.z, v1.z, v2.z, v3.z);
+      pl[4 * i4 + 3] = make_float4(v0.w, v1.w, v2.w, v3.w);
+    }
+  } else {   // planes that are not whole 16-byte words (P5 of 800 x 1333: 25 x 42): element loads
+    for (int i = tid; i < HW; i += T)
+      pl[i] = make_float4(src[i], src[(long)HW + i], src[2L * HW + i], src[3L * HW + i]);
   }
   if (tid == 0) pl[HW] = make_float4(0.f, 0.f, 0.f, 0.f);   // the "right" tap read beside the last pixel (weight 0 or replaced)
   __syncthreads();
@@ -1424,7 +1429,7 @@ int launch_fwd(FwdArgs& a, hipStream_t st, void* workspace, size_t workspace_byt
         const long HW0 = (long)a.L.H[0] * a.L.W[0];
         const size_t lds = (size_t)(HW0 + 1) * 16 + 8 * 4 * 49 * sizeof(float);
         if (!a.amax8 && !a.half_io && POOL == 7 && a.L.nlvl == 1 && a.L.stride[0] >= 0 && P.nbands[0] == 1 &&
-            a.C % 4 == 0 && HW0 % 4 == 0 && lds <= 78 * 1024 && a.B <= 65535 &&
+            a.C % 4 == 0 && lds <= 78 * 1024 && a.B <= 65535 &&
             (((uintptr_t)a.L.data[0] | (uintptr_t)a.out | (uintptr_t)a.ax | (uintptr_t)a.ay) & 15) == 0 &&
             tuning("roi_align_fwd_quad", 1) == 1) {
           SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_align_fwd_quad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -142,7 +142,7 @@ def _fwd_path(path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["band", "naive", "tiled"])
-@pytest.mark.parametrize("case", ["small", "c4", "p2", "mask14", "odd_pool"])
+@pytest.mark.parametrize("case", ["small", "c4", "p5", "p2", "mask14", "odd_pool"])
 def test_single_level_forward_bit_exact(ops, oracle, case, variant):
     from simpledet_amd._lib import lib
     _fwd_path(variant)
@@ -154,6 +154,10 @@ def test_single_level_forward_bit_exact(ops, oracle, case, variant):
             data = synth.feature_maps(1, 2, 64, ((50, 84),))[0]
             rois = synth.random_rois(1, 2, 128)
             pooled, scale = (7, 7), 1 / 16.0
+        elif case == "p5":   # a plane that is not whole 16-byte words (25 x 42): the whole-plane kernel's element fill
+            data = synth.feature_maps(5, 2, 8, ((25, 42),))[0]
+            rois = synth.random_rois(5, 2, 96)
+            pooled, scale = (7, 7), 1 / 32.0
         elif case == "p2":   # large RoIs on the finest level: sparse sample grid
             data = synth.feature_maps(2, 1, 16, ((200, 334),))[0]
             rois = synth.random_rois(2, 1, 96)
@@ -290,6 +294,8 @@ def test_c4_backward_fixed_point_planes(ops, oracle, case):
     # (and with the sums themselves -- gradient sums reach ~30 in the other cases, hundreds when 512 RoIs coincide:
     # there the float adds in another order than the oracle's differ by more)
     tol = 1e-4 * max(1.0, gmax / 5.0, float(np.abs(want[fin]).max()) / 30.0)
+    if case == "piled":   # 25,088 float adds per pixel in hardware order against the oracle's order: fp32-relative only
+        tol = 3e-5 * float(np.abs(want[fin]).max())
     assert float(np.abs(g[fin] - want[fin]).max()) <= tol
     assert float(np.abs(f[fin] - want[fin]).max()) <= tol
 
