@@ -301,6 +301,32 @@ def test_c4_backward_fixed_point_planes(ops, oracle, case):
 
 
 @pytest.mark.gpu
+def test_c4_backward_full_size_properties(ops):
+    """The C4 backward at BASELINE's full size (2,1024,50,84) x 512 RoIs/img, through properties that need no oracle:
+    run-to-run bit equality (integer sums), exact homogeneity for powers of two (the unit scales with max|dY|, so
+    the same integers are added), additivity within the fixed-point unit, and conservation -- the four bilinear
+    weights of a bin sum to one, so sum(dX) = sum of dY over the bins that pooled something."""
+    import torch
+    data = torch.randn((2, 1024, 50, 84), device="cuda")
+    rois = _t(synth.random_rois(31, 2, 512))
+    o, ax, ay = ops.roi_align_v2_forward(data, rois, (7, 7), 1 / 16.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dy1 = torch.randn(o.shape, device="cuda", generator=g)
+    dy2 = torch.randn(o.shape, device="cuda", generator=g)
+    bwd = lambda dy: ops.roi_align_v2_backward(dy, rois, ax, ay, tuple(data.shape), 1 / 16.0)[0]
+    d1 = bwd(dy1)
+    assert torch.equal(d1, bwd(dy1))
+    assert torch.equal(bwd(dy1 * 4.0), d1 * 4.0) and torch.equal(bwd(dy1 * 0.125), d1 * 0.125)
+    d2, d12 = bwd(dy2), bwd(dy1 + dy2)
+    # one unit is <= 2 max|dY| x bound x 2^-30 (bound <= 2048): additivity holds to a few hundred units
+    assert float((d12 - (d1 + d2)).abs().max()) <= 1e-3
+    pooled = (ax != -1) & (ay != -1)
+    want = float((dy1.double() * pooled).sum())
+    got = float(d1.double().sum())
+    assert abs(got - want) <= 1e-6 * float(dy1.double().abs().sum())
+
+
+@pytest.mark.gpu
 def test_backward_rejects_write_inplace(ops):
     import torch
     from simpledet_amd._lib import SimpleDetOpsError
