@@ -619,10 +619,10 @@ void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restri
 // and stores in order: in the loop above the wait for a channel's window loads is also a wait for the previous
 // channel's nine col stores per lane (2.3 KB per wave on their way to HBM), on every one of the 64 channels, and
 // the loads themselves sit between two barriers with nothing to hide them.  Here the NEXT channel's window loads
-// go out before this channel's values are computed and stored, and are waited for behind the nine stores with
-// exactly those nine in flight (s_waitcnt vmcnt(9): every trip issues the same memory operations -- lanes past
-// the last pixel repeat the last pixel's work, the last trip reloads its own window): the load latency hides
-// behind the sampling, the stores are never waited for.  To make room for the two window words per lane the four
+// go out before this channel's values are computed and stored, and are waited for behind the stores with
+// exactly those in flight (s_waitcnt vmcnt(3): every trip issues the same memory operations -- every wave
+// writes three rows, lanes past the last pixel repeat the last pixel's work, the last trip reloads its own
+// window): the load latency hides behind the sampling, the stores are never waited for.  To make room for the two window words per lane the four
 // bilinear weights of a tap are kept as their two fractions and multiplied out per channel (the same products in
 // the same order: the same bits).
 template <int T>
@@ -632,10 +632,19 @@ void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restr
   extern __shared__ __attribute__((aligned(16))) float xs[];
   constexpr int K2 = 9;
   const int P = g.Ho * g.Wo, plane = g.H * g.W;
-  const int tid = threadIdx.x;
-  const int p = iminr(blockIdx.x * T + tid, P - 1);   // (lanes past the last pixel: the last pixel again)
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int p0 = blockIdx.x * T;
+  const int p = iminr(p0 + tid, P - 1);   // (lanes past the last pixel: the last pixel again)
   const int grp = blockIdx.y, n = blockIdx.z;
   const int cpg = g.C / g.dgroup;
+  // The col values leave as WHOLE tile rows: a tap's T values are T * 4 contiguous bytes of col, staged in LDS
+  // ([tap][pixel]) and written behind the barrier that ends the sampling by ONE wave as 16 bytes per lane -- 1 KB
+  // pieces instead of four 256-byte ones (written as 256-byte pieces the 620 MB move at 2.7 TB/s, whatever the
+  // bytes per lane: `profiles/r05u_*`).  Every wave writes exactly three rows (T / 64 = 4 waves, 9 taps: wave w
+  // writes taps 2 w and 2 w + 1 and its own quarter of tap 8), so the count of stores per trip stays static.
+  static_assert(T == 256, "store schedule: four waves, nine taps");
+  float* stg = xs + plane + g.W + 8;   // [K2][T]
   int info[kDcnMaxTaps];
   float lh[K2], lw[K2];
   {
@@ -671,13 +680,25 @@ void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restr
     const float4 r0 = s4[iminr(tid, last4)], r1 = s4[iminr(tid + T, last4)];
     window_to_lds(r0, r1, s4);
   }
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  auto store_rows = [&](float* out) {   // three 16-byte stores per lane; pieces past the last pixel are masked (P % 4 == 0)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int tap = 2 * wave + k;
+      if (p0 + 4 * lane < P)
+        __builtin_nontemporal_store(*reinterpret_cast<const f4v*>(stg + tap * T + 4 * lane),
+                                    reinterpret_cast<f4v*>(out + (tap * P + p0 + 4 * lane)));
+    }
+    if (lane < 16 && p0 + wave * kWave + 4 * lane < P)
+      __builtin_nontemporal_store(*reinterpret_cast<const f4v*>(stg + 8 * T + wave * kWave + 4 * lane),
+                                  reinterpret_cast<f4v*>(out + (8 * P + p0 + wave * kWave + 4 * lane)));
+  };
   for (int c = 0; c < cpg; ++c) {
     const long ch = ch0 + c;
-    __syncthreads();  // this channel's window is in LDS
+    __syncthreads();  // this channel's window is in LDS, the previous channel's rows have left the staging area
     // the NEXT channel's window loads go out first (the last trip reloads its own: same instruction count)
     const float4* s4 = reinterpret_cast<const float4*>(x + (ch0 + (c + 1 < cpg ? c + 1 : c)) * plane + wstart);
     float4 r0 = s4[iminr(tid, last4)], r1 = s4[iminr(tid + T, last4)];
-    float* out = col + ch * K2 * P;   // wave-uniform base + 32-bit lane offset
 #pragma unroll
     for (int tap = 0; tap < K2; ++tap) {
       asm volatile("" : "+v"(info[tap]), "+v"(lh[tap]), "+v"(lw[tap]));  // keep the unpacking and the products inside the loop (registers)
@@ -687,11 +708,12 @@ void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restr
       const float w1 = hh * hw, w2 = hh * lw[tap], w3 = lh[tap] * hw, w4 = lh[tap] * lw[tap];
       float v = (w1 * q.x1 + w2 * q.x2 + w3 * q.x3 + w4 * q.x4);
       if (!(in & kDcnInside)) v = 0.f;
-      __builtin_nontemporal_store(v, out + (tap * P + p));
+      stg[tap * T + tid] = v;
     }
-    // the window loads, with this channel's nine stores still in flight: s_waitcnt vmcnt(9)
+    __syncthreads();  // everybody has read this channel's window and staged its values
+    store_rows(col + ch * K2 * P);   // wave-uniform base + 32-bit lane offset
+    // the window loads, with this channel's three stores still in flight: s_waitcnt vmcnt(3)
     asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
-    __syncthreads();  // everybody has read this channel's window
     window_to_lds(r0, r1, s4);
   }
 }
@@ -857,9 +879,10 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
     const int nt = 1 | (SD_PROF_TUNING("dcn_im2col_nt", 1) & 6);
     // (channel splits per (image, group, pixel tile): 2-8 measured in round 3, no gain -- one)
     const int nsplit = 1;
-    if (kh * kw == 9 && kw == 3 && vec == 1 && nt == 1 && C / dgroup >= 2 && tuning("dcn_im2col", 1) == 1 &&
+    if (kh * kw == 9 && kw == 3 && vec == 1 && nt == 1 && C / dgroup >= 2 && P % 4 == 0 && ((uintptr_t)col & 15) == 0 &&
+        lds + 9 * T * sizeof(float) <= 31 * 1024 && tuning("dcn_im2col", 1) == 1 &&
         tuning("dcn_im2col_pipe", 1) == 1)
-      hipLaunchKernelGGL((deform_im2col_pipe_kernel<T>), dim3(cdiv(P, T), dgroup, N), dim3(T), lds,
+      hipLaunchKernelGGL((deform_im2col_pipe_kernel<T>), dim3(cdiv(P, T), dgroup, N), dim3(T), lds + 9 * T * sizeof(float),
                          (hipStream_t)stream, x, offset, col, g);
     else if (kh * kw == 9)
       hipLaunchKernelGGL((deform_im2col_lds_kernel<T, 9>), dim3(cdiv(P, T), dgroup * nsplit, N),

@@ -47,7 +47,7 @@ Knob g_knobs[] = {
     {"deform_gemm_ksplit", 0, false},    // 1 (default): tiles of a mostly empty last round are cut into k slices (atomic adds)
     {"dcn_im2col", 0, false},            // 1 LDS-plane im2col (default), 0 per-lane global gathers
     {"dcn_window", 0, false},            // 1 stage only the touched range of each plane (default)
-    {"dcn_im2col_pipe", 0, false},       // 1 (default): 3x3 im2col with the col stores one channel behind the window loads (s_waitcnt vmcnt(9)); 0: stores in place
+    {"dcn_im2col_pipe", 0, false},       // 1 (default): 3x3 im2col with the next window loads before this channel is sampled, col rows stored as 1 KB pieces behind them (s_waitcnt vmcnt(3)); 0: stores in place
     {"dcn_col2im", 0, false},            // 1 four channels per workgroup, shared sample geometry (default), 0 one channel
     {"dcn_col2im_fx", 0, false},         // 1 (default): the layer's backward sums dX in fixed point (integer LDS adds), 0 fp32 compare-and-swap
     {"dcn_coord", 0, false},             // 1 LDS-plane offset gradient (default), 0 per-lane gathers
