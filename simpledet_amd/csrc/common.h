@@ -94,6 +94,59 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
          __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// max|.| of four gradients as the maximum of the BIT PATTERNS of |.| (non-negative floats order like unsigned
+// integers; a NaN's pattern lies above inf's, so it survives every maximum -- `a > b ? a : b` on floats drops a NaN
+// in its first operand, which let NaN gradients slip past the "non-finite -> float adds" test until round 6)
+constexpr unsigned kFltMaxBits = 0x7f7fffffu;
+__device__ __forceinline__ unsigned umaxr(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned absbits4(const float4& v) {
+  return umaxr(umaxr(absbits(v.x), absbits(v.y)), umaxr(absbits(v.z), absbits(v.w)));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = umaxr(v, (unsigned)SD_DPP_STEP((int)v, 0xB1));
+  v = umaxr(v, (unsigned)SD_DPP_STEP((int)v, 0x4E));
+  v = umaxr(v, (unsigned)SD_DPP_STEP((int)v, 0x141));
+  v = umaxr(v, (unsigned)SD_DPP_STEP((int)v, 0x140));
+  const int x = (int)v;
+  return umaxr(umaxr((unsigned)__builtin_amdgcn_readlane(x, 0), (unsigned)__builtin_amdgcn_readlane(x, 16)),
+               umaxr((unsigned)__builtin_amdgcn_readlane(x, 32), (unsigned)__builtin_amdgcn_readlane(x, 48)));
+}
+
+// inclusive prefix sum over the 64 lanes on the VALU: row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes (a lane
+// whose source lies before its row keeps 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2
+// and 3.  Every lane must be active.
+__device__ __forceinline__ int wave_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+// 32-bit fixed-point LDS sums have ONE unit per workgroup: 2^-30 .. 2^-29 of (max|g| x weight bound).  That is
+// fine while the gradients of a workgroup span a few octaves; under heavy tails -- one element 10^4 x the
+// typical one -- the typical elements would be rounded to a few units.  So every fixed-point backward looks at
+// the dynamic range it actually streams and keeps the integer adds only while the unit is below ~2^-13 of the
+// GEOMETRIC mean of its non-zero gradients (the mean itself is useless here: a lognormal's mean sits far out in
+// its tail).  In exponents, all integer and therefore independent of any summation order:
+//     E(max|g|) + ceil(log2(weight bound)) <= mean E(g) + kFxRangeBits      (E = biased fp32 exponent field),
+// the mean taken over a fixed quarter of the stream (the first element of every 16-byte item), zeros and
+// denormals not counted.  Near-Gaussian gradients: E(max) - mean E ~ 3.5-4, so weight bounds up to ~2^11 pass;
+// a loss scale cancels out.  A workgroup that fails takes the fp32 compare-and-swap adds -- the reference's own
+// arithmetic (roi_align_v2.cu:67-83, upstream deformable_col2im: a float atomicAdd per tap).
+constexpr int kFxRangeBits = 15;
+__device__ __forceinline__ int fp32_exponent_field(float v) { return (int)((__float_as_uint(v) >> 23) & 255u); }
+__device__ __forceinline__ int ceil_log2_i32(int b) { return b <= 1 ? 0 : 32 - __builtin_clz((unsigned)(b - 1)); }
+// the verdict: exponent sum `se` over `cn` non-zero samples, the streamed maximum, the weight bound's bits
+__device__ __forceinline__ bool fx_range_ok(float gmax, int bound_bits, int se, int cn, int range_bits = kFxRangeBits) {
+  if (gmax == 0.f) return true;      // nothing but zeros
+  if (cn <= 0) return false;         // non-zero values, none of them sampled: no estimate
+  return (long long)(fp32_exponent_field(gmax) + bound_bits - range_bits) * (long long)cn <= (long long)se;
+}
+
 // fp32 add into an LDS word by compare-and-swap.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on
 // gfx950 against ~2 for this loop and 4-9 for the integer LDS atomics (tools/lds_atomic_bench.hip,
 // tools/lds_scatter_bench.hip), so every gradient plane kept in LDS is accumulated this way.

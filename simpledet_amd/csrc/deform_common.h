@@ -8,6 +8,7 @@
 #include "common.h"
 #include "../../include/simpledet_ops.h"
 #include <math.h>
+#include <float.h>
 #include <type_traits>
 
 namespace sd {
@@ -54,7 +55,6 @@ __device__ __forceinline__ Sample im2col_sample(const DcnGeom& g, int h_in, int 
   return s;
 }
 
-constexpr unsigned kCmaxSlots = 32;   // words the producing GEMM spreads its max|C| over (GemmArgs::cmax)
 constexpr int kDcnMaxTaps = 9;        // taps whose sampling state the LDS-plane kernels keep in registers
 
 // packed corner state: bits 0-27 index of (h_low, w_low), bit 28 w_high - w_low, bit 29
@@ -82,14 +82,13 @@ void launch_absmax(AbsSeg s0, AbsSeg s1 = AbsSeg{}, AbsSeg s2 = AbsSeg{}, hipStr
 // ---- host functions used across the translation units ----
 int make_geom(DcnGeom& g, int N, int C, int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h,
               int stride_w, int dil_h, int dil_w, int dgroup);
-// cmax / wsum (device; both or neither): bound of |col| and room for N * dgroup words -- with them the
-// four-channel col2im sums in fixed point
+// wsum (device, N * dgroup words, or null): with it the four-channel col2im sums in fixed point
 int col2im_impl(const float* col, const float* offset, float* dx, int req, int N, int C, int H, int W, int kh,
                 int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dgroup,
-                void* stream, const unsigned* cmax, unsigned* wsum);
+                void* stream, unsigned* wsum);
 int gemm_f32_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, long strideA,
                   const float* B, int ldb, long strideB, float* C, int ldc, long strideC, int batch,
-                  int accumulate, const unsigned* amax, void* stream, unsigned* cmax = nullptr);
+                  int accumulate, const unsigned* amax, void* stream);
 // deform_fused.hip: the col-free forward (falls back to `unfused` for shapes it does not take)
 bool dcn_fused_shape_ok(int C, int H, int W, int kh, int kw, int dgroup);
 int deform_conv_fwd_nocol_impl(const float* x, const float* offset, const float* weight, const float* bias,

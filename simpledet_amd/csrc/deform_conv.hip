@@ -198,17 +198,12 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
   }
   // operand maxima for the scaled fp16 split: {max|W|, max|dY|, max|x| >= max|col|}
   unsigned* amax = dcn_amax_slots(col, (size_t)N * K * P);
-  // fixed-point col2im: max|dcol| out of the GEMM's epilogue (amax[4 .. 4 + kCmaxSlots)) and N * dgroup
-  // weight-sum bounds behind them, all inside the slack behind the col matrix (what is left of its 512
-  // bytes depends on how far the caller's pointer was from a 256-byte boundary)
-  unsigned* cmax = nullptr;
+  // fixed-point col2im: N * dgroup weight-sum bounds inside the slack behind the col matrix (what is left of
+  // its 512 bytes depends on how far the caller's pointer was from a 256-byte boundary)
   unsigned* wsum = nullptr;
   const long slack_words = ((const char*)workspace + workspace_bytes - (const char*)amax) / 4;
-  if (4 + kCmaxSlots + (long)N * dgroup <= slack_words && tuning("deform_gemm_split", 2) >= 1) {
-    cmax = amax + 4;                // kCmaxSlots words
-    wsum = amax + 4 + kCmaxSlots;   // N * dgroup words
-  }
-  SD_HIP_CHECK(hipMemsetAsync(amax, 0, cmax ? 16 + 4 * kCmaxSlots : 16, st));
+  if (4 + (long)N * dgroup <= slack_words) wsum = amax + 4;   // N * dgroup words
+  SD_HIP_CHECK(hipMemsetAsync(amax, 0, 16, st));
   launch_absmax(absmax_seg(weight, 1, F * Kg, F * Kg, 0, 1, amax),
                 absmax_seg(out_grad, (long)N * F, P, P, 0, 1, amax + 1),
                 absmax_seg(x, (long)N * C, H * W, H * W, 0, 1, amax + 2), st);
@@ -216,13 +211,13 @@ static int deform_conv_bwd_impl(const float* out_grad, const float* x, const flo
     // dcol[n][grp] (K/G x P) = W[grp]^T (K/G x F/G) . dY[n][grp] (F/G x P)
     for (int q = 0; q < num_group; ++q)
       if (int e = gemm_f32_impl(1, 0, Kg, P, Fg, weight + (long)q * Fg * Kg, Kg, 0, out_grad + (long)q * Fg * P, P,
-                                (long)F * P, col + (long)q * Kg * P, P, (long)K * P, N, 0, amax, stream, cmax))
+                                (long)F * P, col + (long)q * Kg * P, P, (long)K * P, N, 0, amax, stream))
         return e;
     if (int e = sd_deform_col2im_coord(col, x, offset, d_offset, req_offset, N, C, H, W, kh, kw, pad,
                                        pad, stride, stride, dil, dil, dgroup, stream))
       return e;
     if (int e = col2im_impl(col, offset, d_x, req_x, N, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil,
-                            dgroup, stream, cmax, wsum))
+                            dgroup, stream, wsum))
       return e;
   }
   if (req_weight != SD_REQ_NULL) {

@@ -27,8 +27,6 @@ struct GemmArgs {
   int whole, whole_blocks, ksplit;  // split kernel: tiles run whole, their blocks (padded), k slices of the rest
   int ablate;  // profiling build only: bit 0 skip the A prefetch, bit 1 skip the B prefetch
   const unsigned* amax;  // f16 split: bit patterns of max|A|, max|B| (upper bounds), device memory
-  unsigned* cmax;        // split kernel, optional: atomic max of the bit patterns of |C| as stored (an upper bound
-                         // of max|C| when tiles are cut into k slices: slice maximum x slices)
 };
 
 constexpr int BM = 128;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
@@ -433,7 +431,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
     mfma_step();
   }
   // D layout of the 32x32 tile: element e of lane l -> row (e/4)*8 + (l/32)*4 + e%4, col l%32
-  unsigned vbits = 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -449,26 +446,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
           if (piece || a.mode == 2) atomicAdd(c, v);
           else if (a.mode == 0) *c = v;
           else *c += v;
-          // (the maximum of the bit patterns of |v|: two integer operations per element, and a NaN -- whose
-          // pattern lies above inf's -- survives as "not finite" where fmaxf would drop it)
-          const unsigned ab = __float_as_uint(v) & 0x7fffffffu;
-          vbits = vbits > ab ? vbits : ab;
         }
       }
     }
-  if (a.cmax) {
-    // one atomic per workgroup into one of kCmaxSlots words (tens of thousands of atomics on ONE word
-    // serialise at the L2: +130 us on the col-gradient GEMM); readers take the maximum of the slots
-    __shared__ float s_vmax[4];
-    float vmax = __uint_as_float(vbits > 0x7f800000u ? 0x7f800000u : vbits);
-    if (piece) vmax *= (float)a.ksplit;
-    vmax = wave_max_f32(vmax);
-    if (lane == 0) s_vmax[wave] = vmax;
-    __syncthreads();
-    if (tid == 0)
-      atomicMax(a.cmax + ((unsigned)blockIdx.x % kCmaxSlots),
-                __float_as_uint(fmaxr(fmaxr(s_vmax[0], s_vmax[1]), fmaxr(s_vmax[2], s_vmax[3]))));
-  }
 }
 
 // zero the tiles that k slices add into (C = A.B with the last tiles cut along k)
@@ -680,8 +660,7 @@ using namespace sd;
 
 int sd::gemm_f32_impl(int transA, int transB, int M, int N, int K, const float* A, int lda,
                          long strideA, const float* B, int ldb, long strideB, float* C, int ldc,
-                         long strideC, int batch, int accumulate, const unsigned* amax, void* stream,
-                         unsigned* cmax) {
+                         long strideC, int batch, int accumulate, const unsigned* amax, void* stream) {
   SD_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative dimension");
   SD_REQUIRE(accumulate >= 0 && accumulate <= 2, "accumulate must be 0, 1 or 2");
   if (M == 0 || N == 0 || batch == 0) return SD_OK;
@@ -694,7 +673,6 @@ int sd::gemm_f32_impl(int transA, int transB, int M, int N, int K, const float* 
   g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
   g.mode = accumulate;
   g.amax = amax;
-  g.cmax = cmax;
   if (K == 0) {
     if (accumulate == 0)
       for (int b = 0; b < batch; ++b)

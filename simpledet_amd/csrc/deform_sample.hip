@@ -169,12 +169,15 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
 //
 // FX (round 4): the sums in 32-bit fixed point with plain integer LDS adds (fire and forget) instead of
 // fp32 compare-and-swap loops -- 16 chained loops per sample were the kernel.  The unit needs a bound
-// on what a pixel can collect: |dcol| <= cmax (the maximum the producing GEMM's epilogue recorded) times
+// on what a pixel can collect: max|col| of the workgroup's own values (round 6: taken optimistically from its
+// first trip and verified behind the scatter, like roi_align_bwd_packed4 -- until round 5 the producing GEMM's
+// epilogue had to record a global maximum, so only the layer's backward could use this path) times
 // the largest sum of bilinear weights landing on one pixel, which depends on (image, group) only and
 // is bounded per tap by deform_col2im_wsum_kernel (sum over the taps of each tap's largest pile-up).
-// scale = the power of two that puts that bound below 2^29; one unit is then <= 2^-28 of the largest
-// possible sum, and the result does not depend on the order of the adds.  A non-finite bound (inf /
-// nan in dcol) keeps the compare-and-swap adds, which send inf / nan where the reference sends them.
+// scale = the power of two that puts twice that bound below 2^29; one unit is then <= 2^-27 of the largest
+// possible sum, and the result does not depend on the order of the adds.  Non-finite values, and a dynamic
+// range the unit is too coarse for (kFxRangeBits), keep the compare-and-swap adds, which send inf / nan
+// where the reference sends them.
 
 
 // where a sample lands: LDS index of the (floor, floor) corner relative to the band and the factors of
@@ -264,100 +267,162 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
                                                                 const float* __restrict__ offset,
                                                                 float* __restrict__ dx, DcnGeom g,
                                                                 int band_rows, int req_add,
-                                                                const unsigned* __restrict__ cmax,
                                                                 const unsigned* __restrict__ wsum, int wshift) {
   extern __shared__ __attribute__((aligned(16))) float plane[];
+  __shared__ unsigned s_ctl[4];        // [0] max|col| bits of the first trip, [1] of everything, [2] non-finite flag
+  __shared__ int s_exp[2];             // exponent sum / count of the non-zero sampled values (dynamic-range verdict)
   const int P = g.Ho * g.Wo, K2 = g.kh * g.kw;
   const int c0 = blockIdx.x * CC, n = blockIdx.z;
   const int row0 = blockIdx.y * band_rows, row1 = iminr(row0 + band_rows, g.H);
   const int band_elems = (row1 - row0) * g.W;
   const int tid = threadIdx.x;
   for (int i = tid; i < CC * band_elems; i += T) plane[i] = 0.f;   // (0.f and 0 are the same bits)
-  __syncthreads();
+  if (tid < 4) s_ctl[tid] = 0u;
+  if (tid < 2) s_exp[tid] = 0;
   const int cpg = g.C / g.dgroup, grp = c0 / cpg;
-  // fixed point: scale * (largest possible sum) < 2^29 (rounding of the individual adds and the slack of
-  // the fp32 weight sums stay far inside the remaining two bits)
+  const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P;
+  const float* cp = col + ((long)n * g.C + c0) * K2 * P;
+  const long cstride = (long)K2 * P;  // col elements per channel
+  // maxima as bit patterns of |col| (absbits4: a NaN survives); anything above FLT_MAX's pattern is non-finite
+  auto wave_max_to = [&](unsigned m, int slot) {
+    m = wave_max_u32(m);
+    if ((tid & (kWave - 1)) == 0) {
+      atomicMax(&s_ctl[slot], m);
+      if (m > kFltMaxBits) atomicOr(&s_ctl[2], 1u);
+    }
+  };
+  // Fixed point (round 6: self-contained -- no maximum from the producer of col, so the stand-alone
+  // sd_deform_col2im_ws gets it too): the unit comes from max|col| of the workgroup's OWN 4 x K2 x P values x
+  // the weight bound of its (image, group).  The maximum is taken optimistically from the values of every
+  // thread's first trip (tap 0) with a factor two of headroom and verified behind the scatter, together with
+  // the dynamic range (kFxRangeBits): a late outlier, a non-finite value or a range the unit is too coarse
+  // for clear the planes and sum them again -- with the exact maximum, or with the fp32 compare-and-swap adds.
   bool fx = false;
-  float scale = 1.f;
+  float scale = 1.f, weff = 0.f, gmax_used = 0.f;
+  __syncthreads();   // planes and s_ctl are zero
   if (FX) {
+    unsigned m0 = 0u;
+    if (tid * 4 < P) {
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) m0 = umaxr(m0, absbits4(*reinterpret_cast<const float4*>(cp + cc * cstride + tid * 4)));
+    }
+    wave_max_to(m0, 0);
+    __syncthreads();
+    gmax_used = __uint_as_float(s_ctl[0]);
     // (the integer weight sum is exact in a float up to 2^24 units; beyond that it is rounded to nearest:
     // one more unit of margin)
-    unsigned cbits = 0;
-#pragma unroll
-    for (unsigned k = 0; k < kCmaxSlots; ++k) cbits = cbits > cmax[k] ? cbits : cmax[k];
-    const float bound = __uint_as_float(cbits) * ((float)(wsum[(long)n * g.dgroup + grp] + 1u) / (float)(1u << wshift)) * 1.000001f;
+    weff = ((float)(wsum[(long)n * g.dgroup + grp] + 1u) / (float)(1u << wshift)) * 1.000001f;
+  }
+  // scale * 2 * (largest possible sum) < 2^29: the true maximum may be twice the optimistic one, and both sums of
+  // a channel pair stay below 2^29 in magnitude (rounding of the individual adds and the slack of the fp32
+  // weight sums stay far inside the remaining two bits)
+  auto set_scale = [&](float gmax) {
+    const float bound = gmax * weff;
     const unsigned bb = __float_as_uint(bound);
     const int e = (int)((bb >> 23) & 255);
+    fx = false;
+    scale = 1.f;
     if (bound == 0.f) {
       fx = true;   // nothing but zeros can arrive
     } else if (e != 255 && e != 0) {
-      int es = 127 + 28 - (e - 127);   // scale = 2^(28 - floor(log2 bound))
+      int es = 127 + 27 - (e - 127);   // scale = 2^(27 - floor(log2 bound))
       es = es > 254 ? 254 : es;
       if (es >= 1) {
         scale = __uint_as_float((unsigned)es << 23);
         fx = true;
       }
     }
-  }
-  const float* off = offset + ((long)n * g.dgroup + grp) * 2 * K2 * P;
-  const float* cp = col + ((long)n * g.C + c0) * K2 * P;
-  const long cstride = (long)K2 * P;  // col elements per channel
-  for (int tap = 0; tap < K2; ++tap) {
-    const int i = tap / g.kw, j = tap % g.kw;
-    const float* oh = off + (long)(2 * tap) * P;
-    const float* ow = oh + P;
-    const float* ct = cp + (long)tap * P;
-    for (int p4 = tid * 4; p4 < P; p4 += T * 4) {  // P % 4 == 0 (host)
-      const float4 ofh = *reinterpret_cast<const float4*>(oh + p4);
-      const float4 ofw = *reinterpret_cast<const float4*>(ow + p4);
-      float4 cv[CC];
+  };
+  if (FX && !s_ctl[2]) set_scale(gmax_used);
+  unsigned m_all = 0u;
+  int e_sum = 0, e_cnt = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int tap = 0; tap < K2; ++tap) {
+      const int i = tap / g.kw, j = tap % g.kw;
+      const float* oh = off + (long)(2 * tap) * P;
+      const float* ow = oh + P;
+      const float* ct = cp + (long)tap * P;
+      for (int p4 = tid * 4; p4 < P; p4 += T * 4) {  // P % 4 == 0 (host)
+        const float4 ofh = *reinterpret_cast<const float4*>(oh + p4);
+        const float4 ofw = *reinterpret_cast<const float4*>(ow + p4);
+        float4 cv[CC];
 #pragma unroll
-      for (int cc = 0; cc < CC; ++cc) cv[cc] = *reinterpret_cast<const float4*>(ct + cc * cstride + p4);
-      int h_out = p4 / g.Wo, w_out = p4 - h_out * g.Wo;
+        for (int cc = 0; cc < CC; ++cc) cv[cc] = *reinterpret_cast<const float4*>(ct + cc * cstride + p4);
+        if (FX && attempt == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float offset_h = e == 0 ? ofh.x : e == 1 ? ofh.y : e == 2 ? ofh.z : ofh.w;
-        const float offset_w = e == 0 ? ofw.x : e == 1 ? ofw.y : e == 2 ? ofw.z : ofw.w;
-        const int h_in = h_out * g.stride_h - g.pad_h, w_in = w_out * g.stride_w - g.pad_w;
-        if (++w_out == g.Wo) {
-          w_out = 0;
-          ++h_out;
+          for (int cc = 0; cc < CC; ++cc) {
+            m_all = umaxr(m_all, absbits4(cv[cc]));
+            const int ex = fp32_exponent_field(cv[cc].x);
+            e_sum += ex;
+            e_cnt += ex != 0;
+          }
         }
-        const float inv_h = h_in + i * g.dil_h + offset_h;
-        const float inv_w = w_in + j * g.dil_w + offset_w;
-        int base;
-        float fhv[2], fwv[2];
-        col2im_geom(g, inv_h, inv_w, row0, row1, base, fhv, fwv);
+        int h_out = p4 / g.Wo, w_out = p4 - h_out * g.Wo;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const float w = fhv[d >> 1] * fwv[d & 1];
-          if (w != 0.f) {
-            const int idx = base + (d >> 1) * g.W + (d & 1);
-            if (FX && fx) {
-              // two channels per 64-bit add: (channel 2 k + 1) * 2^32 + (channel 2 k), the low field sign-extended;
-              // both sums stay below 2^29 in magnitude, so the fields come apart again exactly (write-out)
-              long long* q64 = reinterpret_cast<long long*>(plane) + idx;
+        for (int e = 0; e < 4; ++e) {
+          const float offset_h = e == 0 ? ofh.x : e == 1 ? ofh.y : e == 2 ? ofh.z : ofh.w;
+          const float offset_w = e == 0 ? ofw.x : e == 1 ? ofw.y : e == 2 ? ofw.z : ofw.w;
+          const int h_in = h_out * g.stride_h - g.pad_h, w_in = w_out * g.stride_w - g.pad_w;
+          if (++w_out == g.Wo) {
+            w_out = 0;
+            ++h_out;
+          }
+          const float inv_h = h_in + i * g.dil_h + offset_h;
+          const float inv_w = w_in + j * g.dil_w + offset_w;
+          int base;
+          float fhv[2], fwv[2];
+          col2im_geom(g, inv_h, inv_w, row0, row1, base, fhv, fwv);
 #pragma unroll
-              for (int pr = 0; pr < CC / 2; ++pr) {
-                const float g0 = e == 0 ? cv[2 * pr].x : e == 1 ? cv[2 * pr].y : e == 2 ? cv[2 * pr].z : cv[2 * pr].w;
-                const float g1 = e == 0 ? cv[2 * pr + 1].x : e == 1 ? cv[2 * pr + 1].y : e == 2 ? cv[2 * pr + 1].z : cv[2 * pr + 1].w;
-                const long long lo = (long long)__float2int_rn((w * g0) * scale);
-                const long long hi = (long long)__float2int_rn((w * g1) * scale);
-                __hip_atomic_fetch_add(q64 + pr * band_elems, hi * 4294967296ll + lo, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-              }
-            } else {
-              float* q = plane + idx;
+          for (int d = 0; d < 4; ++d) {
+            const float w = fhv[d >> 1] * fwv[d & 1];
+            if (w != 0.f) {
+              const int idx = base + (d >> 1) * g.W + (d & 1);
+              if (FX && fx) {
+                // two channels per 64-bit add: (channel 2 k + 1) * 2^32 + (channel 2 k), the low field sign-extended;
+                // both sums stay below 2^29 in magnitude, so the fields come apart again exactly (write-out)
+                long long* q64 = reinterpret_cast<long long*>(plane) + idx;
 #pragma unroll
-              for (int cc = 0; cc < CC; ++cc) {
-                const float gv = e == 0 ? cv[cc].x : e == 1 ? cv[cc].y : e == 2 ? cv[cc].z : cv[cc].w;
-                lds_add_cas(q + cc * band_elems, w * gv);
+                for (int pr = 0; pr < CC / 2; ++pr) {
+                  const float g0 = e == 0 ? cv[2 * pr].x : e == 1 ? cv[2 * pr].y : e == 2 ? cv[2 * pr].z : cv[2 * pr].w;
+                  const float g1 = e == 0 ? cv[2 * pr + 1].x : e == 1 ? cv[2 * pr + 1].y : e == 2 ? cv[2 * pr + 1].z : cv[2 * pr + 1].w;
+                  const long long lo = (long long)__float2int_rn((w * g0) * scale);
+                  const long long hi = (long long)__float2int_rn((w * g1) * scale);
+                  __hip_atomic_fetch_add(q64 + pr * band_elems, hi * 4294967296ll + lo, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              } else {
+                float* q = plane + idx;
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc) {
+                  const float gv = e == 0 ? cv[cc].x : e == 1 ? cv[cc].y : e == 2 ? cv[cc].z : cv[cc].w;
+                  lds_add_cas(q + cc * band_elems, w * gv);
+                }
               }
             }
           }
         }
       }
     }
+    if (!FX || !fx || attempt > 0) break;
+    // was the optimistic maximum enough, and is the unit fine enough for what was streamed?
+    wave_max_to(m_all, 1);
+    {
+      const int es = wave_sum_i32(e_sum), ec = wave_sum_i32(e_cnt);
+      if ((tid & (kWave - 1)) == 0) {   // integer sums: the order of the waves does not matter
+        atomicAdd(&s_exp[0], es);
+        atomicAdd(&s_exp[1], ec);
+      }
+    }
+    __syncthreads();
+    const float gmax_true = __uint_as_float(s_ctl[1]);
+    // (the unit here is 2^-28 .. 2^-27 of the bound where the RoIAlign planes have 2^-30 .. 2^-29: two bits less range)
+    const bool fine = fx_range_ok(gmax_true, ceil_log2_i32((int)ceilf(fminr(weff, 1e9f))), s_exp[0], s_exp[1], kFxRangeBits - 2);
+    if (!s_ctl[2] && fine && gmax_true <= 2.f * gmax_used) break;   // also when every value is zero
+    __syncthreads();   // every thread has read the verdict before the planes are cleared
+    for (int i = tid; i < CC * band_elems; i += T) plane[i] = 0.f;
+    if (s_ctl[2] || !fine) fx = false;
+    else set_scale(gmax_true);
+    __syncthreads();
   }
   __syncthreads();
   const float unscale = 1.0f / scale;   // exact
@@ -898,11 +963,11 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
   return SD_OK;
 }
 
-// cmax / wsum (device; both or neither): bound of |col| and room for N * dgroup floats -- with them the
+// wsum (device, N * dgroup words, or null): room for the per-(image, group) weight bounds -- with it the
 // four-channel kernel sums in fixed point (deform_col2im_chunk_kernel<.., true>)
 int sd::col2im_impl(const float* col, const float* offset, float* dx, int req, int N, int C, int H, int W,
                        int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
-                       int dgroup, void* stream, const unsigned* cmax, unsigned* wsum) {
+                       int dgroup, void* stream, unsigned* wsum) {
   DcnGeom g;
   if (int e = make_geom(g, N, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dgroup))
     return e;
@@ -927,7 +992,7 @@ int sd::col2im_impl(const float* col, const float* offset, float* dx, int req, i
       // weights as multiples of 2^-wshift: K2 * P of them (every sample of an image on one pixel) stay below 2^32
       int wshift = 20;
       while (wshift > 0 && (double)kh * kw * P * (double)(1u << wshift) >= 4294967296.0) --wshift;
-      const bool fx = cmax && wsum && ldsw <= 150 * 1024 && kh * kw <= 65535 && wshift >= 8 &&
+      const bool fx = wsum && ldsw <= 150 * 1024 && kh * kw <= 65535 && wshift >= 8 &&
                       tuning("dcn_col2im_fx", 1) == 1;
       if (fx) {
         SD_HIP_CHECK(hipMemsetAsync(wsum, 0, sizeof(unsigned) * (size_t)N * dgroup, st));
@@ -940,7 +1005,7 @@ int sd::col2im_impl(const float* col, const float* offset, float* dx, int req, i
           SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
         hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T, true>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
-                           col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, cmax, wsum, wshift);
+                           col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, wsum, wshift);
         SD_LAUNCH_CHECK();
         return SD_OK;
       }
@@ -948,7 +1013,7 @@ int sd::col2im_impl(const float* col, const float* offset, float* dx, int req, i
         SD_HIP_CHECK(hipFuncSetAttribute((const void*)deform_col2im_chunk_kernel<CC, T, false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
       hipLaunchKernelGGL((deform_col2im_chunk_kernel<CC, T, false>), dim3(C / CC, nb4, N), dim3(T), lds4, st,
-                         col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, nullptr, nullptr, 0);
+                         col, offset, dx, g, rows4, req == SD_REQ_ADD ? 1 : 0, nullptr, 0);
       SD_LAUNCH_CHECK();
       return SD_OK;
     }
@@ -976,7 +1041,27 @@ extern "C" int sd_deform_col2im(const float* col, const float* offset, float* dx
                                 int stride_h, int stride_w, int dil_h, int dil_w, int dgroup,
                                 void* stream) {
   return col2im_impl(col, offset, dx, req, N, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
-                     dgroup, stream, nullptr, nullptr);
+                     dgroup, stream, nullptr);
+}
+
+extern "C" size_t sd_deform_col2im_workspace_bytes(int N, int dgroup) {
+  if (N <= 0 || dgroup <= 0) return 16;
+  return (size_t)N * dgroup * sizeof(unsigned) + 16;
+}
+
+extern "C" int sd_deform_col2im_ws(const float* col, const float* offset, float* dx, int req, int N,
+                                   int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                                   int stride_h, int stride_w, int dil_h, int dil_w, int dgroup,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  unsigned* wsum = nullptr;
+  if (workspace && N > 0 && dgroup > 0) {
+    wsum = reinterpret_cast<unsigned*>(((uintptr_t)workspace + 3) & ~(uintptr_t)3);
+    if ((const char*)(wsum + (size_t)N * dgroup) > (const char*)workspace + workspace_bytes)
+      return fail(SD_ERR_WORKSPACE, "deformable col2im workspace too small: %zu < %zu bytes", workspace_bytes,
+                  sd_deform_col2im_workspace_bytes(N, dgroup));
+  }
+  return col2im_impl(col, offset, dx, req, N, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
+                     dgroup, stream, wsum);
 }
 
 extern "C" int sd_deform_col2im_coord(const float* col, const float* x, const float* offset,

@@ -548,14 +548,13 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   // near-Gaussian ones of the baseline), or a later item is non-finite, the band is zeroed and
   // accumulated again with the exact maximum (or with float adds).  The result is the same
   // deterministic function of the inputs either way.
-  auto abs4 = [](const float4& g) {
-    return fmaxr(fmaxr(fabsf(g.x), fabsf(g.y)), fmaxr(fabsf(g.z), fabsf(g.w)));
-  };
-  auto wave_max_to = [&](float m, int bad, int slot) {
-    m = wave_max_f32(m);
-    if ((tid & (kWave - 1)) == 0)  // non-negative floats order like their bit patterns
-      atomicMax(reinterpret_cast<unsigned*>(nlist + slot), __float_as_uint(m));
-    if (__any(bad) && (tid & (kWave - 1)) == 0) atomicOr(nlist + 3, 1);
+  // maxima as bit patterns of |g| (absbits4: a NaN survives); anything above FLT_MAX's pattern is non-finite
+  auto wave_max_to = [&](unsigned m, int slot) {
+    m = wave_max_u32(m);
+    if ((tid & (kWave - 1)) == 0) {
+      atomicMax(reinterpret_cast<unsigned*>(nlist + slot), m);
+      if (m > kFltMaxBits) atomicOr(nlist + 3, 1);
+    }
   };
   auto set_scale = [&](float gmax) {
     const float bound = gmax * (float)nlist[1];  // no pixel of the band can exceed this
@@ -573,11 +572,13 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   const int tch = FLT ? (nl > 0 ? nl : 1) : TCH;  // no tables to stage: the whole list is one chunk
   load_item(tid, 0, iminr(tch, nl) * GP, cur);
   stage_tables(0, iminr(tch, nl));
-  float m_all = abs4(cur.g);
-  int bad = !(m_all <= FLT_MAX);
-  if (use_fx) wave_max_to(m_all, bad, 2);
+  unsigned m_all = absbits4(cur.g);
+  if (use_fx) wave_max_to(m_all, 2);
   __syncthreads();
   float gmax_used = 0.f;
+  // exponent sum / count of the non-zero first elements of the items this thread streams: the dynamic-range
+  // verdict behind the scatter (kFxRangeBits, common.h)
+  int e_sum = 0, e_cnt = 0;
   if (use_fx) {
     gmax_used = __uint_as_float((unsigned)nlist[2]);
     if (nlist[3]) use_fx = false;  // non-finite gradients: float adds (a zeroed band is 0 in both formats)
@@ -597,28 +598,41 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
       for (int t = tid; t < nli; t += THREADS) {
         Item nxt;
         load_item(t + THREADS, cb, nli, nxt);
-        const float ag = abs4(cur.g);
-        bad |= !(ag <= FLT_MAX);
-        m_all = fmaxr(m_all, ag);
+        m_all = umaxr(m_all, absbits4(cur.g));
+        {
+          const int ex = fp32_exponent_field(cur.g.x);
+          e_sum += ex;
+          e_cnt += ex != 0;
+        }
         if (TAPS) scatter_taps(cur, cur.j);
         else scatter_item(cur, cur.j);
         cur = nxt;
       }
     }
     if (!use_fx || attempt > 0) break;
-    // was the optimistic scale enough?  (checked behind the barrier that ends the scatter anyway)
-    wave_max_to(m_all, bad, 4);
+    // was the optimistic scale enough, and is the unit fine enough for what was streamed?  (checked behind
+    // the barrier that ends the scatter anyway)
+    wave_max_to(m_all, 4);
+    {
+      const int es = wave_sum_i32(e_sum), ec = wave_sum_i32(e_cnt);
+      if ((tid & (kWave - 1)) == 0) {   // integer sums: the order of the waves does not matter
+        atomicAdd(nlist + 5, es);
+        atomicAdd(nlist + 6, ec);
+      }
+    }
     __syncthreads();
     const float gmax_true = __uint_as_float((unsigned)nlist[4]);
-    if (!nlist[3] && gmax_true <= 2.f * gmax_used) { synced = true; break; }  // also when all gradients are zero
+    const bool fine = fx_range_ok(gmax_true, ceil_log2_i32(nlist[1]), nlist[5], nlist[6]);
+    if (!nlist[3] && fine && gmax_true <= 2.f * gmax_used) { synced = true; break; }  // also when all gradients are zero
     __syncthreads();  // every thread has read the verdict before the band is cleared
-    // rare: accumulate the band again with the exact maximum (or with float adds)
+    // rare: accumulate the band again with the exact maximum, or -- non-finite gradients, a dynamic range the
+    // fixed-point unit is too coarse for -- with float adds
     {
       float4* p4 = reinterpret_cast<float4*>(smem);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int i = tid; i < plane_pad / 4; i += THREADS) p4[i] = z;
     }
-    if (nlist[3]) use_fx = false;
+    if (nlist[3] || !fine) use_fx = false;
     else set_scale(gmax_true);
   }
   if (!synced) __syncthreads();
@@ -683,7 +697,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
 // thread's first item with a factor two of headroom and verified behind the scatter, as in
 // roi_align_bwd_packed4; non-finite gradients, a weight bound above 2048 and `roi_align_bwd_fx` = 0
 // take the fp32 compare-and-swap adds.  The result is a deterministic function of the inputs.
-//   grid: x = channel quad, y = image; LDS = 4 * H * W words + 8
+//   grid: x = channel quad, y = image; LDS = 4 * H * W words + 8 control words
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArgs a, int lvl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -695,7 +709,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
   const int H = a.L.H[lvl], W = a.L.W[lvl], HW = H * W, PP = a.PP;
   float* plane = smem;  // [CC][HW]
   int* plane_i = reinterpret_cast<int*>(smem);
-  int* ctl = plane_i + CC * HW;  // [0] weight bound, [1] max|dY| of the first items, [2] non-finite flag, [3] true max|dY|
+  int* ctl = plane_i + CC * HW;  // [0] weight bound, [1] max|dY| of the first items, [2] non-finite flag, [3] true max|dY|, [4] exponent sum, [5] non-zero count
   bool use_fx = !a.float_adds;
   if (tid < 8) ctl[tid] = 0;
   if (use_fx) {
@@ -765,14 +779,13 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
       it.L = L;
     }
   };
-  auto abs4 = [](const float4& g) {
-    return fmaxr(fmaxr(fabsf(g.x), fabsf(g.y)), fmaxr(fabsf(g.z), fabsf(g.w)));
-  };
-  auto wave_max_to = [&](float m, int bad, int slot) {
-    m = wave_max_f32(m);
-    if ((tid & (kWave - 1)) == 0)  // non-negative floats order like their bit patterns
-      atomicMax(reinterpret_cast<unsigned*>(ctl + slot), __float_as_uint(m));
-    if (__any(bad) && (tid & (kWave - 1)) == 0) atomicOr(ctl + 2, 1);
+  // maxima as bit patterns of |g| (absbits4: a NaN survives); anything above FLT_MAX's pattern is non-finite
+  auto wave_max_to = [&](unsigned m, int slot) {
+    m = wave_max_u32(m);
+    if ((tid & (kWave - 1)) == 0) {
+      atomicMax(reinterpret_cast<unsigned*>(ctl + slot), m);
+      if (m > kFltMaxBits) atomicOr(ctl + 2, 1);
+    }
   };
   float fx_scale = 1.f, fx_inv = 1.f;
   auto set_scale = [&](float gmax) {
@@ -786,24 +799,30 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
   };
   Item cur;
   load_item(tid, cur);
-  float m_all = cur.L >= 0 ? abs4(cur.g) : 0.f;
-  int bad = !(m_all <= FLT_MAX);
-  if (use_fx) wave_max_to(m_all, bad, 1);
+  unsigned m_all = cur.L >= 0 ? absbits4(cur.g) : 0u;
+  if (use_fx) wave_max_to(m_all, 1);
   __syncthreads();  // the planes are zero, the first maxima are in
   float gmax_used = 0.f;
+  int e_sum = 0, e_cnt = 0;  // exponent sum / count of the non-zero first elements streamed (kFxRangeBits)
   if (use_fx) {
     gmax_used = __uint_as_float((unsigned)ctl[1]);
+    // (the non-finite flag has its own barrier-separated read: a wave that reaches the verdict of attempt 0
+    // early ORs into ctl[2] only after every wave has passed the barrier above)
     if (ctl[2]) use_fx = false;
     else set_scale(gmax_used > 0.f ? gmax_used : 1.f);
   }
+  __syncthreads();  // every wave has read ctl[1] / ctl[2] before a fast wave's verdict can change them
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt > 0) load_item(tid, cur);
     for (int u = tid; u < nunits; u += THREADS) {
       Item nxt;
       load_item(u + THREADS, nxt);
-      const float ag = abs4(cur.g);
-      bad |= !(ag <= FLT_MAX);
-      m_all = fmaxr(m_all, ag);
+      m_all = umaxr(m_all, absbits4(cur.g));
+      {
+        const int ex = fp32_exponent_field(cur.g.x);
+        e_sum += ex;
+        e_cnt += ex != 0;
+      }
       const float gg[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w}, xx[4] = {cur.x.x, cur.x.y, cur.x.z, cur.x.w};
       const float yy[4] = {cur.y.x, cur.y.y, cur.y.z, cur.y.w};
 #pragma unroll
@@ -838,14 +857,24 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
       cur = nxt;
     }
     if (!use_fx || attempt > 0) break;
-    // was the optimistic scale enough?
-    wave_max_to(m_all, bad, 3);
+    // was the optimistic scale enough, and is the unit fine enough for what was streamed?
+    wave_max_to(m_all, 3);
+    {
+      const int es = wave_sum_i32(e_sum), ec = wave_sum_i32(e_cnt);
+      if ((tid & (kWave - 1)) == 0) {   // integer sums: the order of the waves does not matter
+        atomicAdd(ctl + 4, es);
+        atomicAdd(ctl + 5, ec);
+      }
+    }
     __syncthreads();
     const float gmax_true = __uint_as_float((unsigned)ctl[3]);
-    if (!ctl[2] && gmax_true <= 2.f * gmax_used) break;  // also when all gradients are zero
+    const bool fine = fx_range_ok(gmax_true, ceil_log2_i32(ctl[0]), ctl[4], ctl[5]);
+    if (!ctl[2] && fine && gmax_true <= 2.f * gmax_used) break;  // also when all gradients are zero
     __syncthreads();  // every thread has read the verdict before the planes are cleared
-    for (int i = tid; i < CC * HW; i += THREADS) plane_i[i] = 0;  // rare: again, with the exact maximum (or float adds)
-    if (ctl[2]) use_fx = false;
+    // rare: again, with the exact maximum -- or with float adds (non-finite gradients, a dynamic range the
+    // fixed-point unit is too coarse for)
+    for (int i = tid; i < CC * HW; i += THREADS) plane_i[i] = 0;
+    if (ctl[2] || !fine) use_fx = false;
     else set_scale(gmax_true);
     __syncthreads();
   }
@@ -883,6 +912,7 @@ int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace,
       SD_HIP_CHECK(hipFuncSetAttribute((const void*)roi_align_bwd_flt4_kernel<512>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     hipLaunchKernelGGL((roi_align_bwd_flt4_kernel<512>), dim3(a.C / 4, a.B), dim3(512), lds4, st, a, 0);
+    note_dispatch("sd::roi_align_bwd_flt4_kernel<512>");
     SD_LAUNCH_CHECK();
     return SD_OK;
   }
@@ -967,6 +997,13 @@ int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace,
     if (nl < SD_MAX_FPN_LEVELS) a.unit_base[nl] = (int)ub;
   }
   a.lists_units = 0;
+  a.pix_bound_words = 0;
+  if (tuning("roi_align_bwd_pixbound", 1) == 1)
+    for (int i = 0; i < nl; ++i) {
+      const int l = a.order[i];
+      const long words = (long)(a.band_rows[l] + 1) * (a.L.W[l] + 1);
+      if (words <= kPixBoundMaxWords && words > a.pix_bound_words) a.pix_bound_words = (int)words;
+    }
   if (use_lists && nl < SD_MAX_FPN_LEVELS) {
     a.ws_list = static_cast<int*>(workspace);
     if (use_taps) a.ws_taps = reinterpret_cast<float*>(static_cast<char*>(workspace) + list_bytes);
@@ -1102,8 +1139,10 @@ extern "C" int sd_roi_align_v2_bwd(const float* out_grad, const float* rois, con
     a.filter_lvl = -1;
     a.req = req_data;
     bool done = false;
-    if (tuning("roi_align_bwd", 2) == 2 && (a.PP == 49 || a.PP == 196) && (long)B * R * C > 0 &&
-        R <= 8192) {
+    // (the fused kernels' weight bounds count bins per axis: square 7x7 / 14x14 pools only -- a 1x49 pool has
+    // PP = 49 too and goes to the plane kernels, whose 64-bit sums need no such bound)
+    if (tuning("roi_align_bwd", 2) == 2 && (a.PP == 49 || a.PP == 196) && pooled_h == pooled_w &&
+        (long)B * R * C > 0 && R <= 8192) {
       BwdFusedArgs f{};
       f.L = a.L;
       f.L.nlvl = 1; f.L.H[0] = H; f.L.W[0] = W; f.L.scale[0] = spatial_scale;
@@ -1281,7 +1320,8 @@ extern "C" int sd_fpn_roi_align_bwd(const float* out_grad, const float* rois,
   for (int l = 0; l < nlvl; ++l)
     SD_REQUIRE(d_feats_host[l] || (long)B * C == 0, "d_feats[%d] null", l);
   const long count = (long)B * R * C * a.PP;
-  if (tuning("roi_align_bwd", 2) == 2 && (a.PP == 49 || a.PP == 196) && count > 0 && R <= 8192) {
+  if (tuning("roi_align_bwd", 2) == 2 && (a.PP == 49 || a.PP == 196) && pooled_h == pooled_w && count > 0 &&
+      R <= 8192) {
     BwdFusedArgs f{};
     f.L = a.L;
     f.dy = out_grad; f.ax = maxidx_x; f.ay = maxidx_y; f.rois = rois;

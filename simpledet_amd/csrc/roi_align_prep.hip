@@ -199,7 +199,10 @@ __device__ __forceinline__ void bwd_lists_block(const BwdFusedArgs& a, int block
   // PARTS workgroups per unit: each builds the (cheap) list, the first stores it, all share
   // the tap entries -- the entry loop is a chain of dependent round trips (list -> box ->
   // entry), so more workgroups shorten the pre-pass
-  const int unit = block / PARTS, part = block % PARTS;
+  // (round 6: one more workgroup per unit when the bands get a per-pixel weight bound -- it builds the list and
+  // the bound and no tap entries, so the bound is off the tap workgroups' chain)
+  const int NP = PARTS + (a.pix_bound_words > 0 ? 1 : 0);
+  const int unit = block / NP, part = block % NP;
   int li = 0;
   while (li + 1 < a.nlaunch && unit >= a.unit_base[li + 1]) ++li;
   const int lvl = a.order[li];
@@ -215,9 +218,76 @@ __device__ __forceinline__ void bwd_lists_block(const BwdFusedArgs& a, int block
   bwd_band_list<PH, PW, THREADS>(a, lvl, img, nbands, row0, row1, rb0, list, nlist, nlist + 8);
   int* dst = a.ws_list + (long)unit * (a.R + 2);
   const int nl = nlist[0];
+  // Round 6: the weight bound PER PIXEL.  bwd_band_list sums nx * ny over every RoI of the band (1,000-1,800 at
+  // the baseline), but a RoI can put weight only on the pixels of its own clipped box +-2: every RoI adds its
+  // nx * ny to its rectangle of a 2-D difference array of the band, a row prefix (wave scans) and a column
+  // prefix (only its maximum is kept) give the largest bound any pixel of the band can reach -- typically 20-100.
+  // The fixed-point unit of the channel workgroups is 2^-30 of (max|dY| x this bound): an order of magnitude
+  // finer, and an order of magnitude more dynamic range before a workgroup has to take the float adds
+  // (kFxRangeBits).  Done by the unit's extra workgroup (part == PARTS), once per unit and launch.
+  const int H = a.L.H[lvl], W = a.L.W[lvl];
+  const int DW = W + 1, DH = row1 - row0 + 1;
+  const bool pix = DW * DH <= a.pix_bound_words;
   if (part == 0) {
-    if (tid < 2) dst[tid] = nlist[tid];
+    if (tid == 0) dst[0] = nl;
+    if (tid == 1 && !pix) dst[1] = nlist[1];
     for (int i = tid; i < nl; i += THREADS) dst[2 + i] = list[i];
+  }
+  if (part == PARTS && !pix) return;   // this level's bands are too large for the difference array
+  if (part == PARTS) {
+    constexpr int NW = THREADS / kWave;
+    const int wave = tid / kWave, lane = tid & (kWave - 1);
+    int* D = nlist + 8 + 16;
+    for (int i = tid; i < DW * DH; i += THREADS) D[i] = 0;
+    __syncthreads();
+    const float scale = a.L.scale[lvl];
+    for (int j = tid; j < nl; j += THREADS) {
+      const float4 rb = *reinterpret_cast<const float4*>(a.rois + ((long)img * a.R + list[j]) * 4);
+      // pixels the taps of this RoI can reach: the clipped box +-2 (the list's own row test); anything else
+      // (NaN / inf coordinates) counts on the whole band
+      const float xs = fminr(fmaxr(rb.x * scale, 0.f), (float)(W - 1)), xe = fminr(fmaxr(rb.z * scale, 0.f), (float)(W - 1));
+      const float ys = fminr(fmaxr(rb.y * scale, 0.f), (float)(H - 1)), ye = fminr(fmaxr(rb.w * scale, 0.f), (float)(H - 1));
+      const float xlo = fminr(xs, xe) - 2.f, xhi = fmaxr(xs, xe) + 2.f;
+      const float ylo = fminr(ys, ye) - 2.f, yhi = fmaxr(ys, ye) + 2.f;
+      int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
+      if (xlo >= -2.f && xhi <= (float)(W + 1)) { x0 = imaxr((int)floorf(xlo), 0); x1 = iminr((int)ceilf(xhi), W - 1); }
+      if (ylo >= -2.f && yhi <= (float)(H + 1)) { y0 = imaxr((int)floorf(ylo), 0); y1 = iminr((int)ceilf(yhi), H - 1); }
+      y0 = imaxr(y0, row0) - row0;
+      y1 = iminr(y1, row1 - 1) - row0;
+      if (y0 > y1) continue;
+      const float bwx = (rb.z - rb.x) * scale * (1.f / (float)PW), bwy = (rb.w - rb.y) * scale * (1.f / (float)PH);
+      const float fx = 2.00002f * __builtin_amdgcn_rcpf(bwx), fy = 2.00002f * __builtin_amdgcn_rcpf(bwy);
+      const int nx = (bwx > 0.f && fx < (float)PW) ? iminr((int)fx + 2, PW) : PW;
+      const int ny = (bwy > 0.f && fy < (float)PH) ? iminr((int)fy + 2, PH) : PH;
+      const int w = nx * ny;
+      atomicAdd(D + y0 * DW + x0, w);
+      atomicAdd(D + y0 * DW + x1 + 1, -w);
+      atomicAdd(D + (y1 + 1) * DW + x0, -w);
+      atomicAdd(D + (y1 + 1) * DW + x1 + 1, w);
+    }
+    __syncthreads();
+    for (int y = wave; y < DH; y += NW) {  // inclusive prefix along the row, 64 columns per step
+      int carry = 0;
+      for (int xb = 0; xb < DW; xb += kWave) {
+        const int x = xb + lane;
+        const int v = wave_scan_i32(x < DW ? D[y * DW + x] : 0) + carry;
+        if (x < DW) D[y * DW + x] = v;
+        carry = __builtin_amdgcn_readlane(v, kWave - 1);
+      }
+    }
+    __syncthreads();
+    int m = 0;
+    for (int x = tid; x < DW; x += THREADS) {  // prefix down the columns: only its maximum is kept
+      int run = 0;
+      for (int y = 0; y < DH; ++y) {
+        run += D[y * DW + x];
+        m = imaxr(m, run);
+      }
+    }
+    if (m > 0) atomicMax(nlist + 5, m);
+    __syncthreads();
+    if (tid == 0) dst[1] = iminr(nlist[1], nlist[5]);
+    return;
   }
   // ... and the tap entries of the listed RoIs (see roi_align_bwd_packed4): per sample coordinate
   // {neighbours, fraction} with the backward's own expressions, the row neighbours as offsets
@@ -271,8 +341,8 @@ __global__ __launch_bounds__(kBandThreads) void roi_prep_merged_kernel(BandArgs 
 int launch_fwd_prep(const BandArgs& A, int pool, int nblocks, const BwdFusedArgs* bplan, hipStream_t st) {
   const FwdArgs& a = A.f;
   if (bplan) {
-    const dim3 g((unsigned)(nblocks + bplan->lists_units * kMergedListSplit));
-    const size_t lds = (size_t)(a.R + 8 + 16) * 4;
+    const dim3 g((unsigned)(nblocks + bplan->lists_units * (kMergedListSplit + (bplan->pix_bound_words > 0 ? 1 : 0))));
+    const size_t lds = (size_t)(a.R + 8 + 16 + bplan->pix_bound_words) * 4;
     if (pool == 7) hipLaunchKernelGGL((roi_prep_merged_kernel<7>), g, dim3(kBandThreads), lds, st, A, *bplan, nblocks);
     else hipLaunchKernelGGL((roi_prep_merged_kernel<14>), g, dim3(kBandThreads), lds, st, A, *bplan, nblocks);
   } else {
@@ -284,8 +354,8 @@ int launch_fwd_prep(const BandArgs& A, int pool, int nblocks, const BwdFusedArgs
 }
 
 int launch_bwd_lists(const BwdFusedArgs& a, int units, hipStream_t st) {
-  const size_t lds = (size_t)(a.R + 8 + 16) * 4;
-  const dim3 g((unsigned)units * kListSplit);
+  const size_t lds = (size_t)(a.R + 8 + 16 + a.pix_bound_words) * 4;
+  const dim3 g((unsigned)units * (kListSplit + (a.pix_bound_words > 0 ? 1 : 0)));
   if (a.PP == 49) hipLaunchKernelGGL((roi_align_bwd_lists<7, 7>), g, dim3(512), lds, st, a);
   else hipLaunchKernelGGL((roi_align_bwd_lists<14, 14>), g, dim3(512), lds, st, a);
   SD_LAUNCH_CHECK();

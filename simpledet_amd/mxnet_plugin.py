@@ -1170,8 +1170,23 @@ def install(mx=None):
                 if name_kw is not None:
                     native["name"] = name_kw
                 return original(*args, **native)
-            sym = mx.sym.Custom(*args, op_type=_PREFIX + name, name=name_kw, **inputs, **params)
             p = prop(**params)
+            if args and inputs:
+                # MXNet composes a variadic operator (Custom is `*data`) from positional OR keyword Symbols, never
+                # both (Symbol._compose raises TypeError) -- and the reference mixes them for the built-in it
+                # believes it is calling (models/sepc/sepc_dconv.py:12-16: DeformableConvolution(x, offset,
+                # weight=weight, bias=bias, ...)): positional inputs take the operator's argument names in order
+                names = list(p.list_arguments())
+                if len(args) > len(names):
+                    raise TypeError("%s takes %d inputs (%s), %d given positionally" % (name, len(names), names, len(args)))
+                for k, v in zip(names, args):
+                    if k in inputs:
+                        raise TypeError("%s: input '%s' given positionally and by keyword" % (name, k))
+                    inputs[k] = v
+                # keyword composition matches by name; keep the operator's own order for readability of the graph
+                inputs = {k: inputs[k] for k in names if k in inputs} | {k: v for k, v in inputs.items() if k not in names}
+                args = ()
+            sym = mx.sym.Custom(*args, op_type=_PREFIX + name, name=name_kw, **inputs, **params)
             nvis = getattr(p, "num_visible_outputs", len(p.list_outputs()))
             nout = len(p.list_outputs())
             if nvis == nout:

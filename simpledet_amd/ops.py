@@ -766,14 +766,22 @@ def deform_im2col(x, offset, kernel=(3, 3), pad=1, stride=1, dilate=1, num_defor
 
 
 def deform_col2im(col, offset, x_shape, kernel=(3, 3), pad=1, stride=1, dilate=1,
-                  num_deformable_group=1):
+                  num_deformable_group=1, workspace=True):
     _chk(col, "col", ndim=3)
     _chk(offset, "offset", ndim=4)
     N, C, H, W = [int(v) for v in x_shape]
     kh, kw = kernel
     dx = torch.empty((N, C, H, W), device=col.device, dtype=torch.float32)
-    lib().call("sd_deform_col2im", _p(col), _p(offset), _p(dx), REQ["write"], N, C, H, W, kh, kw, pad,
-               pad, stride, stride, dilate, dilate, int(num_deformable_group), _stream())
+    if not workspace:   # fp32 compare-and-swap adds (what a caller without a workspace gets)
+        lib().call("sd_deform_col2im", _p(col), _p(offset), _p(dx), REQ["write"], N, C, H, W, kh, kw, pad,
+                   pad, stride, stride, dilate, dilate, int(num_deformable_group), _stream())
+        return dx
+    lib().cdll.sd_deform_col2im_workspace_bytes.restype = ctypes.c_size_t
+    n = int(lib().cdll.sd_deform_col2im_workspace_bytes(N, int(num_deformable_group)))
+    ws = torch.empty(n, device=col.device, dtype=torch.uint8)
+    lib().call("sd_deform_col2im_ws", _p(col), _p(offset), _p(dx), REQ["write"], N, C, H, W, kh, kw, pad,
+               pad, stride, stride, dilate, dilate, int(num_deformable_group), _p(ws), ctypes.c_size_t(n),
+               _stream())
     return dx
 
 

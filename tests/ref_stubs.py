@@ -225,6 +225,9 @@ def make_mx():
 
     def Custom(*args, op_type=None, name=None, **kwargs):
         prop_cls = registry[op_type]
+        if args and any(isinstance(v, Symbol) for v in kwargs.values()):
+            # mxnet/symbol/symbol.py, Symbol._compose: a variadic operator takes its input Symbols
+            raise TypeError("compose only accept input Symbols either as positional or keyword arguments, not both")
         ins = _flatten_syms(args) + [v for v in kwargs.values() if isinstance(v, Symbol)]
         _single_output_inputs(op_type, ins)
         params = {k: v for k, v in kwargs.items() if not isinstance(v, Symbol)}

@@ -123,9 +123,15 @@ def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
                      for n in range(x.shape[0])])
     np.testing.assert_array_equal(col, want)  # same float ops in the same order: bit exact
     g = np.random.RandomState(8).standard_normal(col.shape).astype(np.float32)
-    dx = ops.deform_col2im(_t(g), _t(off), x.shape, **a).cpu().numpy()
     wdx = np.stack([oracle.deform_col2im(g[n], off[n], x[n].shape, **kw) for n in range(x.shape[0])])
-    np.testing.assert_allclose(dx, wdx, rtol=1e-4, atol=1e-4)
+    # sd_deform_col2im_ws (round 6: fixed-point sums where the four-channel kernel applies) and the
+    # workspace-free sd_deform_col2im (fp32 compare-and-swap adds)
+    for ws in (True, False):
+        dx = ops.deform_col2im(_t(g), _t(off), x.shape, workspace=ws, **a).cpu().numpy()
+        np.testing.assert_allclose(dx, wdx, rtol=1e-4, atol=1e-4)
+    again = ops.deform_col2im(_t(g), _t(off), x.shape, workspace=True, **a).cpu().numpy()
+    if (x.shape[1] // kw["dgroup"]) % 4 == 0 and (col.shape[2] % 4) == 0 and kw["kernel"] == (3, 3):
+        np.testing.assert_array_equal(again, ops.deform_col2im(_t(g), _t(off), x.shape, workspace=True, **a).cpu().numpy())
     do = ops.deform_col2im_coord(_t(g), _t(x), _t(off), **a).cpu().numpy()
     wdo = np.stack([oracle.deform_col2im_coord(g[n], x[n], off[n], **kw) for n in range(x.shape[0])])
     np.testing.assert_allclose(do, wdo, rtol=1e-4, atol=1e-4)
@@ -549,6 +555,44 @@ def test_nocol_entry_takes_any_kernel_shape(ops, oracle, kshape):
     want = oracle.deform_conv_fwd(x, off, w, pad=0, stride=1, dil=1, dgroup=dg)
     assert y.shape == want.shape
     assert np.abs(y - want).max() <= _bar(want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 6, 8, 2), (4, 6, 7, 1)])
+def test_boundary_rules_on_the_gpu(ops, oracle, shape):
+    """GPU twin of tests/test_deform_conv_autograd.py::test_boundary_rules_known_answers (which ties the oracle to
+    hand-worked values of upstream's rules R1-R5): every (tap, pixel) of this tensor samples a coordinate from the
+    boundary set {-0.5, -0.001, 0, H-1, H-0.5, H, H+0.5, interior} x the same for w, every combination present.
+    im2col bit-equal, col2im / col2im_coord within 1e-6 of the oracle (sums of <= 72 terms), on the LDS-plane
+    kernels ((8,6,8): H*W % 4 == 0, four channels per group) and on the per-lane kernels ((4,6,7))."""
+    C, H, W, dg = shape
+    rs = np.random.RandomState(90)
+    x = rs.standard_normal((1, C, H, W)).astype(np.float32)
+    hs = [-0.5, -1e-3, 0.0, H - 1.0, H - 0.5, float(H), H + 0.5, 2.25]
+    ws = [-0.5, -1e-3, 0.0, W - 1.0, W - 0.5, float(W), W + 0.5, 3.5]
+    off = np.zeros((1, dg * 18, H, W), np.float32)
+    k = 0
+    for g_ in range(dg):
+        for t in range(9):
+            for ho in range(H):
+                for wo in range(W):
+                    th, tw = hs[k % 8], ws[(k // 8) % 8]
+                    k += 1 + (g_ == 1)   # another walk through the combinations in the second group
+                    off[0, g_ * 18 + 2 * t, ho, wo] = np.float32(th - (ho - 1 + t // 3))
+                    off[0, g_ * 18 + 2 * t + 1, ho, wo] = np.float32(tw - (wo - 1 + t % 3))
+    assert k >= 64
+    kw = dict(kernel=(3, 3), pad=1, stride=1, dil=1, dgroup=dg)
+    a = dict(kernel=(3, 3), pad=1, stride=1, dilate=1, num_deformable_group=dg)
+    col = ops.deform_im2col(_t(x), _t(off), **a).cpu().numpy()
+    wcol = oracle.deform_im2col(x[0], off[0], **kw)
+    np.testing.assert_array_equal(col[0], wcol)
+    assert (wcol == 0).mean() > 0.3 and (wcol != 0).mean() > 0.1     # both sides of every border are populated
+    g = rs.standard_normal(col.shape).astype(np.float32)
+    for ws_ in (True, False):
+        dx = ops.deform_col2im(_t(g), _t(off), x.shape, workspace=ws_, **a).cpu().numpy()
+        np.testing.assert_allclose(dx[0], oracle.deform_col2im(g[0], off[0], x[0].shape, **kw), atol=2e-5)
+    do = ops.deform_col2im_coord(_t(g), _t(x), _t(off), **a).cpu().numpy()
+    np.testing.assert_allclose(do[0], oracle.deform_col2im_coord(g[0], x[0], off[0], **kw), atol=2e-5)
 
 
 @pytest.mark.gpu
