@@ -133,12 +133,13 @@ class _DeformConv(torch.autograd.Function):
                 g[3] if has_bias and need[3] else None, None, None, None, None, None, None)
 
 
-def DeformableConvolution(data, offset, weight, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
+def DeformableConvolution(data, offset, weight, *, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
                           pad=(0, 0), num_filter=None, num_group=1, num_deformable_group=1,
                           no_bias=False):
     """mx.sym.contrib.DeformableConvolution with upstream's parameter set (no_bias defaults to False
     there): models/dcn/builder.py:14-17 (no_bias=True, 4 deformable groups), models/RepPoints/builder.py:
-    215-245 (bias), models/sepc/sepc_dconv.py:12-16 (num_group / bias passed through)."""
+    215-245 (bias), models/sepc/sepc_dconv.py:12-16 (num_group / bias passed through).  Everything behind the
+    three tensors is keyword-only: a positional `kernel` must not land in `bias`."""
     if no_bias:
         if bias is not None:
             raise ValueError("no_bias=True but a bias was given")

@@ -709,7 +709,7 @@ void deform_im2col_pipe_kernel(const float* __restrict__ x, const float* __restr
   // bytes per lane: `profiles/r05u_*`).  Every wave writes exactly three rows (T / 64 = 4 waves, 9 taps: wave w
   // writes taps 2 w and 2 w + 1 and its own quarter of tap 8), so the count of stores per trip stays static.
   static_assert(T == 256, "store schedule: four waves, nine taps");
-  float* stg = xs + plane + g.W + 8;   // [K2][T]
+  float* stg = xs + ((plane + g.W + 8 + 3) & ~3);   // [K2][T], 16-byte aligned for the ds_read_b128 row reads whatever W is
   int info[kDcnMaxTaps];
   float lh[K2], lw[K2];
   {
@@ -945,10 +945,10 @@ extern "C" int sd_deform_im2col(const float* x, const float* offset, float* col,
     // (channel splits per (image, group, pixel tile): 2-8 measured in round 3, no gain -- one)
     const int nsplit = 1;
     if (kh * kw == 9 && kw == 3 && vec == 1 && nt == 1 && C / dgroup >= 2 && P % 4 == 0 && ((uintptr_t)col & 15) == 0 &&
-        lds + 9 * T * sizeof(float) <= 31 * 1024 && tuning("dcn_im2col", 1) == 1 &&
+        lds + 16 + 9 * T * sizeof(float) <= 31 * 1024 && tuning("dcn_im2col", 1) == 1 &&
         tuning("dcn_im2col_pipe", 1) == 1)
-      hipLaunchKernelGGL((deform_im2col_pipe_kernel<T>), dim3(cdiv(P, T), dgroup, N), dim3(T), lds + 9 * T * sizeof(float),
-                         (hipStream_t)stream, x, offset, col, g);
+      hipLaunchKernelGGL((deform_im2col_pipe_kernel<T>), dim3(cdiv(P, T), dgroup, N), dim3(T),
+                         lds + 16 + 9 * T * sizeof(float), (hipStream_t)stream, x, offset, col, g);
     else if (kh * kw == 9)
       hipLaunchKernelGGL((deform_im2col_lds_kernel<T, 9>), dim3(cdiv(P, T), dgroup * nsplit, N),
                          dim3(T), lds, (hipStream_t)stream, x, offset, col, g, nsplit, vec, nt);

@@ -1098,7 +1098,7 @@ extern "C" int sd_get_top_proposal(const float* bbox, const float* score, int B,
   while (P2t < top_n) P2t <<= 1;
   // fewer rows wanted than given: radix select, then sort the survivors only (N is then bounded by
   // the 2^24 rows of the select, not by the LDS sort capacity)
-  const int select = (top_n < N && P2t < P2 && true) ? 1 : 0;
+  const int select = (top_n < N && P2t < P2) ? 1 : 0;
   if (select) P2 = P2t;
   SD_REQUIRE(P2 <= kMaxSortKeys, "get_top_proposal: N=%d / top_n=%d exceeds %d", N, top_n,
              kMaxSortKeys);

@@ -17,8 +17,22 @@ Python CustomOp `assign_layer_fpn`).  Its only run-time extension hook is `mx.op
 in the build container; tests drive the adapter through a tiny stub of the mx.operator interface).
 
 Data path: NDArray -> raw device pointer through MXNet's C API (MXNDArrayGetData) -> C ABI on the
-NULL stream -> sd_stream_synchronize before forward()/backward() return, because MXNet treats a
-CustomOp's outputs as written when the callback returns (threading).
+stream `install(stream=...)` names (default: the NULL stream) -> sd_stream_synchronize on that stream before
+forward()/backward() return, because MXNet treats a CustomOp's outputs as written when the callback returns
+(threading).
+
+The ordering ASSUMPTION of the default (stated because no MXNet build is available here to check it): MXNet's
+engine has made the inputs ready before it calls the callback (`wait_to_read` on every input is a no-op then, and is
+issued anyway); the kernels are launched on the legacy NULL stream, which the HIP runtime orders against every
+blocking stream of the device -- MXNet's per-device compute streams are created blocking
+(`mshadow::Stream<gpu>`: hipStreamCreate, not hipStreamNonBlocking) -- and the host-side synchronise at the end
+makes the outputs complete before the engine marks them written.  That serialises the device per op, which is
+the price of the only run-time hook the reference has.  The library itself needs none of it: every entry point
+takes the stream and neither synchronises nor touches another stream (tests/test_mxnet_plugin.py runs the adapter's
+ops back to back on a side stream with the per-op synchronise switched off).  A host that can hand the adapter
+the stream MXNet orders the op's outputs on -- `install(stream=<int | callable>, sync=False)` -- gets asynchronous
+launches; the FCompute shim of INTEGRATION.md (B) is that design inside MXNet (`ctx.get_stream<gpu>()`,
+roi_align_v2-inl.h:182).
 """
 import ctypes
 import os
@@ -28,7 +42,7 @@ from ._lib import SD_ERR_UNSUPPORTED, SimpleDetOpsError, lib
 
 REQ = {"null": 0, "write": 1, "inplace": 2, "add": 3}
 _PREFIX = "sd_"
-_state = {"mx": None, "registered": False, "rng": {}}
+_state = {"mx": None, "registered": False, "rng": {}, "stream": None, "sync": True}
 
 
 # ------------------------------------------------------------------------------------ helpers ----
@@ -57,8 +71,29 @@ def _req(r):
     return REQ[r] if isinstance(r, str) else int(r)
 
 
+def _stream():
+    """hipStream_t the adapter launches on: install(stream=...) -- None = the NULL stream, an int / c_void_p, or
+    a callable evaluated per call (e.g. `lambda: torch.cuda.current_stream().cuda_stream`)."""
+    st = _state.get("stream")
+    if callable(st):
+        st = st()
+    if st is None or isinstance(st, ctypes.c_void_p):
+        return st
+    return ctypes.c_void_p(int(st))
+
+
+def _call(name, *args):
+    """lib().call with the adapter's stream in place of a trailing None where the entry point's last parameter is
+    `void* stream` (read off include/simpledet_ops.h)."""
+    proto = lib().protos.get(name)
+    if args and args[-1] is None and proto and proto[1] and proto[1][-1][0] == "stream":
+        args = args[:-1] + (_stream(),)
+    return lib().call(name, *args)
+
+
 def _sync():
-    lib().call("sd_stream_synchronize", None)
+    if _state.get("sync", True):
+        lib().call("sd_stream_synchronize", _stream())
 
 
 def _tuple(v, n=None, typ=float):
@@ -123,7 +158,7 @@ def _build_ops(mx):
             R = rois.shape[1]
             wsb = lib().cdll.sd_roi_align_v2_workspace_bytes(B, R)
             ws = _scratch(data, wsb)
-            lib().call("sd_roi_align_v2_fwd_ws", _ptr(data), _ptr(rois), _ptr(out_data[0]),
+            _call("sd_roi_align_v2_fwd_ws", _ptr(data), _ptr(rois), _ptr(out_data[0]),
                        _ptr(out_data[1]), _ptr(out_data[2]), B, C, H, W, R, self.ph, self.pw,
                        float(self.scale), _ptr(ws), ctypes.c_size_t(wsb), None)
             _sync()
@@ -133,7 +168,7 @@ def _build_ops(mx):
             _wait(out_grad[0], rois, out_data[1], out_data[2])
             B, C, H, W = data.shape
             R = rois.shape[1]
-            lib().call("sd_roi_align_v2_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+            _call("sd_roi_align_v2_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
                        _ptr(out_data[2]), _ptr(in_grad[0]), _ptr(in_grad[1]), _req(req[0]),
                        _req(req[1]), B, C, H, W, R, self.ph, self.pw, float(self.scale), None)
             _sync()
@@ -186,7 +221,7 @@ def _build_ops(mx):
             data, rois = in_data
             _wait(data, rois)
             B, C, H, W = data.shape
-            lib().call("sd_roi_pool_v1_fwd", _ptr(data), _ptr(rois), _ptr(out_data[0]),
+            _call("sd_roi_pool_v1_fwd", _ptr(data), _ptr(rois), _ptr(out_data[0]),
                        _ptr(out_data[1]), B, C, H, W, rois.shape[0], self.ph, self.pw,
                        float(self.scale), None)
             _sync()
@@ -195,7 +230,7 @@ def _build_ops(mx):
             data, rois = in_data
             _wait(out_grad[0], rois, out_data[1])
             B, C, H, W = data.shape
-            lib().call("sd_roi_pool_v1_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+            _call("sd_roi_pool_v1_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
                        _ptr(in_grad[0]), _ptr(in_grad[1]), _req(req[0]), _req(req[1]), B, C, H, W,
                        rois.shape[0], self.ph, self.pw, float(self.scale), None)
             _sync()
@@ -261,18 +296,18 @@ def _build_ops(mx):
                 # libc's global rand() state of a process that never called srand (seed 1): one
                 # stream per device, shared by every ProposalTarget node like the libc global is
                 host = (ctypes.c_int32 * 33)()
-                lib().call("sd_glibc_srand_host", ctypes.c_uint32(1), host)
+                _call("sd_glibc_srand_host", ctypes.c_uint32(1), host)
                 _state["rng"][key] = _state["mx"].nd.array(list(host), ctx=rois.context, dtype="int32")
             rng = _state["rng"][key]
             wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
             ws = _scratch(rois, wsb)
             if vr is not None:
-                lib().call("sd_proposal_target_v2", _ptr(rois), _ptr(gt), _ptr(vr),
+                _call("sd_proposal_target_v2", _ptr(rois), _ptr(gt), _ptr(vr),
                            int(p.get("filter_scales", False)), N, M, ctypes.byref(cp), _ptr(rng),
                            _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
                            _ptr(out_data[4]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
             else:
-                lib().call("sd_proposal_target", _ptr(rois), _ptr(gt), N, M, ctypes.byref(cp), _ptr(rng),
+                _call("sd_proposal_target", _ptr(rois), _ptr(gt), N, M, ctypes.byref(cp), _ptr(rng),
                            _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
                            _ptr(out_data[4]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
             _sync()
@@ -374,7 +409,7 @@ def _build_ops(mx):
             key = str(rois.context)
             if key not in _state["rng"]:
                 host = (ctypes.c_int32 * 33)()
-                lib().call("sd_glibc_srand_host", ctypes.c_uint32(1), host)
+                _call("sd_glibc_srand_host", ctypes.c_uint32(1), host)
                 _state["rng"][key] = _state["mx"].nd.array(list(host), ctx=rois.context, dtype="int32")
             rng = _state["rng"][key]
             if p["output_ratio"]:  # proposal_mask_target-inl.h:159-161: the seventh output, kWriteTo
@@ -383,7 +418,7 @@ def _build_ops(mx):
                 wsb = lib().cdll.sd_proposal_mask_target_ratio_workspace_bytes(
                     B, N, M, p["image_rois"], ctypes.c_float(p["fg_fraction"]), mp)
                 ws = _scratch(rois, wsb)
-                lib().call("sd_proposal_mask_target_ratio", _ptr(rois), _ptr(gt), _ptr(polys), _ptr(vr),
+                _call("sd_proposal_mask_target_ratio", _ptr(rois), _ptr(gt), _ptr(polys), _ptr(vr),
                            int(p["filter_scales"]), N, M, L, p["mask_size"], ctypes.byref(cp), _ptr(rng),
                            _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
                            _ptr(out_data[4]), _ptr(out_data[5]), _ptr(out_data[6]), mp, None, _ptr(ws),
@@ -392,7 +427,7 @@ def _build_ops(mx):
                 return
             wsb = lib().cdll.sd_proposal_target_workspace_bytes(B, N, M)
             ws = _scratch(rois, wsb)
-            lib().call("sd_proposal_mask_target", _ptr(rois), _ptr(gt), _ptr(polys), _ptr(vr),
+            _call("sd_proposal_mask_target", _ptr(rois), _ptr(gt), _ptr(polys), _ptr(vr),
                        int(p["filter_scales"]), N, M, L, p["mask_size"], ctypes.byref(cp), _ptr(rng),
                        _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), _ptr(out_data[3]),
                        _ptr(out_data[4]), _ptr(out_data[5]), None, _ptr(ws), ctypes.c_size_t(wsb), None)
@@ -468,7 +503,7 @@ def _build_ops(mx):
             _no_add(req)
             _require_write(req[:1], ["output"])
             H, W = in_data[0].shape[2], in_data[0].shape[3]
-            lib().call("sd_gen_anchor", _ptr(out_data[0]), H, W, self.stride, _darr(self.scales),
+            _call("sd_gen_anchor", _ptr(out_data[0]), H, W, self.stride, _darr(self.scales),
                        len(self.scales), _darr(self.ratios), len(self.ratios), None)
             _sync()
 
@@ -523,7 +558,7 @@ def _build_ops(mx):
                 # (uninitialised in the reference) is zeroed.
                 self.assign(out_data[0], "write", 0)
                 self.assign(out_data[1], "write", 0)
-            lib().call("sd_nms", _ptr(rois), B, N, self.pre, self.post, float(self.thr), 0,
+            _call("sd_nms", _ptr(rois), B, N, self.pre, self.post, float(self.thr), 0,
                        int(self.sorted), _ptr(out_data[0]), _ptr(out_data[1]), None, _ptr(ws),
                        ctypes.c_size_t(wsb), None)
             _sync()
@@ -575,7 +610,7 @@ def _build_ops(mx):
                 n *= int(s)
             mx_ = _state["mx"]
             per = mx_.nd.empty((len(self.strides),) + tuple(rois.shape), ctx=rois.context)
-            lib().call("sd_fpn_roi_assign", _ptr(rois), n, _iarr(self.strides), len(self.strides),
+            _call("sd_fpn_roi_assign", _ptr(rois), n, _iarr(self.strides), len(self.strides),
                        float(self.scale0), float(self.lvl0), _ptr(per), None, None)
             _sync()
             for i in range(len(self.strides)):
@@ -643,7 +678,7 @@ def _build_ops(mx):
             n = int(lib().cdll.sd_deform_convolution_fwd_workspace_bytes(
                 N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], g["G"], keep))
             ws = _scratch(x, n)
-            lib().call("sd_deform_convolution_fwd", _ptr(x), _ptr(off), _ptr(w), _ptr(b), _ptr(out_data[0]), N, C,
+            _call("sd_deform_convolution_fwd", _ptr(x), _ptr(off), _ptr(w), _ptr(b), _ptr(out_data[0]), N, C,
                        H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], g["G"], keep,
                        _ptr(ws), ctypes.c_size_t(n), None)
             self._fwd_ws = (ws, tuple(x.shape)) if keep else None
@@ -661,7 +696,7 @@ def _build_ops(mx):
             if kept is not None and kept[1] == tuple(x.shape):
                 col = ctypes.c_void_p(lib().cdll.sd_deform_conv_col_of_workspace(_ptr(kept[0])))
             has_b = g["bias"]
-            lib().call("sd_deform_convolution_bwd", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w), col,
+            _call("sd_deform_convolution_bwd", _ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w), col,
                        _ptr(in_grad[0]), _ptr(in_grad[1]), _ptr(in_grad[2]), _ptr(in_grad[3]) if has_b else None,
                        _req(req[0]), _req(req[1]), _req(req[2]), _req(req[3]) if has_b else REQ["null"],
                        N, C, H, W, g["F"], g["kh"], g["kw"], g["pad"], g["stride"], g["dil"], g["dg"], g["G"],
@@ -782,7 +817,7 @@ def _build_ops(mx):
             fn = "sd_fpn_roi_align_fwd_packed" if self.packed else "sd_fpn_roi_align_fwd"
 
             def run(name, level_ptrs, out0):
-                lib().call(name, level_ptrs, Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois),
+                _call(name, level_ptrs, Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois),
                            _ptr(out0), _ptr(out_data[1]), _ptr(out_data[2]), B, C, rois.shape[1],
                            self.pooled[0], self.pooled[1], float(self.scale0), float(self.lvl0),
                            _ptr(ws), ctypes.c_size_t(wsb), None)
@@ -791,7 +826,7 @@ def _build_ops(mx):
                 # training: ONE rois-only pre-pass for the step -- the backward's band lists / tap
                 # tables are built here, into the op's fourth (private) output
                 plan = out_data[3]
-                lib().call(fn + "_plan", ptrs, Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois),
+                _call(fn + "_plan", ptrs, Hs, Ws, _iarr(self.strides), len(feats), _ptr(rois),
                            _ptr(out_data[0]), _ptr(out_data[1]), _ptr(out_data[2]), B, C, rois.shape[1],
                            self.pooled[0], self.pooled[1], float(self.scale0), float(self.lvl0),
                            _ptr(ws), ctypes.c_size_t(wsb), _ptr(plan), ctypes.c_size_t(plan.size), None)
@@ -809,11 +844,11 @@ def _build_ops(mx):
                     # carries itself (models/FPN/builder.py:581-586, 607-608) around the fp32 op
                     f32 = [_scratch(rois, f.size * 4).reshape(f.shape) for f in feats]
                     for f, g in zip(feats, f32):
-                        lib().call("sd_cast_f16_to_f32", _ptr(f), _ptr(g), ctypes.c_size_t(f.size), None)
+                        _call("sd_cast_f16_to_f32", _ptr(f), _ptr(g), ctypes.c_size_t(f.size), None)
                     o32 = _scratch(rois, out_data[0].size * 4).reshape(out_data[0].shape)
                     p32 = (ctypes.c_void_p * len(f32))(*[_ptr(g).value for g in f32])
                     run(fn, p32, o32)
-                    lib().call("sd_cast_f32_to_f16", _ptr(o32), _ptr(out_data[0]),
+                    _call("sd_cast_f32_to_f16", _ptr(o32), _ptr(out_data[0]),
                                ctypes.c_size_t(o32.size), REQ["write"], None)
             _sync()
 
@@ -834,7 +869,7 @@ def _build_ops(mx):
                 wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(Hs16, Ws16, len(feats), B, rois.shape[1])
                 ws = _scratch(rois, wsb)
                 try:
-                    lib().call("sd_fpn_roi_align_bwd_packed_f16", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                    _call("sd_fpn_roi_align_bwd_packed_f16", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
                                _ptr(out_data[2]), ptrs16, Hs16, Ws16, _iarr(self.strides), len(feats), req_data,
                                B, C, rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
                                float(self.lvl0), _ptr(ws), ctypes.c_size_t(wsb), None)
@@ -848,7 +883,7 @@ def _build_ops(mx):
                 # the sums are formed by the fp32 kernel: the graph's to_fp32 / to_fp16 casts
                 # (models/FPN/builder.py:581-586, 607-608) happen here, at the op boundary
                 og = _scratch(rois, out_grad[0].size * 4).reshape(out_grad[0].shape)
-                lib().call("sd_cast_f16_to_f32", _ptr(out_grad[0]), _ptr(og), ctypes.c_size_t(out_grad[0].size), None)
+                _call("sd_cast_f16_to_f32", _ptr(out_grad[0]), _ptr(og), ctypes.c_size_t(out_grad[0].size), None)
                 grads16 = in_grad[:-1]
                 in_grad = [_scratch(rois, g.size * 4).reshape(g.shape) for g in grads16] + [in_grad[-1]]
                 rq = {REQ["write"]}
@@ -858,7 +893,7 @@ def _build_ops(mx):
             out_grad = [og]
             if self.packed and not self.fp16 and getattr(self, "_planned", False):
                 plan = out_data[3]   # lists / tap tables left by this op's forward
-                lib().call("sd_fpn_roi_align_bwd_packed_plan", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                _call("sd_fpn_roi_align_bwd_packed_plan", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
                            _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B, C,
                            rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
                            float(self.lvl0), _ptr(plan), ctypes.c_size_t(plan.size), None)
@@ -866,18 +901,18 @@ def _build_ops(mx):
                 lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes.restype = ctypes.c_size_t
                 wsb = lib().cdll.sd_fpn_roi_align_bwd_workspace_bytes(Hs, Ws, len(feats), B, rois.shape[1])
                 ws = _scratch(rois, wsb)
-                lib().call("sd_fpn_roi_align_bwd_packed_ws", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                _call("sd_fpn_roi_align_bwd_packed_ws", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
                            _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B, C,
                            rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
                            float(self.lvl0), _ptr(ws), ctypes.c_size_t(wsb), None)
             else:
-                lib().call("sd_fpn_roi_align_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
+                _call("sd_fpn_roi_align_bwd", _ptr(out_grad[0]), _ptr(rois), _ptr(out_data[1]),
                            _ptr(out_data[2]), ptrs, Hs, Ws, _iarr(self.strides), len(feats), rq.pop(), B, C,
                            rois.shape[1], self.pooled[0], self.pooled[1], float(self.scale0),
                            float(self.lvl0), None)
             if self.fp16:
                 for g32, g16 in zip(in_grad[:-1], grads16):
-                    lib().call("sd_cast_f32_to_f16", _ptr(g32), _ptr(g16), ctypes.c_size_t(g16.size), req_data, None)
+                    _call("sd_cast_f32_to_f16", _ptr(g32), _ptr(g16), ctypes.c_size_t(g16.size), req_data, None)
             _sync()
             self.assign(in_grad[-1], req[-1], 0)
 
@@ -959,7 +994,7 @@ def _build_ops(mx):
                 self.assign(out_data[0], "write", 0)
                 self.assign(out_data[1], "write", 0)
             fa = lambda v: (ctypes.c_float * len(v))(*v)
-            lib().call("sd_proposal_v3_iou" if g["iou_loss"] else "sd_proposal_v3",
+            _call("sd_proposal_v3_iou" if g["iou_loss"] else "sd_proposal_v3",
                        _ptr(cls_prob), _ptr(bbox_pred), _ptr(im_info),
                        _ptr(out_data[0]), _ptr(out_data[1]), B, A, H, W, g["pre"], g["post"],
                        float(g["thr"]), g["min_size"], fa(g["scales"]), len(g["scales"]),
@@ -1019,7 +1054,7 @@ def _build_ops(mx):
             _no_add(req)
             bbox, score = in_data
             _wait(bbox, score)
-            lib().call("sd_get_top_proposal", _ptr(bbox), _ptr(score), bbox.shape[0], bbox.shape[1],
+            _call("sd_get_top_proposal", _ptr(bbox), _ptr(score), bbox.shape[0], bbox.shape[1],
                        self.top_n, _ptr(out_data[0]), _ptr(out_data[1]), None)
             _sync()
 
@@ -1063,7 +1098,7 @@ def _build_ops(mx):
             _wait(rois, pred, info)
             g = self.g
             fa = lambda v: (ctypes.c_float * 4)(*v)
-            lib().call("sd_decode_bbox", _ptr(rois), _ptr(pred), _ptr(info), _ptr(out_data[0]),
+            _call("sd_decode_bbox", _ptr(rois), _ptr(pred), _ptr(info), _ptr(out_data[0]),
                        rois.shape[0], rois.shape[1], pred.shape[2] // 4, fa(g["mean"]), fa(g["std"]),
                        int(g["agnostic"]), int(g["xyxy"]), None)
             _sync()
@@ -1138,7 +1173,7 @@ def _namespaces(mx, ns):
     return out
 
 
-def install(mx=None):
+def install(mx=None, stream=None, sync=True):
     """register() + alias the reference's symbol constructors to mx.sym.Custom, e.g.
     mx.sym.contrib.ROIAlign_v2(data=d, rois=r, pooled_size=(7,7), spatial_scale=0.25) builds
     mx.sym.Custom(d, r, op_type='sd__contrib_ROIAlign_v2', pooled_size='(7, 7)', ...) and returns
@@ -1147,10 +1182,15 @@ def install(mx=None):
     The constructor an alias replaces is kept (`<namespace>._sd_reference_<name>`, and on the alias as
     `_sd_original`).  An operator whose prop class has `sd_supports(params)` (DeformableConvolution) hands
     a call with parameters the kernels do not take BACK to that constructor: the node is then the native
-    operator, exactly what the graph held without install() (`_state["fallbacks"]` lists them)."""
+    operator, exactly what the graph held without install() (`_state["fallbacks"]` lists them).
+
+    `stream` / `sync`: the hipStream_t every operator launches on (None: the NULL stream; an int; or a callable
+    evaluated per call) and whether forward() / backward() synchronise it before they return (the module
+    docstring has the ordering contract; sync=False is for a host that orders the outputs on `stream` itself)."""
     props = register(mx)
     mx = _state["mx"]
     _state["fallbacks"] = []
+    _state["stream"], _state["sync"] = stream, bool(sync)
 
     def make(name, prop, original):
         def ctor(*args, **kwargs):

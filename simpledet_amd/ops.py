@@ -879,6 +879,9 @@ def deform_conv_backward(out_grad, x, offset, weight, pad=1, stride=1, dilate=1,
         grads = (torch.empty_like(x), torch.empty_like(offset), torch.empty_like(weight))
         if bias:
             grads = grads + (torch.empty(F, device=x.device, dtype=torch.float32),)
+    elif len(grads) != (4 if bias else 3):
+        raise ValueError("grads must hold %d tensors (d_data, d_offset, d_weight%s), got %d"
+                         % (4 if bias else 3, ", d_bias" if bias else "", len(grads)))
     ws, n = _dcn_ws(x, kh, kw, pad, stride, dilate)
     col = None
     if fwd_ws is not None:

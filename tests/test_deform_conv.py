@@ -145,6 +145,7 @@ def test_im2col_col2im_coord_match_oracle(ops, oracle, cfg):
     dict(N=2, C=32, H=28, W=36, F=8, dg=4, off_scale=2.5, stride=2),
     dict(N=1, C=12, H=20, W=24, F=8, dg=2, off_scale=1.0),      # 6 channels per group
     dict(N=1, C=32, H=25, W=42, F=8, dg=4, off_scale=1.0),      # H*W % 4 != 0: scalar window copies
+    dict(N=1, C=16, H=28, W=42, F=8, dg=2, off_scale=1.5),      # H*W % 4 == 0, W % 4 != 0: the pipe kernel's staging rows must still be 16-byte aligned
 ])
 def test_sampling_kernel_families_give_the_same_bits(ops, cfg):
     """deformable im2col and the offset gradient in their two forms -- LDS windows (`dcn_im2col` / `dcn_coord` = 1,
@@ -764,24 +765,24 @@ def test_autograd_mirror_with_bias_and_groups(ops):
     dy = torch.randn_like(y)
     g = ops.deform_conv_backward(dy, x, off, w, bias=True, **a)
     xr, offr, wr, br = (t.clone().requires_grad_(True) for t in (x, off, w, b))
-    out = contrib.DeformableConvolution(xr, offr, wr, br, kernel=(3, 3), pad=(1, 1), num_filter=F, num_group=G,
+    out = contrib.DeformableConvolution(xr, offr, wr, bias=br, kernel=(3, 3), pad=(1, 1), num_filter=F, num_group=G,
                                         num_deformable_group=2)
     out.backward(dy)
     close = lambda u, v: float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max()))
     assert close(out.detach(), y) and torch.equal(offr.grad, g[1]) and torch.equal(br.grad, g[3])
     assert close(xr.grad, g[0]) and close(wr.grad, g[2])
     with pytest.raises(ValueError):
-        contrib.DeformableConvolution(x, off, w, None, kernel=(3, 3), pad=(1, 1), num_group=G)   # no_bias=False, no bias
+        contrib.DeformableConvolution(x, off, w, bias=None, kernel=(3, 3), pad=(1, 1), num_group=G)   # no_bias=False, no bias
     # no gradient wanted: the col-free path (its workspace is a few MB, not N*C*9*Ho*Wo*4 bytes)
     calls = []
     real = ops.deform_conv_forward
     try:
         ops.deform_conv_forward = lambda *p, **k: (calls.append(k.get("keep_col", False)), real(*p, **k))[1]
         with torch.no_grad():
-            contrib.DeformableConvolution(xr, offr, wr, br, kernel=(3, 3), pad=(1, 1), num_group=G,
+            contrib.DeformableConvolution(xr, offr, wr, bias=br, kernel=(3, 3), pad=(1, 1), num_group=G,
                                           num_deformable_group=2)
-        contrib.DeformableConvolution(x, off, w, b, kernel=(3, 3), pad=(1, 1), num_group=G, num_deformable_group=2)
-        contrib.DeformableConvolution(xr, offr, wr, br, kernel=(3, 3), pad=(1, 1), num_group=G,
+        contrib.DeformableConvolution(x, off, w, bias=b, kernel=(3, 3), pad=(1, 1), num_group=G, num_deformable_group=2)
+        contrib.DeformableConvolution(xr, offr, wr, bias=br, kernel=(3, 3), pad=(1, 1), num_group=G,
                                       num_deformable_group=2)
     finally:
         ops.deform_conv_forward = real
