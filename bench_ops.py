@@ -229,6 +229,84 @@ def run(seed=0, cpu=True, only=None):
                                         "ProposalMaskTarget -> 14x14 RoIAlign fwd+bwd; one HIP graph"}
         del t_feats, t_dy, t_dy14, graph
 
+    # ---- the TEST-time chain of one image (BASELINE configs[0]; detection_infer_speed.py:66-77 ->
+    # detection_test.py:233-267): fused FPN RoIAlign forward of the 1000 test proposals -> [bbox head: the model's,
+    # synthetic outputs here] -> DecodeBBox -> per-class score filter -> soft-NMS of every class, one HIP graph, no
+    # host round trip; beside it what the reference runs after the head on the HOST: decodebbox.cc (CPU only),
+    # the numpy filter and the Cython soft_nms, class after class (its Pool(cpu_count() // 2) spreads IMAGES) ----
+    if want("test_chain"):
+        B, R, K = 1, 1000, 81
+        strides4 = [4, 8, 16, 32]
+        rs = np.random.RandomState(seed + 31)
+        feats = [torch.randn((B, 256, h, w), device="cuda") for h, w in synth.FPN_SHAPES]
+        rois_np = synth.random_rois(seed + 31, B, R, degenerate=False)
+        deltas_np = (rs.standard_normal((B, R, 4 * K)) * 0.5).astype(np.float32)
+        logit = rs.standard_normal((B, R, K)).astype(np.float32) * 3
+        e = np.exp(logit - logit.max(-1, keepdims=True))
+        score_np = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+        info_np = np.array([[800, 1333, 1.0]], np.float32)
+        t_rois, t_deltas, t_score, t_info = T(rois_np), T(deltas_np), T(score_np), T(info_np)
+        MIN_SCORE = 0.05   # config/faster_r50v1_fpn_1x.py:177
+
+        def chain():
+            pooled, _ = ops.fpn_roi_align_forward_packed(feats, t_rois, strides4, (7, 7))
+            boxes = ops.decode_bbox(t_rois, t_deltas, t_info, class_agnostic=False)
+            dets, counts = ops.det_filter(boxes, t_score, MIN_SCORE)
+            return (pooled,) + tuple(ops.soft_nms_batched(dets, counts, 0.5, 0.5, 0.001, 1)) + (counts,)
+        ms_eager = _time_gpu(chain, iters=10, warm=3)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            chain()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_out = chain()
+        ms_graph = _time_gpu(graph.replay, iters=10, warm=3)
+        ms_roi = _time_gpu(lambda: ops.fpn_roi_align_forward_packed(feats, t_rois, strides4, (7, 7)), iters=10, warm=2)
+        res["test_chain"] = {"ms": ms_graph, "eager_ms": ms_eager, "roi_align_fwd_ms": ms_roi,
+                             "images_per_s": 1e3 / ms_graph, "host_syncs_in_chain": 0,
+                             "config": "B=1, R=1000, 81 classes: fused FPN RoIAlign 7x7 fwd (256 ch, packed) -> DecodeBBox "
+                                       "(per class) -> score > 0.05 -> soft-NMS (linear, Nt 0.5, thr 0.001) of all classes; "
+                                       "one HIP graph"}
+        if orc:
+            graph.replay()
+            torch.cuda.synchronize()
+            pooled, od, oi, oc, counts = [N_(x) for x in g_out]
+            t0 = time.perf_counter()
+            wboxes = orc.decode_bbox(rois_np, deltas_np, info_np, class_agnostic=False)
+            wd, wc = orc.det_filter(wboxes, score_np, MIN_SCORE)
+            t_dec = time.perf_counter() - t0
+            okk = np.array_equal(counts, wc)
+            t0 = time.perf_counter()
+            for q in range(B * K):
+                wb, wi = orc.soft_nms(wd[q, :wc[q]], 0.5, 0.5, 0.001, 1)
+                okk = okk and oc[q] == len(wi) and np.array_equal(od[q, :oc[q]], wb) and np.array_equal(oi[q, :oc[q]], wi)
+            t_nms = time.perf_counter() - t0
+            wf = orc.fpn_roi_align_fwd([N_(f) for f in feats], rois_np, strides4, (7, 7), nthreads=8)
+            okk = okk and np.array_equal(pooled, wf[0])
+            res["test_chain"]["matches_oracle"] = bool(okk)
+            res["test_chain"]["matches_oracle_scope"] = "pooled features, every class's kept boxes / indices / order"
+            res["test_chain"]["cpu_port_post_head_ms"] = (t_dec + t_nms) * 1e3
+            res["test_chain"]["boxes_over_threshold"] = int(wc.sum())
+            try:  # the reference's own Cython soft_nms (oracle/_ref), the way do_nms() walks the classes
+                from oracle._ref import cpu_nms as _ref_nms
+                t0 = time.perf_counter()
+                for q in range(B * K):
+                    if wc[q]:
+                        _ref_nms.soft_nms(np.ascontiguousarray(wd[q, :wc[q]]), np.float32(0.5), np.float32(0.5),
+                                          np.float32(0.001), np.uint8(1))
+                t_ref = time.perf_counter() - t0
+                res["test_chain"]["cpu_ms"] = (t_dec + t_ref) * 1e3
+                res["test_chain"]["cpu_ms_what"] = ("post-head work of one image on one host core: oracle decode + filter "
+                                                    "(%.1f ms) + the reference's Cython soft_nms over the classes (%.1f ms)"
+                                                    % (t_dec * 1e3, t_ref * 1e3))
+                res["test_chain"]["post_head_gpu_ms"] = ms_graph - ms_roi
+            except Exception:
+                pass
+        del feats, graph, g_out
+
     # ---- batched soft-NMS: 16 images x 80 classes x 1000 boxes (BASELINE configs[2]) ----
     if want("soft_nms"):
         P, n = 16 * 80, 1000

@@ -27,6 +27,7 @@ struct GemmArgs {
   int whole, whole_blocks, ksplit;  // split kernel: tiles run whole, their blocks (padded), k slices of the rest
   int ablate;  // profiling build only: bit 0 skip the A prefetch, bit 1 skip the B prefetch
   const unsigned* amax;  // f16 split: bit patterns of max|A|, max|B| (upper bounds), device memory
+  int vec_store;         // split kernel: C rows are 16-byte aligned and N % 4 == 0 (plain stores leave as whole tile rows)
 };
 
 constexpr int BM = 128;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
@@ -431,6 +432,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
     mfma_step();
   }
   // D layout of the 32x32 tile: element e of lane l -> row (e/4)*8 + (l/32)*4 + e%4, col l%32
+  // Round 6: a plain store of a whole tile (C = A.B, the dcol product of the layer's backward: 619 MB of output for
+  // four k steps per tile) goes through LDS -- written per lane as above every store instruction is two 128-byte
+  // pieces of two rows that are not line aligned (16,800-byte rows), 64 of them per lane.  The accumulators are
+  // transposed through the 64 KB the operand planes no longer need (column major: a lane's four consecutive rows are
+  // one ds_write_b128; the 16-byte granule of (column c, rows 4 g ..) sits at g ^ swz(c), which keeps both the
+  // writes' 8-lane groups and the reads' 16-lane groups on distinct banks), every thread takes 4 x 4 blocks back
+  // (four ds_read_b128), and a store instruction writes 16 bytes per lane: two whole 512-byte tile rows.
+  if (!piece && a.mode == 0 && a.vec_store) {
+    __syncthreads();   // every wave is done with the operand planes
+    auto swz = [](int c) { return ((c >> 2) ^ ((c & 3) << 2)) & 15; };
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cc = wn + j * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = wm + i * 32 + g * 8 + (lane >> 5) * 4;
+          float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          if (MODE == kSplitF16) {   // exact (powers of two)
+            v.x = (v.x * inva) * invb; v.y = (v.y * inva) * invb; v.z = (v.z * inva) * invb; v.w = (v.w * inva) * invb;
+          }
+          *reinterpret_cast<float4*>(smem + cc * 512 + (((r0 >> 2) ^ swz(cc)) << 4)) = v;
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int blk = tid + it * 256, c0 = (blk & 31) * 4, r0 = (blk >> 5) * 4;
+      float4 q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        q[k] = *reinterpret_cast<const float4*>(smem + (c0 + k) * 512 + (((r0 >> 2) ^ swz(c0 + k)) << 4));
+      if (n0 + c0 < a.N) {   // (N % 4 == 0: a block of four columns is inside or outside as a whole)
+        float* cp = C + (long)(m0 + r0) * a.ldc + n0 + c0;
+        if (m0 + r0 + 0 < a.M) *reinterpret_cast<float4*>(cp) = make_float4(q[0].x, q[1].x, q[2].x, q[3].x);
+        if (m0 + r0 + 1 < a.M) *reinterpret_cast<float4*>(cp + a.ldc) = make_float4(q[0].y, q[1].y, q[2].y, q[3].y);
+        if (m0 + r0 + 2 < a.M) *reinterpret_cast<float4*>(cp + 2L * a.ldc) = make_float4(q[0].z, q[1].z, q[2].z, q[3].z);
+        if (m0 + r0 + 3 < a.M) *reinterpret_cast<float4*>(cp + 3L * a.ldc) = make_float4(q[0].w, q[1].w, q[2].w, q[3].w);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -538,6 +582,8 @@ static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
 #endif
     g.fast = aligned(g.A, ak, g.sam, g.sak, g.strideA, g.M) &&
              aligned(g.B, bk, g.sbn, g.sbk, g.strideB, g.N);
+    g.vec_store = (((uintptr_t)g.C & 15) == 0 && g.ldc % 4 == 0 && g.strideC % 4 == 0 && g.N % 4 == 0 &&
+                   tuning("deform_gemm_vecstore", 1) == 1) ? 1 : 0;
     int e;
     if (ak && bk) e = launch_gemm_split<true, true>(g, grid, st);
     else if (ak) e = launch_gemm_split<true, false>(g, grid, st);

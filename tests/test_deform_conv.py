@@ -219,6 +219,29 @@ def test_mfma_gemm_all_layouts(ops, shape, split):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 256, 300, 72), (3, 70, 4200, 33), (1, 2304, 4200, 256), (2, 130, 132, 200)])
+def test_gemm_tile_rows_through_lds_are_the_same_bits(ops, shape):
+    """Round 6: a whole-tile plain store of the split GEMM leaves through LDS as 512-byte tile rows
+    (`deform_gemm_vecstore` = 1, default, when C is 16-byte aligned and N % 4 == 0) instead of as element stores in
+    the accumulator layout (= 0): the same values, bit for bit, partial tiles in M and N included."""
+    import torch
+    from simpledet_amd._lib import lib
+    Bt, M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn((Bt, K, M), device="cuda", generator=g)   # trans_a: the dcol product's layout
+    b = torch.randn((Bt, K, N), device="cuda", generator=g)
+    got = ops.gemm_f32(a, b, trans_a=True)
+    lib().set_tuning("deform_gemm_vecstore", 0)
+    try:
+        want = ops.gemm_f32(a, b, trans_a=True)
+    finally:
+        lib().set_tuning("deform_gemm_vecstore", 1)
+    assert torch.equal(got, want)
+    ref = torch.bmm(a.double().transpose(1, 2), b.double())
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scales", [(1.0, 1.0, 1.0), (50.0, 1e-5, 1e-3), (1e-6, 3e4, 200.0)])
 def test_dcn_products_default_split_is_as_good_as_exact_fp32(ops, scales):
     """VERDICT r3 "Next 1b" / ADVICE r3 (low): the DCN layer's three products -- y = W col,
