@@ -20,16 +20,19 @@
 //                 with min_pos_thr = 0 a gt box nothing overlaps makes every valid anchor positive),
 //                 per-block fg / bg counts; rpn_scan + rpn_lists turn them into the ordered index
 //                 lists np.where would return
-//   rpn_sample    ONE wave, images in order (the generator state carries from image to image):
-//                 * MT19937 twist in LDS, 64 outputs per step, tempered on read
-//                 * a batch of 64 outputs is consumed at once: lane t accepts iff
-//                   (out & mask) <= i - #accepts before t -- decided by one comparison unless a
-//                   lane sits within 63 of the bound, then by a ballot/popcount fixed point (exact,
-//                   1-2 rounds) --, cut at the accept where the rejection mask shrinks; four
-//                   batches are read and tempered ahead per trip
+//   rpn_sample    ONE workgroup, images in order (the generator state carries from image to image); round 6: five
+//                 waves that meet through LDS counters only --
+//                 * four PRODUCER waves make MT19937's raw sequence (X[j] = X[j-227] ^ tw(X[j-624], X[j-623]):
+//                   227 consecutive words are independent, and two steps fit between hand-shakes) into an LDS ring,
+//                   raw and tempered, as far ahead as the ring allows
+//                 * the CONSUMER wave takes up to 1024 draws per dependent step: candidates (v & mask <= i) by
+//                   ballot, sure accepts by a rank bound, the handful of unsettled ones in order with their exact
+//                   rank; batch by batch (ballot / popcount fixed point, exact) where the rejection mask is small,
+//                   near a mask segment's end and inside the recorded swaps
 //                 * only the last `keep` positions of the permutation survive, and they are final
 //                   after the first `keep` swaps: those swaps are replayed on a sparse array
-//                 so ~200 k dependent draws cost ~3 k wave steps instead of 200 k serial ones
+//                 so ~330 k dependent draws per image cost ~700 wave steps (2.7 -> 1.4 ms for two images; the rest is
+//                 the single consumer wave's ~12 clocks per instruction)
 //   rpn_encode    final label, box deltas in double (nonlinear_transform on float64 anchors),
 //                 weights; written either in flat all-anchor order or in the loader's final
 //                 (A, sum h*w) / (4A, sum h*w) layout
@@ -280,42 +283,42 @@ __global__ __launch_bounds__(kRpnT) void rpn_lists_kernel(RpnArgs a) {
   if (lab == 0) a.bg_list[(long)img * a.N + off1 + __popcll(mb & lt)] = n;
 }
 
-// ---- MT19937 (numpy legacy RandomState) in one wave ------------------------------------------------
-struct Mt {
-  unsigned* key;  // LDS, 624 words
-  int pos;        // wave uniform
+// ---- MT19937 (numpy legacy RandomState): a producer wave and a consumer wave -----------------------
+// Round 6.  Until round 5 ONE wave twisted the state and consumed it (2.7 ms for two images: a lone wave pays
+// ~12 clocks per dependent instruction, and twist and rejection chain were one dependency chain).  The generator's
+// raw output is a pure sequence -- X[j] = X[j - 227] ^ tw(X[j - 624], X[j - 623]) for j >= 624, X[0 .. 623] = the
+// state's key words; all three sources lie >= 227 words back, so 227 consecutive words are independent -- and only
+// WHERE in it each draw is taken depends on the data.  So the other waves of the workgroup produce the sequence
+// into an LDS ring, 227 words per step, as far ahead as the ring allows, and the first wave consumes it (tempering
+// on read); four waves share the production, 57 words of a step each.  The two meet through LDS counters only (release / acquire at workgroup scope; no s_barrier: the waves
+// of one workgroup are co-resident by construction, the same guarantee a barrier rests on).  Every wait is a bounded
+// spin: on overrun the kernel stops and raises `counts[B * 4]` (the host entry point does not read it back --
+// a wrong sample shows in the tests, a hang would cost a GPU).
+constexpr int kMtRing = 4096;        // words (16 KB raw + 16 KB tempered); the producers stay < kMtRing ahead of what the consumer still needs
+constexpr int kMtSpinCap = 1 << 22;  // ~seconds of s_sleep polling
+constexpr int kMtProd = 4;           // producer waves: wave w makes elements [57 w, 57 w + 57) of every 227-word step
+constexpr int kMtSlice = 57;         // (227 = 3 * 57 + 56)
+
+struct MtStream {
+  unsigned* ring;   // LDS: word j of the sequence at ring[j & (kMtRing - 1)] (raw: what the recurrence and the state need)
+  unsigned* tring;  // LDS: the same word tempered (what a draw returns), written by the producers beside it
+  int* ctl;         // LDS: [0..3] steps completed by the producer waves, [4] first word the consumer still needs,
+                    //      [5] stop, [6] overrun
+  int pos;          // consumer: index of the next output (wave uniform)
 };
 
-// new[k] = old[k + 397 (mod 624)] ^ twist(old[k], old[k + 1]); for k >= 227 the far word is one this
-// pass has already produced.  Three phases of independent elements -- [0, 227) reads old far words,
-// [227, 454) and [454, 624) read the phase before -- with four elements per lane whose reads are all
-// issued before any write of the phase (a lone wave pays ~12 clocks per dependent instruction:
-// ten batches of 64 in sequence cost 4x as much).
-__device__ __forceinline__ void mt_twist(Mt& m, int lane) {
-  constexpr int kBound[4] = {0, 227, 454, 624};
-#pragma unroll
-  for (int ph = 0; ph < 3; ++ph) {
-    unsigned nv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = kBound[ph] + u * kWave + lane;
-      nv[u] = 0;
-      if (k < kBound[ph + 1]) {
-        // (k + 1 == 624 only in the last phase, where word 0 is already new: the reference's wrap)
-        const unsigned y = (m.key[k] & 0x80000000u) | (m.key[k + 1 < 624 ? k + 1 : 0] & 0x7fffffffu);
-        const unsigned far = m.key[k + 397 < 624 ? k + 397 : k - 227];
-        nv[u] = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      }
-    }
-    wave_lds_sync();  // every read of the phase precedes its writes
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = kBound[ph] + u * kWave + lane;
-      if (k < kBound[ph + 1]) m.key[k] = nv[u];
-    }
-    wave_lds_sync();
-  }
-  m.pos = 0;
+__device__ __forceinline__ int mt_ld(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void mt_st(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// steps every producer wave has completed (one 16-byte LDS read)
+__device__ __forceinline__ int mt_steps_done(const int* ctl) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i d = *reinterpret_cast<const volatile v4i*>(ctl);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return iminr(iminr(d.x, d.y), iminr(d.z, d.w));
 }
 
 __device__ __forceinline__ unsigned mt_temper(unsigned y) {
@@ -326,60 +329,137 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
   return y;
 }
 
+// Producer wave w: elements [57 w, 57 w + 57) of every step, TWO steps per hand-shake.  Word j = 624 + 227 s + e
+// reads j - 227 (the same element of step s - 1: this wave's own word -- inside a pair it never leaves the
+// register) and j - 624 / j - 623 = elements e + 57 / e + 58 of step s - 3 (or e - 170 / e - 169 of step s - 2):
+// other waves' words, at least two steps back.  So once every wave has completed step s - 1, steps s AND s + 1 can
+// be made without another look at the others: one round of flag reads per 454 words.  (A hand-shake is two or three
+// dependent LDS round trips of a wave that issues an instruction every ~12 clocks: with one per step the four
+// producers delivered 0.23 words per clock against the 0.45 the consumer takes.)  Runs until ctl[5] is raised.
+__device__ void mt_produce(unsigned* ring, unsigned* tring, int* ctl, int w, int lane) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const int e = w * kMtSlice + lane;
+  const bool mine = lane < kMtSlice && e < 227;
+  auto tw = [](unsigned far, unsigned a, unsigned b) {
+    const unsigned y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  };
+  for (int s = 0;; s += 2) {
+    const int made = 624 + 227 * s;   // first word of the pair of steps
+    int spins = 0;
+    while (true) {
+      const v4i d = *reinterpret_cast<const volatile v4i*>(ctl);       // steps completed by the four producers
+      const v4i c = *reinterpret_cast<const volatile v4i*>(ctl + 4);   // consumer floor, stop, overrun
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (c.y) return;
+      // word j overwrites word j - kMtRing: everything from the consumer's floor on stays
+      if (made + 454 <= c.x + kMtRing - 64 && iminr(iminr(d.x, d.y), iminr(d.z, d.w)) >= s) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kMtSpinCap) { mt_st(ctl + 6, 1); return; }
+    }
+    if (mine) {
+      const int j = made + e, j1 = j + 227;
+      const unsigned f0 = ring[(j - 227) & (kMtRing - 1)];
+      const unsigned a0 = ring[(j - 624) & (kMtRing - 1)], b0 = ring[(j - 623) & (kMtRing - 1)];
+      const unsigned a1 = ring[(j1 - 624) & (kMtRing - 1)], b1 = ring[(j1 - 623) & (kMtRing - 1)];
+      const unsigned x0 = tw(f0, a0, b0), x1 = tw(x0, a1, b1);
+      ring[j & (kMtRing - 1)] = x0;
+      ring[j1 & (kMtRing - 1)] = x1;
+      // (tempered beside it: the consumer is a lone wave too, every instruction taken off it counts)
+      tring[j & (kMtRing - 1)] = mt_temper(x0);
+      tring[j1 & (kMtRing - 1)] = mt_temper(x1);
+    }
+    mt_st(ctl + w, s + 2);   // (release: behind the ring writes)
+  }
+}
+
+// consumer: words [pos, pos + n) are there (false on overrun)
+__device__ __forceinline__ bool mt_need(MtStream& m, int n) {
+  int spins = 0;
+  while (624 + 227 * mt_steps_done(m.ctl) < m.pos + n) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kMtSpinCap || mt_ld(m.ctl + 6)) { mt_st(m.ctl + 6, 1); return false; }
+  }
+  return true;
+}
+
 constexpr int kRpnMaxKeep = 1024;
+
+// NB batches of 64 draws in ONE dependent step, exactly.  Draw t accepts iff v_t <= i - A(t), A(t) = accepts in
+// front of it.  The CANDIDATES (v <= i) are the only draws that can accept, and the number of candidates up to the
+// end of a draw's batch bounds its A(t) from above: v <= i - that is a sure accept.  What is left -- candidates
+// with i - bound < v <= i, about bound / mask of them -- is a handful per trip; they are settled one after the
+// other in order with their exact rank (each rejection lowers the A of everything behind it by one).  Per batch
+// that is one LDS read, two compares and a few scalar operations, independent of the other batches.  Returns the
+// number of accepts, or -1 when the trip would leave the mask's segment (the caller then goes batch by batch).
+template <int NB>
+__device__ __forceinline__ int mt_trip(const MtStream& m, int i, int lo, unsigned mask, int lane) {
+  int vv[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) vv[j] = (int)(m.tring[(m.pos + j * kWave + lane) & (kMtRing - 1)] & mask);
+  unsigned long long cand[NB], amb[NB];
+  int base[NB + 1];
+  base[0] = 0;
+  unsigned long long anyamb = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    cand[j] = __ballot(vv[j] <= i);
+    base[j + 1] = base[j] + __popcll(cand[j]);
+    amb[j] = __ballot(vv[j] > i - base[j + 1]) & cand[j];
+    anyamb |= amb[j];
+  }
+  int K = base[NB];
+  if (anyamb) {
+    int rej = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      unsigned long long todo = amb[j];
+      while (todo) {
+        const int t = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int vt = __builtin_amdgcn_readlane(vv[j], t);
+        const int rt = base[j] + __popcll(cand[j] & ((1ull << t) - 1));
+        if (vt > i - rt + rej) ++rej;
+      }
+    }
+    K -= rej;
+  }
+  return K < i - lo + 1 ? K : -1;
+}
 
 // permutation(n) of the legacy RandomState, of which only the last `keep` entries are wanted
 // (choice(inds, n - keep, replace=False) disables the FIRST n - keep): fills surv[0..keep) with the
 // list positions that survive and advances the generator by exactly the draws numpy consumes.
-__device__ void rpn_sample(Mt& m, int n, int keep, int* jrec, int* hp, int* hv, int* surv, int lane) {
-  constexpr int NB = 4;  // batches of 64 outputs read (and tempered) ahead per trip
+__device__ void rpn_sample(MtStream& m, int n, int keep, int* jrec, int* hp, int* hv, int* surv, int lane) {
   int i = n - 1;
   const unsigned long long lt = (1ull << lane) - 1;
   while (i >= 1) {
-    if (m.pos >= 624) mt_twist(m, lane);
-    const int avail = 624 - m.pos;
+    // the consumer no longer needs anything before the block its last draw came from (the final state is that block)
+    mt_st(m.ctl + 4, m.pos > 624 ? m.pos - 624 : 0);
+    // Trip size by mask: the unsettled candidates of an L-draw trip number ~L * (L / 2) / mask -- a handful for 1024
+    // draws from mask 2^17 on (where four fifths of the draws are spent), for 512 from 2^15, for 128 from 2^11;
+    // below that, and inside the recorded swaps, batch by batch.
+    const bool past = (n - 1) - i >= keep;
+    const int nb = !past || i < 1024 ? 1 : i < 16384 ? 2 : i < 65536 ? 8 : 16;
+    if (!mt_need(m, nb * kWave)) return;
     unsigned mask = (unsigned)i;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
     const int lo = (int)(mask >> 1) + 1;  // steps i in [lo, mask] share this rejection mask
-    unsigned raw[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int idx = m.pos + j * kWave + lane;
-      raw[j] = mt_temper(m.key[idx < 624 ? idx : 623]);
+    if (nb > 1) {
+      const int K = nb == 16 ? mt_trip<16>(m, i, lo, mask, lane) : nb == 8 ? mt_trip<8>(m, i, lo, mask, lane)
+                                                                          : mt_trip<2>(m, i, lo, mask, lane);
+      if (K >= 0) {
+        i -= K;
+        m.pos += nb * kWave;
+        continue;
+      }
     }
-    // Fast path, a dozen instructions per batch (a lone wave issues a dependent instruction only
-    // every ~12 clocks, so the count is what matters): lane t accepts iff
-    // v_t <= i - (#accepts among the lanes before it), and that count is at most 63, so when no lane
-    // has i - 63 < v <= i the accepts are simply the lanes with v <= i.  The batch must be whole,
-    // must not reach the end of the mask's segment and must lie past the recorded swaps; anything
-    // else goes through the exact general step below, one batch at a time.
-    int jd = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (avail - j * kWave < kWave) break;
-      const int v = (int)(raw[j] & mask);
-      const unsigned long long sure = __ballot(v <= i - (kWave - 1)), notrej = __ballot(v <= i);
-      const int K = __popcll(sure);
-      if (sure != notrej || K >= i - lo + 1 || (n - 1) - i < keep) break;
-      i -= K;
-      m.pos += kWave;
-      ++jd;
-    }
-    if (jd == NB) continue;
-    // ---- general step for the batch at m.pos (raw[jd] when it was read ahead in full) ----
-    const int left = 624 - m.pos;
-    const int chunk = left < kWave ? left : kWave;
-    const bool have = lane < chunk;
-    unsigned rj = raw[0];
-#pragma unroll
-    for (int j = 1; j < NB; ++j)
-      if (jd == j) rj = raw[j];
-    const unsigned v = have ? (rj & mask) : 0xffffffffu;
-    bool acc = have && v <= (unsigned)i;
+    const unsigned v = m.tring[(m.pos + lane) & (kMtRing - 1)] & mask;
+    bool acc = v <= (unsigned)i;
     unsigned long long bits = __ballot(acc);
     while (true) {  // ballot / popcount fixed point: exact, 1-2 rounds
       const int c = __popcll(bits & lt);
-      const bool acc2 = have && (long)v <= (long)i - c;
+      const bool acc2 = (long)v <= (long)i - c;
       const unsigned long long b2 = __ballot(acc2);
       acc = acc2;
       if (b2 == bits) break;
@@ -387,7 +467,7 @@ __device__ void rpn_sample(Mt& m, int n, int keep, int* jrec, int* hp, int* hv, 
     }
     int K = __popcll(bits);
     const int R = i - lo + 1;  // accepts this mask still serves
-    int consumed = chunk;
+    int consumed = kWave;
     if (K >= R) {
       // the R-th accept ends the segment; later draws of the batch are re-read with the next mask
       // (also when it is the batch's last accept: the rejected draws behind it were judged with
@@ -436,15 +516,27 @@ __device__ void rpn_sample(Mt& m, int n, int keep, int* jrec, int* hp, int* hv, 
   }
 }
 
-__global__ __launch_bounds__(kWave) void rpn_sample_kernel(RpnArgs a) {
-  __shared__ unsigned key[624];
+__global__ __launch_bounds__((1 + kMtProd) * kWave) void rpn_sample_kernel(RpnArgs a) {
+  __shared__ unsigned ring[kMtRing], tring[kMtRing];
+  __shared__ __attribute__((aligned(16))) int ctl[8];
   __shared__ int jrec[kRpnMaxKeep], hp[kRpnMaxKeep], hv[kRpnMaxKeep], surv[kRpnMaxKeep];
-  const int lane = threadIdx.x;
-  for (int k = lane; k < 624; k += kWave) key[k] = (unsigned)a.mt[k];
-  Mt m{key, a.mt[624]};
-  wave_lds_sync();
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  // the key words are the first 624 words of the sequence; a stored position of 624 ("twist before the next draw")
+  // is simply the next word
+  for (int k = threadIdx.x; k < 624; k += (1 + kMtProd) * kWave) {
+    ring[k] = (unsigned)a.mt[k];
+    tring[k] = mt_temper(ring[k]);
+  }
+  if (threadIdx.x < 8) ctl[threadIdx.x] = 0;
+  __syncthreads();   // (the only barrier: before the waves part)
+  if (wave >= 1) {
+    mt_produce(ring, tring, ctl, wave - 1, lane);
+    return;
+  }
+  MtStream m{ring, tring, ctl, a.mt[624]};
+  const int pos0 = m.pos;
   const int num = a.p.image_anchor;
-  for (int img = 0; img < a.B; ++img) {
+  for (int img = 0; img < a.B && !mt_ld(ctl + 6); ++img) {
     int* c = a.counts + img * 4;
     const int n_fg = c[0], n_bg = c[1];
     int fg_left = n_fg;
@@ -468,8 +560,18 @@ __global__ __launch_bounds__(kWave) void rpn_sample_kernel(RpnArgs a) {
     }
     wave_lds_sync();
   }
-  for (int k = lane; k < 624; k += kWave) a.mt[k] = (int)key[k];
-  if (lane == 0) a.mt[624] = m.pos;
+  // The state numpy would hold now: the block the last draw came from and the position behind it (624 = "twist
+  // before the next draw"); untouched when nothing was drawn.  The block is still in the ring: the producer never
+  // overwrites anything from ctl[4] = pos - 624 on.
+  if (m.pos != pos0 && !mt_ld(ctl + 6)) {
+    const int b0 = ((m.pos - 1) / 624) * 624;
+    int spins = 0;   // (the block's tail may still be on its way)
+    while (624 + 227 * mt_steps_done(ctl) < b0 + 624 && ++spins <= kMtSpinCap) __builtin_amdgcn_s_sleep(1);
+    for (int k = lane; k < 624; k += kWave) a.mt[k] = (int)ring[(b0 + k) & (kMtRing - 1)];
+    if (lane == 0) a.mt[624] = m.pos - b0;
+  }
+  if (lane == 0 && mt_ld(ctl + 6)) a.counts[a.B * 4] = 1;   // overrun: the sample is not valid
+  mt_st(ctl + 5, 1);   // the producers may leave
 }
 
 __global__ __launch_bounds__(kRpnT) void rpn_encode_kernel(RpnArgs a) {
@@ -534,7 +636,7 @@ static size_t rpn_layout(int B, int N, int M, int nblk, RpnArgs* a, char* base) 
   const size_t o_mo = take((size_t)B * N * 4), o_am = take((size_t)B * N * 4), o_lb = take((size_t)B * N);
   const size_t o_kp = take((size_t)B * N), o_gm = take((size_t)B * (M > 0 ? M : 1) * 4);
   const size_t o_bk = take((size_t)B * nblk * 2 * 4), o_fg = take((size_t)B * N * 4);
-  const size_t o_bg = take((size_t)B * N * 4), o_ct = take((size_t)B * 4 * 4);
+  const size_t o_bg = take((size_t)B * N * 4), o_ct = take((size_t)(B * 4 + 1) * 4);
   if (a) {
     a->maxov = reinterpret_cast<float*>(base + o_mo);
     a->argmax = reinterpret_cast<int*>(base + o_am);
@@ -648,7 +750,7 @@ extern "C" int sd_rpn_anchor_target(const float* im_info, const float* gt_bbox, 
   hipLaunchKernelGGL(rpn_label_kernel, grid, dim3(kRpnT), lds, st, a);
   hipLaunchKernelGGL(rpn_scan_kernel, dim3(B), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(rpn_lists_kernel, grid, dim3(kRpnT), 0, st, a);
-  hipLaunchKernelGGL(rpn_sample_kernel, dim3(1), dim3(kWave), 0, st, a);
+  hipLaunchKernelGGL(rpn_sample_kernel, dim3(1), dim3((1 + kMtProd) * kWave), 0, st, a);
   hipLaunchKernelGGL(rpn_encode_kernel, grid, dim3(kRpnT), 0, st, a);
   SD_LAUNCH_CHECK();
   return SD_OK;
