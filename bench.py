@@ -553,6 +553,33 @@ def main():
                                   "the reference's roi_align_v2.cc compiled against oracle/mxshim",
                         "equals_gpu_forward_bit_for_bit": bool(np.array_equal(ref_out, state["out"].cpu().numpy())),
                     }
+                    # ... and its compiled BACKWARD (round 6).  The operator's semantics are the GPU scatter kernel
+                    # (roi_align_v2.cu:35-84, what this library's backward reproduces), run here from the reference's
+                    # own source on one host core (oracle/mxshim/cuemu.h: the CUDA grid as a serial loop, atomicAdd
+                    # as +=), level by level as the un-fused graph does; its CPU file's gather kernel
+                    # (roi_align_v2.cc:35-106) is O(pixels x RoIs) -- timed on P5 only, where it takes seconds.
+                    ref_fw = []
+                    for l, st_ in enumerate(strides):
+                        rop = refmx.RefOp("roi_align_v2", "_contrib_ROIAlign_v2", pooled_size=(7, 7),
+                                          spatial_scale=1.0 / st_)
+                        ref_fw.append((rop, rop.forward([feats_np[l], per[l]], ctx="cpu")))
+                    t0 = time.perf_counter()
+                    ref_dx = [rop.backward([dy_np], [feats_np[l], per[l]], fw, ctx="gpu")[0]
+                              for l, (rop, fw) in enumerate(ref_fw)]
+                    t_bwd = time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    rop5, fw5 = ref_fw[-1]
+                    rop5.backward([dy_np], [feats_np[-1], per[-1]], fw5, ctx="cpu")
+                    t_gather5 = time.perf_counter() - t0
+                    gd = [g.cpu().numpy() for g in d_feats]
+                    cpu_baseline["reference"].update({
+                        "ms_backward": t_bwd * 1e3,
+                        "value_fwd_bwd": args.images / (t_ref + t_bwd), "unit_fwd_bwd": "images/s",
+                        "backward_sample": "1 pass of ROIAlignBackwardKernelGPU_v2 (roi_align_v2.cu, the operator's "
+                                           "semantics) over the four levels, emulated serially on one core",
+                        "backward_max_abs_diff_to_gpu": max(float(np.abs(a_ - b_).max()) for a_, b_ in zip(ref_dx, gd)),
+                        "cpu_gather_backward_p5_only_ms": t_gather5 * 1e3,
+                    })
             except Exception as e:  # the reference library is optional on the GPU box
                 cpu_baseline["reference"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # the GPU results of the LAST TIMED step against the oracle (not timed): forward values bit

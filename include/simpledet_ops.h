@@ -174,24 +174,38 @@ int sd_fpn_roi_align_bwd_packed(const float* out_grad, const float* rois, const 
 /* Numerics of the packed backward (and of the drop-in sd_roi_align_v2_bwd / sd_fpn_roi_align_bwd in
  * their default form).  Every tap value is computed in fp32 exactly as the reference does; the SUM a
  * pixel receives is accumulated in 32-bit fixed point whose unit is fixed per workgroup (one band of
- * one channel) from max|dY| over that band and a bound on the weights a pixel can collect: ~2e-6 x
- * max|dY| of the band per added value.  The result is independent of the order of the adds (the
- * backward is bit-reproducible, the reference's float atomics are not), within 1e-4 of the exact sums
- * for dY ~ N(0,1) (measured 2.5e-5), but the error is ABSOLUTE relative to the band's largest
- * gradient: an element orders of magnitude smaller than max|dY| of its band keeps fewer significant
- * digits than the reference's fp32 adds would give it.  Non-finite dY and extreme weight pile-ups
- * switch a workgroup to fp32 compare-and-swap adds by themselves.  Callers that need fp32-relative
- * sums everywhere select those adds for every workgroup with
+ * one channel): 2^-30 .. 2^-29 of (max|dY| of the band) x (a bound on the weight one pixel can collect).  With
+ * a workspace the bound is per PIXEL of the band (round 6: a 2-D difference array of the RoIs' footprints in the
+ * list pre-pass, typically 20-100), without one it is summed over the band's RoIs (1,000-1,800 at the baseline).
+ * The result is independent of the order of the adds (bit-reproducible; the reference's float atomics are not).
+ *   Measured against the oracle (tests/test_fixed_point_precision.py, profiles/r06e_fixed_point_precision.json):
+ * dY ~ N(0,1) at BASELINE's size: 1.1e-5 max abs error with the per-pixel bound (2.3e-5 with the summed bound,
+ * 3.8e-6 for fp32 adds in hardware order; bar 1e-4).
+ *   A fixed-point unit is ABSOLUTE for its band, so it is only used while the band's gradients span a range
+ * it resolves (round 6): behind the scatter a workgroup compares the exponent of its largest |dY| plus the bits
+ * of its weight bound with the MEAN exponent of its non-zero gradients (a quarter of them, sampled at fixed
+ * positions; all-integer, so the verdict does not depend on any order) and keeps the integer sums only if
+ *     E(max|dY|) + ceil(log2(weight bound)) <= mean E(dY) + 15,
+ * i.e. the unit is below ~2^-13 of the gradients' geometric mean.  Near-Gaussian gradients pass with 4-9 bits to
+ * spare (a loss scale cancels out); heavy-tailed ones -- dY = N(0,1) x lognormal(sigma = 3) x 128: until round 6
+ * 39 % of the elements were off by more than 1e-4 relative, the median small element by 0.8 % -- make the
+ * workgroup clear its band and sum it again with fp32 compare-and-swap adds, the reference's own arithmetic
+ * (roi_align_v2.cu:67-83): then 9e-7 of the elements differ from the oracle by more than 1e-4 max(1, |want|), the
+ * same as for the float adds alone (two float summation orders differ where a pixel's addends cancel), and
+ * |err| <= 1e-4 max(median|dY|, sum of the pixel's |addends|) holds everywhere.  Non-finite dY (inf AND NaN:
+ * the maximum is taken over bit patterns) and weight bounds above 2048 take the float adds as well.  Callers
+ * that want fp32 adds in every workgroup select them with
  *     sd_set_tuning("roi_align_bwd_fx", 0)
  * (packed arg-max and float arg-max planes alike) at ~1.2-1.5 x the time; the sums then depend on the order
  * in which the hardware serves the adds, like the reference's.
  *   sd_roi_align_v2_bwd on a single map with C % 4 == 0 whose four planes fit 72 KB of LDS (the C4
- * family) runs roi_align_bwd_flt4_kernel (four whole planes per workgroup).  Since round 5 it sums in
- * the same 32-bit fixed point, scaled by max|dY| of the workgroup x a per-PIXEL weight bound taken from
+ * family; square 7x7 / 14x14 pools) runs roi_align_bwd_flt4_kernel (four whole planes per workgroup), which sums
+ * the same way, scaled by max|dY| of the workgroup x a per-pixel weight bound taken from
  * the RoIs' footprints (so `rois` must be the boxes the arg-max planes were produced with, as they are
- * in the operator): bit-reproducible, 4.5e-5 from the exact sums for dY ~ N(0,1) at the C4 shape; the
- * same fall-backs and the same sd_set_tuning("roi_align_bwd_fx", 0) as above.
- * sd_set_tuning("roi_align_bwd_flt4", 0) selects the banded kernel there. */
+ * in the operator): bit-reproducible, 4.9e-5 from the exact sums for dY ~ N(0,1) at the full C4 shape
+ * (2,1024,50,84) x 512 RoIs; the same verdict, the same fall-backs and the same
+ * sd_set_tuning("roi_align_bwd_fx", 0) as above.  sd_set_tuning("roi_align_bwd_flt4", 0) selects the banded
+ * kernel there. */
 /* The same with a device workspace of sd_fpn_roi_align_bwd_workspace_bytes(): the per-band RoI
  * lists are then built by one small pre-pass instead of by every channel's workgroup (same
  * results bit for bit).  workspace may be NULL (= the call above). */
