@@ -132,19 +132,38 @@ __device__ __forceinline__ int wave_scan_i32(int v) {
 // the dynamic range it actually streams and keeps the integer adds only while the unit is below ~2^-13 of the
 // GEOMETRIC mean of its non-zero gradients (the mean itself is useless here: a lognormal's mean sits far out in
 // its tail).  In exponents, all integer and therefore independent of any summation order:
-//     E(max|g|) + ceil(log2(weight bound)) <= mean E(g) + kFxRangeBits      (E = biased fp32 exponent field),
-// the mean taken over a fixed quarter of the stream (the first element of every 16-byte item), zeros and
-// denormals not counted.  Near-Gaussian gradients: E(max) - mean E ~ 3.5-4, so weight bounds up to ~2^11 pass;
+//     E(max|g|) + ceil(log2(weight bound)) <= mean E(g) + kFxRangeBits - 1  (E = biased fp32 exponent field),
+// the mean taken over a fixed sample of the stream (the first element of a 16-byte item; the band kernel looks at
+// every fourth of its trips), zeros and denormals not counted.  Near-Gaussian gradients: E(max) - mean E ~ 3.5-4, so weight bounds up to ~2^11 pass;
 // a loss scale cancels out.  A workgroup that fails takes the fp32 compare-and-swap adds -- the reference's own
 // arithmetic (roi_align_v2.cu:67-83, upstream deformable_col2im: a float atomicAdd per tap).
-constexpr int kFxRangeBits = 15;
+constexpr int kFxRangeBits = 16;   // (the threshold below adds one bit for the optimistic maximum: 15 against the true one)
 __device__ __forceinline__ int fp32_exponent_field(float v) { return (int)((__float_as_uint(v) >> 23) & 255u); }
 __device__ __forceinline__ int ceil_log2_i32(int b) { return b <= 1 ? 0 : 32 - __builtin_clz((unsigned)(b - 1)); }
-// the verdict: exponent sum `se` over `cn` non-zero samples, the streamed maximum, the weight bound's bits
-__device__ __forceinline__ bool fx_range_ok(float gmax, int bound_bits, int se, int cn, int range_bits = kFxRangeBits) {
-  if (gmax == 0.f) return true;      // nothing but zeros
-  if (cn <= 0) return false;         // non-zero values, none of them sampled: no estimate
-  return (long long)(fp32_exponent_field(gmax) + bound_bits - range_bits) * (long long)cn <= (long long)se;
+// The statistic travels as ONE integer per thread / wave / workgroup (one wave reduction, one LDS atomic, one LDS
+// read behind the barrier that ends the scatter anyway -- every instruction in a short-lived workgroup's chain
+// counts: two reductions and a 64-bit verdict cost the headline backward 2 us): per non-zero sample
+//     ((E(g) - e_thr) << 12) + 1,    e_thr = E(optimistic max|g|) + 1 + ceil(log2(weight bound)) - kFxRangeBits,
+// so the upper bits sum the (signed) margins and the low 12 bits count the samples (< 4096 per workgroup: the
+// callers thin their sampling accordingly).  Fine <=> the margins sum to >= 0; when the true maximum turns out more
+// than twice the optimistic one the margins are corrected by the difference of the exponents times the count.
+__device__ __forceinline__ int fx_range_thr(float gmax_used, int bound) {
+  return fp32_exponent_field(gmax_used) + 1 + ceil_log2_i32(bound) - kFxRangeBits;
+}
+__device__ __forceinline__ int fx_range_sample(float v, int e_thr) {
+  const int ex = fp32_exponent_field(v);
+  return ex ? ((ex - e_thr) << 12) + 1 : 0;
+}
+__device__ __forceinline__ bool fx_range_fine(int packed, float gmax_used, float gmax_true) {
+  const int cnt = packed & 4095, margins = packed >> 12;
+  const int extra = fp32_exponent_field(gmax_true) - (fp32_exponent_field(gmax_used) + 1);
+  return margins - (extra > 0 ? extra * cnt : 0) >= 0;
+}
+// trips between samples (a power of two minus one) so that `per_trip` samples per trip over `trips` trips stay < 4096
+__device__ __forceinline__ int fx_range_stride_mask(long per_trip, long trips, int at_least = 0) {
+  int m = at_least;
+  while (per_trip * ((trips + m) / (m + 1)) > 4000) m = 2 * m + 1;
+  return m;
 }
 
 // fp32 add into an LDS word by compare-and-swap.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
                                                                 const unsigned* __restrict__ wsum, int wshift) {
   extern __shared__ __attribute__((aligned(16))) float plane[];
   __shared__ unsigned s_ctl[4];        // [0] max|col| bits of the first trip, [1] of everything, [2] non-finite flag
-  __shared__ int s_exp[2];             // exponent sum / count of the non-zero sampled values (dynamic-range verdict)
+  __shared__ int s_exp[2];             // [0] range margins | sample count of the sampled values (dynamic-range verdict)
   const int P = g.Ho * g.Wo, K2 = g.kh * g.kw;
   const int c0 = blockIdx.x * CC, n = blockIdx.z;
   const int row0 = blockIdx.y * band_rows, row1 = iminr(row0 + band_rows, g.H);
@@ -335,7 +335,10 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
   };
   if (FX && !s_ctl[2]) set_scale(gmax_used);
   unsigned m_all = 0u;
-  int e_sum = 0, e_cnt = 0;
+  // (the unit here is 2^-28 .. 2^-27 of the bound where the RoIAlign planes have 2^-30 .. 2^-29: two bits less range;
+  // sampled: channel 0 of tap 0, the first 16 K pixels -- < 4096 values)
+  int e_acc = 0;
+  const int e_thr = fx_range_thr(gmax_used, (int)ceilf(fminr(weff, 1e9f))) + 2;
   for (int attempt = 0; attempt < 2; ++attempt) {
     for (int tap = 0; tap < K2; ++tap) {
       const int i = tap / g.kw, j = tap % g.kw;
@@ -352,9 +355,7 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
 #pragma unroll
           for (int cc = 0; cc < CC; ++cc) {
             m_all = umaxr(m_all, absbits4(cv[cc]));
-            const int ex = fp32_exponent_field(cv[cc].x);
-            e_sum += ex;
-            e_cnt += ex != 0;
+            if (cc == 0 && tap == 0 && p4 < 16000) e_acc += fx_range_sample(cv[cc].x, e_thr);
           }
         }
         int h_out = p4 / g.Wo, w_out = p4 - h_out * g.Wo;
@@ -407,16 +408,12 @@ __global__ __launch_bounds__(T) void deform_col2im_chunk_kernel(const float* __r
     // was the optimistic maximum enough, and is the unit fine enough for what was streamed?
     wave_max_to(m_all, 1);
     {
-      const int es = wave_sum_i32(e_sum), ec = wave_sum_i32(e_cnt);
-      if ((tid & (kWave - 1)) == 0) {   // integer sums: the order of the waves does not matter
-        atomicAdd(&s_exp[0], es);
-        atomicAdd(&s_exp[1], ec);
-      }
+      const int es = wave_sum_i32(e_acc);
+      if ((tid & (kWave - 1)) == 0) atomicAdd(&s_exp[0], es);   // integer sums: the order of the waves does not matter
     }
     __syncthreads();
     const float gmax_true = __uint_as_float(s_ctl[1]);
-    // (the unit here is 2^-28 .. 2^-27 of the bound where the RoIAlign planes have 2^-30 .. 2^-29: two bits less range)
-    const bool fine = fx_range_ok(gmax_true, ceil_log2_i32((int)ceilf(fminr(weff, 1e9f))), s_exp[0], s_exp[1], kFxRangeBits - 2);
+    const bool fine = fx_range_fine(s_exp[0], gmax_used, gmax_true);
     if (!s_ctl[2] && fine && gmax_true <= 2.f * gmax_used) break;   // also when every value is zero
     __syncthreads();   // every thread has read the verdict before the planes are cleared
     for (int i = tid; i < CC * band_elems; i += T) plane[i] = 0.f;

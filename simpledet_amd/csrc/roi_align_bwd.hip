@@ -576,13 +576,15 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   if (use_fx) wave_max_to(m_all, 2);
   __syncthreads();
   float gmax_used = 0.f;
-  // exponent sum / count of the non-zero first elements of the items this thread streams: the dynamic-range
-  // verdict behind the scatter (kFxRangeBits, common.h)
-  int e_sum = 0, e_cnt = 0;
+  // margins / count of the sampled non-zero gradients this thread streams: the dynamic-range verdict behind the
+  // scatter (kFxRangeBits, common.h)
+  int e_acc = 0, e_thr = 0, e_mask = 3;
   if (use_fx) {
     gmax_used = __uint_as_float((unsigned)nlist[2]);
     if (nlist[3]) use_fx = false;  // non-finite gradients: float adds (a zeroed band is 0 in both formats)
     else set_scale(gmax_used > 0.f ? gmax_used : 1.f);
+    e_thr = fx_range_thr(gmax_used, nlist[1]);
+    e_mask = fx_range_stride_mask(THREADS, ((long)nl * GP + THREADS - 1) / THREADS, 3);   // (every fourth trip at the baseline)
   }
   bool synced = false;  // the scatter is already fenced by a barrier
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -599,11 +601,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
         Item nxt;
         load_item(t + THREADS, cb, nli, nxt);
         m_all = umaxr(m_all, absbits4(cur.g));
-        {
-          const int ex = fp32_exponent_field(cur.g.x);
-          e_sum += ex;
-          e_cnt += ex != 0;
-        }
+        if (((t / THREADS) & e_mask) == 0) e_acc += fx_range_sample(cur.g.x, e_thr);   // (wave uniform)
         if (TAPS) scatter_taps(cur, cur.j);
         else scatter_item(cur, cur.j);
         cur = nxt;
@@ -614,15 +612,12 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
     // the barrier that ends the scatter anyway)
     wave_max_to(m_all, 4);
     {
-      const int es = wave_sum_i32(e_sum), ec = wave_sum_i32(e_cnt);
-      if ((tid & (kWave - 1)) == 0) {   // integer sums: the order of the waves does not matter
-        atomicAdd(nlist + 5, es);
-        atomicAdd(nlist + 6, ec);
-      }
+      const int es = wave_sum_i32(e_acc);
+      if ((tid & (kWave - 1)) == 0) atomicAdd(nlist + 5, es);   // integer sums: the order of the waves does not matter
     }
     __syncthreads();
     const float gmax_true = __uint_as_float((unsigned)nlist[4]);
-    const bool fine = fx_range_ok(gmax_true, ceil_log2_i32(nlist[1]), nlist[5], nlist[6]);
+    const bool fine = fx_range_fine(nlist[5], gmax_used, gmax_true);
     if (!nlist[3] && fine && gmax_true <= 2.f * gmax_used) { synced = true; break; }  // also when all gradients are zero
     __syncthreads();  // every thread has read the verdict before the band is cleared
     // rare: accumulate the band again with the exact maximum, or -- non-finite gradients, a dynamic range the
@@ -709,7 +704,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
   const int H = a.L.H[lvl], W = a.L.W[lvl], HW = H * W, PP = a.PP;
   float* plane = smem;  // [CC][HW]
   int* plane_i = reinterpret_cast<int*>(smem);
-  int* ctl = plane_i + CC * HW;  // [0] weight bound, [1] max|dY| of the first items, [2] non-finite flag, [3] true max|dY|, [4] exponent sum, [5] non-zero count
+  int* ctl = plane_i + CC * HW;  // [0] weight bound, [1] max|dY| of the first items, [2] non-finite flag, [3] true max|dY|, [4] range margins | sample count
   bool use_fx = !a.float_adds;
   if (tid < 8) ctl[tid] = 0;
   if (use_fx) {
@@ -803,13 +798,15 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
   if (use_fx) wave_max_to(m_all, 1);
   __syncthreads();  // the planes are zero, the first maxima are in
   float gmax_used = 0.f;
-  int e_sum = 0, e_cnt = 0;  // exponent sum / count of the non-zero first elements streamed (kFxRangeBits)
+  int e_acc = 0, e_thr = 0, e_mask = 7;  // margins / count of the sampled non-zero gradients (kFxRangeBits, common.h)
   if (use_fx) {
     gmax_used = __uint_as_float((unsigned)ctl[1]);
     // (the non-finite flag has its own barrier-separated read: a wave that reaches the verdict of attempt 0
     // early ORs into ctl[2] only after every wave has passed the barrier above)
     if (ctl[2]) use_fx = false;
     else set_scale(gmax_used > 0.f ? gmax_used : 1.f);
+    e_thr = fx_range_thr(gmax_used, ctl[0]);
+    e_mask = fx_range_stride_mask(THREADS, ((long)nunits + THREADS - 1) / THREADS, 7);
   }
   __syncthreads();  // every wave has read ctl[1] / ctl[2] before a fast wave's verdict can change them
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -818,11 +815,7 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
       Item nxt;
       load_item(u + THREADS, nxt);
       m_all = umaxr(m_all, absbits4(cur.g));
-      {
-        const int ex = fp32_exponent_field(cur.g.x);
-        e_sum += ex;
-        e_cnt += ex != 0;
-      }
+      if (((u / THREADS) & e_mask) == 0) e_acc += fx_range_sample(cur.g.x, e_thr);   // (wave uniform)
       const float gg[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w}, xx[4] = {cur.x.x, cur.x.y, cur.x.z, cur.x.w};
       const float yy[4] = {cur.y.x, cur.y.y, cur.y.z, cur.y.w};
 #pragma unroll
@@ -860,15 +853,12 @@ __global__ __launch_bounds__(THREADS) void roi_align_bwd_flt4_kernel(BwdFusedArg
     // was the optimistic scale enough, and is the unit fine enough for what was streamed?
     wave_max_to(m_all, 3);
     {
-      const int es = wave_sum_i32(e_sum), ec = wave_sum_i32(e_cnt);
-      if ((tid & (kWave - 1)) == 0) {   // integer sums: the order of the waves does not matter
-        atomicAdd(ctl + 4, es);
-        atomicAdd(ctl + 5, ec);
-      }
+      const int es = wave_sum_i32(e_acc);
+      if ((tid & (kWave - 1)) == 0) atomicAdd(ctl + 4, es);   // integer sums: the order of the waves does not matter
     }
     __syncthreads();
     const float gmax_true = __uint_as_float((unsigned)ctl[3]);
-    const bool fine = fx_range_ok(gmax_true, ceil_log2_i32(ctl[0]), ctl[4], ctl[5]);
+    const bool fine = fx_range_fine(ctl[4], gmax_used, gmax_true);
     if (!ctl[2] && fine && gmax_true <= 2.f * gmax_used) break;  // also when all gradients are zero
     __syncthreads();  // every thread has read the verdict before the planes are cleared
     // rare: again, with the exact maximum -- or with float adds (non-finite gradients, a dynamic range the
@@ -1001,7 +991,7 @@ int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace,
   if (tuning("roi_align_bwd_pixbound", 1) == 1)
     for (int i = 0; i < nl; ++i) {
       const int l = a.order[i];
-      const long words = (long)(a.band_rows[l] + 1) * (a.L.W[l] + 1);
+      const long words = (long)(((a.band_rows[l] - 1) >> 2) + 2) * (((a.L.W[l] - 1) >> 2) + 2);   // 4 x 4 cells (bwd_lists_block)
       if (words <= kPixBoundMaxWords && words > a.pix_bound_words) a.pix_bound_words = (int)words;
     }
   if (use_lists && nl < SD_MAX_FPN_LEVELS) {

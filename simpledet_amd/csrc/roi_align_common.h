@@ -310,10 +310,10 @@ struct BwdFusedArgs {
   int lists_units;                   // (level, image, band) units the list pre-pass covers
   int half_io;                       // dy and dx are fp16 (packed arg-max, wide kernel only)
   int float_adds;                    // 1: every workgroup sums with fp32 compare-and-swap adds (tuning key roi_align_bwd_fx = 0)
-  int pix_bound_words;               // list pre-pass: LDS words for the per-pixel weight bound of a band ((rows + 1) * (W + 1)
-                                     // of the largest level that gets one; 0: the bands keep the summed bound)
+  int pix_bound_words;               // list pre-pass: LDS words for the per-cell (4 x 4 pixels) weight bound of a band, of the
+                                     // largest level that gets one; 0: the bands keep the summed bound
 };
-constexpr int kPixBoundMaxWords = 10240;  // 40 KB: bands of up to 36 KB (+ one row and one column)
+constexpr int kPixBoundMaxWords = 10240;  // 40 KB of difference array at most
 
 constexpr int kListSplit = 4;         // 512-thread blocks per unit of the stand-alone list pre-pass
 constexpr int kMergedListSplit = 2;   // 1024-thread blocks per unit inside the merged pre-pass

@@ -218,15 +218,18 @@ __device__ __forceinline__ void bwd_lists_block(const BwdFusedArgs& a, int block
   bwd_band_list<PH, PW, THREADS>(a, lvl, img, nbands, row0, row1, rb0, list, nlist, nlist + 8);
   int* dst = a.ws_list + (long)unit * (a.R + 2);
   const int nl = nlist[0];
-  // Round 6: the weight bound PER PIXEL.  bwd_band_list sums nx * ny over every RoI of the band (1,000-1,800 at
-  // the baseline), but a RoI can put weight only on the pixels of its own clipped box +-2: every RoI adds its
-  // nx * ny to its rectangle of a 2-D difference array of the band, a row prefix (wave scans) and a column
-  // prefix (only its maximum is kept) give the largest bound any pixel of the band can reach -- typically 20-100.
-  // The fixed-point unit of the channel workgroups is 2^-30 of (max|dY| x this bound): an order of magnitude
-  // finer, and an order of magnitude more dynamic range before a workgroup has to take the float adds
-  // (kFxRangeBits).  Done by the unit's extra workgroup (part == PARTS), once per unit and launch.
+  // Round 6: the weight bound per CELL of 4 x 4 pixels.  bwd_band_list sums nx * ny over every RoI of the band
+  // (1,000-1,800 at the baseline), but a RoI can put weight only on the pixels of its own clipped box +-2: every RoI
+  // adds its nx * ny to the rectangle of cells its footprint touches in a 2-D difference array of the band, a row
+  // prefix (wave scans) and a column prefix (only its maximum is kept) give the largest bound any cell -- hence any
+  // pixel -- of the band can reach: typically 30-150.  The fixed-point unit of the channel workgroups is 2^-30 of
+  // (max|dY| x this bound): an order of magnitude finer, and an order of magnitude more dynamic range before a
+  // workgroup has to take the float adds (kFxRangeBits).  (Per pixel the array is 7 k words for a P2 band and its
+  // scans put 2 us on the pre-pass, which the forward waits for; per cell it is 600 words and costs nothing
+  // measurable.)  Done by the unit's extra workgroup (part == PARTS), once per unit and launch.
   const int H = a.L.H[lvl], W = a.L.W[lvl];
-  const int DW = W + 1, DH = row1 - row0 + 1;
+  constexpr int CS = 2;   // log2 of the cell edge
+  const int DW = ((W - 1) >> CS) + 2, DH = ((row1 - row0 - 1) >> CS) + 2;
   const bool pix = DW * DH <= a.pix_bound_words;
   if (part == 0) {
     if (tid == 0) dst[0] = nl;
@@ -255,6 +258,7 @@ __device__ __forceinline__ void bwd_lists_block(const BwdFusedArgs& a, int block
       y0 = imaxr(y0, row0) - row0;
       y1 = iminr(y1, row1 - 1) - row0;
       if (y0 > y1) continue;
+      x0 >>= CS; x1 >>= CS; y0 >>= CS; y1 >>= CS;   // cells
       const float bwx = (rb.z - rb.x) * scale * (1.f / (float)PW), bwy = (rb.w - rb.y) * scale * (1.f / (float)PH);
       const float fx = 2.00002f * __builtin_amdgcn_rcpf(bwx), fy = 2.00002f * __builtin_amdgcn_rcpf(bwy);
       const int nx = (bwx > 0.f && fx < (float)PW) ? iminr((int)fx + 2, PW) : PW;

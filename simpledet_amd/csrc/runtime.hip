@@ -38,7 +38,7 @@ Knob g_knobs[] = {
     {"roi_align_bwd", 0, false},         // 2 (default) fused all-level kernel; 1 per-level LDS planes; 0 global atomics
     {"roi_align_bwd_flt4", 0, false},    // 1 (default): single-level float arg-max backward with four channel planes per workgroup when they fit
     {"roi_align_bwd_fx", 0, false},      // 1 (default): band sums in 32-bit fixed point (bit-reproducible); 0: fp32 compare-and-swap adds, hardware order
-    {"roi_align_bwd_pixbound", 0, false}, // 1 (default): the list pre-pass bounds the weight per PIXEL of a band (2-D difference array); 0: summed over the band's RoIs (what workspace-free calls get)
+    {"roi_align_bwd_pixbound", 0, false}, // 1 (default): the list pre-pass bounds the weight per 4 x 4 pixel cell of a band (2-D difference array); 0: summed over the band's RoIs (what workspace-free calls get)
     {"roi_align_bwd_lists", 0, false},   // workspace pre-pass: 1 RoI lists + tap tables per band unit (default), 2 lists only, 0 none
     {"roi_pool_fwd", 0, false},          // 1 (default) four planes in LDS per workgroup, 2 one plane, 0 wave per (roi, channel)
     {"roi_pool_bwd", 0, false},          // 1 (default) LDS planes, four channels per workgroup, 2 one channel, 0 global atomics

@@ -304,3 +304,81 @@ def test_nan_gradient_is_not_dropped_by_the_fixed_point_paths(ops, oracle, pos):
     np.testing.assert_array_equal(np.isnan(g), np.isnan(w))
     m = ~np.isnan(w)
     assert np.abs(g[m] - w[m]).max() <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ (d)
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["baseline", "piled"])
+def test_weight_bound_of_the_list_pre_pass_equals_its_numpy_statement(ops, oracle, case):
+    """The fixed-point unit of the packed backward rests on the weight bound the list pre-pass leaves per (level,
+    image, band) unit (round 6: the maximum over 4 x 4 pixel cells of the summed nx * ny of the RoIs whose clipped
+    box +-2 touches the cell -- a 2-D difference array, wave scans).  A bound that is too SMALL would let the
+    integer sums wrap silently, so it is restated here in numpy from the rois alone and compared unit by unit with
+    what the device wrote into the plan (`sd_fpn_roi_align_fwd_packed_plan`: [count, bound, RoI indices] per unit)."""
+    import torch
+    f32 = np.float32
+    B, R, C = 2, 512, 8
+    feats = synth.feature_maps(7, batch=B, channels=C)
+    rois = synth.random_rois(7, B, R)
+    if case == "piled":   # 300 copies of one small box: the bound must count every one of them on the same cells
+        rois[0, :300] = np.array([400.0, 300.0, 431.0, 333.0], f32)
+    _, state = ops.fpn_roi_align_forward_packed([_t(f) for f in feats], _t(rois), STRIDES, (7, 7), plan=True)
+    plan = state[2].cpu().numpy().view(np.int32)
+    _, level = oracle.fpn_roi_assign(rois, STRIDES)
+    shapes = [f.shape[2:] for f in feats]
+    # the launcher's band plan (roi_align_bwd.hip launch_bwd_fused: 27 KB bands with the tap tables)
+    nbands, rows = [], []
+    for (H, W) in shapes:
+        nb = max(1, -(-(H * W * 4) // (27 * 1024)))
+        r = -(-H // nb)
+        nbands.append(-(-H // r))
+        rows.append(r)
+    order = sorted(range(4), key=lambda l: (nbands[l], -shapes[l][0] * shapes[l][1]))
+    unit = 0
+    checked = 0
+    for l in order:
+        H, W = shapes[l]
+        scale = f32(1.0 / STRIDES[l])
+        for img in range(B):
+            for band in range(nbands[l]):
+                row0, row1 = band * rows[l], min(band * rows[l] + rows[l], H)
+                rec = plan[unit * (R + 2):(unit + 1) * (R + 2)]
+                unit += 1
+                DW, DH = ((W - 1) >> 2) + 2, ((row1 - row0 - 1) >> 2) + 2
+                D = np.zeros((DH + 1, DW + 1), np.int64)
+                total, want_list = 0, []
+                for r in range(R):
+                    if level[img, r] != l:
+                        continue
+                    x1, y1, x2, y2 = rois[img, r]
+                    clip = lambda v, hi: min(max(f32(v) * scale, f32(0)), f32(hi))
+                    ys, ye = clip(y1, H - 1), clip(y2, H - 1)
+                    ylo, yhi = f32(min(ys, ye) - f32(2)), f32(max(ys, ye) + f32(2))
+                    if nbands[l] > 1 and (yhi < row0 or ylo > row1 - 1):
+                        continue
+                    want_list.append(r)
+                    xs, xe = clip(x1, W - 1), clip(x2, W - 1)
+                    xlo, xhi = f32(min(xs, xe) - f32(2)), f32(max(xs, xe) + f32(2))
+                    bwx = f32(f32(f32(x2 - x1) * scale) * f32(1.0 / 7))
+                    bwy = f32(f32(f32(y2 - y1) * scale) * f32(1.0 / 7))
+                    def nbins(bw):
+                        if not bw > 0:
+                            return 7
+                        fx = f32(f32(2.00002) * f32(f32(1) / bw))
+                        return min(int(fx) + 2, 7) if fx < 7 else 7
+                    w = nbins(bwx) * nbins(bwy)
+                    total += w
+                    X0, X1 = max(int(np.floor(xlo)), 0), min(int(np.ceil(xhi)), W - 1)
+                    Y0, Y1 = max(int(np.floor(ylo)), 0), min(int(np.ceil(yhi)), H - 1)
+                    Y0, Y1 = max(Y0, row0) - row0, min(Y1, row1 - 1) - row0
+                    if Y0 > Y1:
+                        continue
+                    D[Y0 >> 2:(Y1 >> 2) + 1, X0 >> 2:(X1 >> 2) + 1] += w
+                assert rec[0] == len(want_list) and list(rec[2:2 + rec[0]]) == want_list, (l, img, band)
+                want = min(total, int(D.max()))
+                # (the device takes 1 / bin width from v_rcp_f32, 1 ulp: a count may differ where 2.00002 / width lands
+                # on an integer -- never downwards by more than one bin row / column of one RoI)
+                assert abs(int(rec[1]) - want) <= 7, (l, img, band, int(rec[1]), want, total)
+                assert int(rec[1]) >= 0.9 * want
+                checked += 1
+    assert checked == sum(nbands) * B
