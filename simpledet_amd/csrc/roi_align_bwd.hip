@@ -52,6 +52,20 @@ __device__ __forceinline__ void lds_add_fx(long long* p, float v, double scale) 
 __device__ __forceinline__ void lds_add_i32(int* p, float v, float scale) {
   __hip_atomic_fetch_add(p, __float2int_rn(v * scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// The tap-table form of the headline backward (round 6: its workgroups are VALU bound, 69 % of the SIMD cycles,
+// ~50 vector instructions per bin): the value is already scaled, the address is a byte offset into the band (the
+// pre-pass stores its offsets times four), and the conversion is ONE instruction -- v_cvt_rpi_i32_f32,
+// floor(x + 0.5), where __float2int_rn is v_rndne_f32 + v_cvt_i32_f32.  (Round half up instead of half to even: a
+// tie is as far from either neighbour; the sums stay order independent.)
+typedef __attribute__((address_space(3))) int lds_i32;
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {   // LDS byte address of a __shared__ object
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void lds_add_i32_at(unsigned lds_byte_addr, float v) {
+  int q;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(v));
+  __hip_atomic_fetch_add((lds_i32*)(uintptr_t)lds_byte_addr, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // One workgroup owns CPB channel planes (rows [row0,row1) of them) of one image in LDS.
 //   FX = true : int64 fixed-point planes (8 B per pixel), float-CAS fallback on non-finite dY (the only
@@ -322,6 +336,7 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
   int* list = reinterpret_cast<int*>(tab + (FLT ? 0 : TCH * TS));  // RoIs of this image on this band
   int* nlist = list + a.R;  // [0] count [1] bound [2] max|dY| bits, first chunk [3] non-finite [4] max|dY| bits, all
   int* plane_i = reinterpret_cast<int*>(smem);
+  const unsigned plane_lds = lds_offset_of(smem);
 
   // the RoI boxes (or the unit's list) are in flight while the band is zeroed
   int* wcnt = nlist + 8;  // [THREADS / 64] scratch of the list builder
@@ -493,33 +508,34 @@ void roi_align_bwd_packed4(BwdFusedArgs a) {
       if (q == PW) { q = 0; ++p; }
       const int code = (it.code >> (8 * s)) & 0xff;
       if (code == 255) continue;
-      const int k = (code * 11) >> 5, l = code - 3 * k;  // code = 3k + l, k,l in 0..2
-      const float2 re = *reinterpret_cast<const float2*>(tj + 2 * (p * 3 + k));
-      const float2 ce = *reinterpret_cast<const float2*>(tj + 2 * (3 * PH + q * 3 + l));
+      const int k = __mul24(code, 11) >> 5, l = code - __mul24(k, 3);  // code = 3k + l, k,l in 0..2
+      const float2 re = *reinterpret_cast<const float2*>(tj + 2 * (__mul24(p, 3) + k));
+      const float2 ce = *reinterpret_cast<const float2*>(tj + 2 * (3 * PH + __mul24(q, 3) + l));
+      // (the entries hold BYTE offsets into the band: row offsets 4 * (row - row0) * W, 0xffff = outside; columns 4 * col)
       const unsigned rp = __float_as_uint(re.x), cp = __float_as_uint(ce.x);
-      const int o0 = rp & 0xffffu, o1 = rp >> 16, wleft = cp & 0xffffu, wright = cp >> 16;
+      const unsigned o0 = rp & 0xffffu, o1 = rp >> 16, wleft = cp & 0xffffu, wright = cp >> 16;
       const float alpha = re.y, beta = ce.y;
       const float g = use_fx ? gg[s] * fx_scale : gg[s];
       const float w00 = g * (1 - alpha) * (1 - beta), w01 = g * (1 - alpha) * beta;
       const float w10 = g * alpha * (1 - beta), w11 = g * alpha * beta;
       if (use_fx) {
         if (o0 != 0xffff) {
-          lds_add_i32(plane_i + o0 + wleft, w00, 1.f);
-          lds_add_i32(plane_i + o0 + wright, w01, 1.f);
+          lds_add_i32_at(plane_lds + o0 + wleft, w00);
+          lds_add_i32_at(plane_lds + o0 + wright, w01);
         }
         if (o1 != 0xffff) {
-          lds_add_i32(plane_i + o1 + wleft, w10, 1.f);
-          lds_add_i32(plane_i + o1 + wright, w11, 1.f);
+          lds_add_i32_at(plane_lds + o1 + wleft, w10);
+          lds_add_i32_at(plane_lds + o1 + wright, w11);
         }
         continue;
       }
       if (o0 != 0xffff) {
-        lds_add_cas(plane + o0 + wleft, w00);
-        lds_add_cas(plane + o0 + wright, w01);
+        lds_add_cas(plane + ((o0 + wleft) >> 2), w00);
+        lds_add_cas(plane + ((o0 + wright) >> 2), w01);
       }
       if (o1 != 0xffff) {
-        lds_add_cas(plane + o1 + wleft, w10);
-        lds_add_cas(plane + o1 + wright, w11);
+        lds_add_cas(plane + ((o1 + wleft) >> 2), w10);
+        lds_add_cas(plane + ((o1 + wright) >> 2), w11);
       }
     }
   };
@@ -947,6 +963,10 @@ int launch_bwd_fused(BwdFusedArgs& a, int nlvl, hipStream_t st, void* workspace,
     if (int e = plan(27L * 1024, 2)) return e;
     list_bytes = (((size_t)units * (a.R + 2) * sizeof(int)) + 15) & ~(size_t)15;
     use_taps = workspace_bytes >= list_bytes + (size_t)units * a.R * 2 * ne * sizeof(float);
+    // (the tap entries hold 16-bit BYTE offsets into the band: a band wider than 64 KB -- a single row of > 16 K
+    // pixels -- keeps the coordinate-table form)
+    for (int l = 0; l < nlvl; ++l)
+      if (a.dx[l] && (long)a.band_rows[l] * a.L.W[l] * 4 >= 65535) use_taps = false;
     use_lists = use_taps;
   }
   if (!use_taps) {

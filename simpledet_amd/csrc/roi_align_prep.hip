@@ -313,10 +313,11 @@ __device__ __forceinline__ void bwd_lists_block(const BwdFusedArgs& a, int block
       const int lo = iminr(imaxr((int)floorf(v), 0), size - 1);
       const int hi = iminr(imaxr((int)ceilf(v), 0), size - 1);
       const float frac = (lo == hi) ? 0.5f : (v - (float)lo);  // (v - low) / (high - low), high - low == 1
-      unsigned w0 = (unsigned)lo | ((unsigned)hi << 16);
+      // (byte offsets into the band, so that a bin's LDS address is one add: 4 * col, 4 * (row - row0) * W < 65535)
+      unsigned w0 = (unsigned)(4 * lo) | ((unsigned)(4 * hi) << 16);
       if (row) {
-        const unsigned o0 = (lo >= row0 && lo < row1) ? (unsigned)((lo - row0) * W) : 0xffffu;
-        const unsigned o1 = (hi >= row0 && hi < row1) ? (unsigned)((hi - row0) * W) : 0xffffu;
+        const unsigned o0 = (lo >= row0 && lo < row1) ? (unsigned)(4 * (lo - row0) * W) : 0xffffu;
+        const unsigned o1 = (hi >= row0 && hi < row1) ? (unsigned)(4 * (hi - row0) * W) : 0xffffu;
         w0 = o0 | (o1 << 16);
       }
       *reinterpret_cast<float2*>(tdst + (long)j * (2 * NE) + 2 * e) = make_float2(__uint_as_float(w0), frac);
