@@ -28,6 +28,7 @@ struct GemmArgs {
   int ablate;  // profiling build only: bit 0 skip the A prefetch, bit 1 skip the B prefetch
   const unsigned* amax;  // f16 split: bit patterns of max|A|, max|B| (upper bounds), device memory
   int vec_store;         // split kernel: C rows are 16-byte aligned and N % 4 == 0 (plain stores leave as whole tile rows)
+  int nt_store;          // split kernel: those stores are non-temporal
 };
 
 constexpr int BM = 128;  // the N extent of a tile is 64 * J (J = 1, 2, 3), see launch_gemm
@@ -467,10 +468,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(GemmArgs a) {
         q[k] = *reinterpret_cast<const float4*>(smem + (c0 + k) * 512 + (((r0 >> 2) ^ swz(c0 + k)) << 4));
       if (n0 + c0 < a.N) {   // (N % 4 == 0: a block of four columns is inside or outside as a whole)
         float* cp = C + (long)(m0 + r0) * a.ldc + n0 + c0;
-        if (m0 + r0 + 0 < a.M) *reinterpret_cast<float4*>(cp) = make_float4(q[0].x, q[1].x, q[2].x, q[3].x);
-        if (m0 + r0 + 1 < a.M) *reinterpret_cast<float4*>(cp + a.ldc) = make_float4(q[0].y, q[1].y, q[2].y, q[3].y);
-        if (m0 + r0 + 2 < a.M) *reinterpret_cast<float4*>(cp + 2L * a.ldc) = make_float4(q[0].z, q[1].z, q[2].z, q[3].z);
-        if (m0 + r0 + 3 < a.M) *reinterpret_cast<float4*>(cp + 3L * a.ldc) = make_float4(q[0].w, q[1].w, q[2].w, q[3].w);
+        // Non-temporal (round 6): a whole-tile product streams its C (619 MB for the dcol product) through an L2 whose other
+        // tenant is the shared operand every tile re-reads; the product alone 0.469 -> 0.362 ms on a fresh C, the layer's
+        // backward 1.47 -> 1.44 (its consumers then find less of dcol in the memory-side cache): profiles/r06h_*
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v o0 = {q[0].x, q[1].x, q[2].x, q[3].x}, o1 = {q[0].y, q[1].y, q[2].y, q[3].y};
+        const f4v o2 = {q[0].z, q[1].z, q[2].z, q[3].z}, o3 = {q[0].w, q[1].w, q[2].w, q[3].w};
+        if (a.nt_store) {
+          if (m0 + r0 + 0 < a.M) __builtin_nontemporal_store(o0, reinterpret_cast<f4v*>(cp));
+          if (m0 + r0 + 1 < a.M) __builtin_nontemporal_store(o1, reinterpret_cast<f4v*>(cp + a.ldc));
+          if (m0 + r0 + 2 < a.M) __builtin_nontemporal_store(o2, reinterpret_cast<f4v*>(cp + 2L * a.ldc));
+          if (m0 + r0 + 3 < a.M) __builtin_nontemporal_store(o3, reinterpret_cast<f4v*>(cp + 3L * a.ldc));
+        } else {
+          if (m0 + r0 + 0 < a.M) *reinterpret_cast<f4v*>(cp) = o0;
+          if (m0 + r0 + 1 < a.M) *reinterpret_cast<f4v*>(cp + a.ldc) = o1;
+          if (m0 + r0 + 2 < a.M) *reinterpret_cast<f4v*>(cp + 2L * a.ldc) = o2;
+          if (m0 + r0 + 3 < a.M) *reinterpret_cast<f4v*>(cp + 3L * a.ldc) = o3;
+        }
       }
     }
     return;
@@ -584,6 +598,7 @@ static int launch_gemm(GemmArgs& g, int batch, hipStream_t st) {
              aligned(g.B, bk, g.sbn, g.sbk, g.strideB, g.N);
     g.vec_store = (((uintptr_t)g.C & 15) == 0 && g.ldc % 4 == 0 && g.strideC % 4 == 0 && g.N % 4 == 0 &&
                    tuning("deform_gemm_vecstore", 1) == 1) ? 1 : 0;
+    g.nt_store = tuning("deform_gemm_nt", 1);
     int e;
     if (ak && bk) e = launch_gemm_split<true, true>(g, grid, st);
     else if (ak) e = launch_gemm_split<true, false>(g, grid, st);

@@ -46,6 +46,7 @@ Knob g_knobs[] = {
     {"soft_nms_threads", 0, false},      // threads per problem: 64, 128 or 256 (default)
     {"deform_gemm_split", 0, false},     // 2 (default): scaled fp16 hi/lo split (needs operand maxima); 1: bf16 hi/lo split; 0: fp32 MFMA
     {"deform_gemm_vecstore", 0, false},  // 1 (default): whole-tile plain stores of the split GEMM leave as 512-byte tile rows through LDS; 0: element stores from the accumulator layout (what unaligned C gets)
+    {"deform_gemm_nt", 0, false},        // 1 (default): those whole-tile stores are non-temporal; 0: plain
     {"deform_gemm_ksplit", 0, false},    // 1 (default): tiles of a mostly empty last round are cut into k slices (atomic adds)
     {"dcn_im2col", 0, false},            // 1 LDS-plane im2col (default), 0 per-lane global gathers
     {"dcn_window", 0, false},            // 1 stage only the touched range of each plane (default)

@@ -237,6 +237,12 @@ def test_gemm_tile_rows_through_lds_are_the_same_bits(ops, shape):
     finally:
         lib().set_tuning("deform_gemm_vecstore", 1)
     assert torch.equal(got, want)
+    lib().set_tuning("deform_gemm_nt", 0)   # (round 6: those row stores are non-temporal by default; plain ones: same bits)
+    try:
+        plain = ops.gemm_f32(a, b, trans_a=True)
+    finally:
+        lib().set_tuning("deform_gemm_nt", 1)
+    assert torch.equal(got, plain)
     ref = torch.bmm(a.double().transpose(1, 2), b.double())
     assert float((got.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
 
