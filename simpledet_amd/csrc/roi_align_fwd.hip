@@ -1034,13 +1034,38 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(BandArgs A) {
     // of the RoIs that pool nothing), after the band work: workgroup = (RoI slot, channel slice).
     // (As blocks of their own in front of the launch they delayed every band workgroup's start.) ----
     const int nroi = a.B * a.R;
+    // Round 6: the RoIs that pool nothing (flag 2) of the float arg-max form first, as whole (RoI, all channels) blocks of
+    // constants -- C * 49 contiguous floats per output -- with 16-byte stores, one RoI per workgroup and trip.  In the
+    // un-fused FPN graph (models/FPN/builder.py:588-605) three quarters of a level op's RoIs are such rows (zero boxes of
+    // the other levels): 115 MB of a 154 MB output; walked below as (RoI, channel slice) tasks of element stores, each behind
+    // its own dependent load of the box, they were the tail of the launch.
+    bool fast_void = false;
+    if constexpr (!PK && !HALF) {
+      fast_void = (((uintptr_t)a.out | (uintptr_t)a.ax | (uintptr_t)a.ay) & 15) == 0 && (a.C * PPG) % 4 == 0;
+      if (fast_void) {
+        const int n4 = a.C * PPG / 4;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f), neg = make_float4(-1.f, -1.f, -1.f, -1.f);
+        for (int n = wg; n < nroi; n += nwg) {
+          if (P.fbflag[n] != 2) continue;   // (uniform)
+          float4* o4 = reinterpret_cast<float4*>(a.out + (long)n * a.C * PPG);
+          float4* x4 = reinterpret_cast<float4*>(a.ax + (long)n * a.C * PPG);
+          float4* y4 = reinterpret_cast<float4*>(a.ay + (long)n * a.C * PPG);
+          for (int i = tid; i < n4; i += kBandThreads) {
+            o4[i] = zero;
+            x4[i] = neg;
+            y4[i] = neg;
+          }
+        }
+      }
+    }
     const int nsl = nwg >= a.fbslice ? a.fbslice : 1, csl = a.C / nsl, slice = wg % nsl;
     const int nslots = nwg / nsl;
     // the flags of this workgroup's RoIs are fetched 64 at a time by every wave (one load each,
     // not a chain of dependent loads), then only the flagged ones are visited
     for (int n0 = wg / nsl; n0 < nroi && wg / nsl < nslots; n0 += nslots * kWave) {
       const int nl = n0 + lane * nslots;
-      const int myflag = nl < nroi ? P.fbflag[nl] : 0;
+      int myflag = nl < nroi ? P.fbflag[nl] : 0;
+      if (fast_void && myflag == 2) myflag = 0;   // written above
       unsigned long long todo = __ballot(myflag != 0);
       while (todo) {
       const int src = __builtin_ctzll(todo);
