@@ -211,10 +211,13 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     backend = os.environ.get("SD_BENCH_BACKEND", "nccl")  # "gloo": launcher-path test on CPU boxes
+    # SD_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, collectives, the all-reduce legs) with ONE rank --
+    # how the RCCL side of this file is exercised on a single-GPU box (`torchrun --nproc-per-node 1 bench.py --gpus 1`)
+    multi = world > 1 or os.environ.get("SD_BENCH_FORCE_DIST") == "1"
     use_cuda = backend == "nccl"
     if use_cuda:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": torch.device("cuda", local_rank)} if use_cuda else {}
         dist.init_process_group(backend, **kw)
@@ -239,10 +242,10 @@ def main():
     out_shape = (args.images, args.rois, args.channels, 7, 7)
     dy = torch.randn(out_shape, device="cuda")
     d_feats = [torch.empty_like(f) for f in feats]
-    grad_mb = args.grad_allreduce if args.grad_allreduce >= 0 else (R50_FPN_GRAD_MB if world > 1 else 0.0)
+    grad_mb = args.grad_allreduce if args.grad_allreduce >= 0 else (R50_FPN_GRAD_MB if multi else 0.0)
     reducer = None
     rccl_ranks = 1
-    if world > 1:
+    if multi:
         # a real collective before anything is timed: every rank contributes 1
         one = torch.ones(1, device="cuda")
         dist.all_reduce(one)
@@ -279,7 +282,7 @@ def main():
         state["arg"] = (ax, ay) if args.float_argmax else am
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -294,7 +297,7 @@ def main():
         step()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not multi:
             return x, [x]
         t = torch.tensor([x], device="cuda", dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
@@ -321,7 +324,7 @@ def main():
     elapsed, vals = max_over_ranks(elapsed_local)
     per_rank_ms = [v * 1e3 / args.steps for v in vals]
     scaling = {}
-    if world > 1:
+    if multi:
         # afterwards, outside the timed region: rank 0 alone (the N = 1 figure of this box in this
         # invocation), then the reference's gradient all-reduce beside the path
         t_single = leg_single_rank(step, barrier, args, rank, torch.device("cuda"))
@@ -401,7 +404,7 @@ def main():
         del src, dst
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -639,7 +642,7 @@ def main():
     line.update(extra)
     print(json.dumps(line))
     sys.stdout.flush()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

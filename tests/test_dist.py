@@ -155,3 +155,32 @@ def test_bench_self_launch_two_ranks_gloo():
     # the composite leg contains the path's steps plus the collective: it cannot be faster than ~the path
     assert ga["ops_plus_allreduce_ms_per_step"] >= 0.2 * d["ms_per_step"]
     assert len(d["per_rank_ms_per_step"]) == 2
+
+
+@pytest.mark.gpu
+def test_bench_rccl_code_path_with_one_rank():
+    """Round 6 ("missing" 1: no RCCL rank had ever executed bench.py's N > 1 code): the whole N > 1 path --
+    process group on backend nccl (= RCCL) with `device_id`, the all-reduce of ones, barriers, the all-gather of the
+    per-rank times, the broadcast of rank 0's solo leg, `OverlappedAllReduce` on its side stream started behind the
+    forward and joined at the end of the step -- under torchrun with ONE rank, which is what a single-GPU box can run
+    (SD_BENCH_FORCE_DIST=1; RCCL refuses two ranks on one device).  A communicator of size one still goes through
+    RCCL's enqueue / stream-ordering code; what it cannot show is bandwidth."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SD_BENCH_FORCE_DIST"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-ops", "--no-extra"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["value"] > 0
+    assert d["n1_ms_per_step_same_invocation"] > 0 and len(d["per_rank_ms_per_step"]) == 1
+    ga = d["grad_allreduce"]
+    assert ga["mb_per_step"] == 165.0 and ga["alone_ms"] >= 0 and ga["ops_plus_allreduce_ms_per_step"] > 0
